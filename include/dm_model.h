@@ -1,0 +1,128 @@
+/*
+ * dm_model.h — POD description of a compiled humanoid model ("DmModel").
+ *
+ * This is a DATA FORMAT, not code: it is what the host-side MJCF compiler
+ * (deepmimic_mujoco_amd/model.py) emits after reading
+ * deepmimic_humanoid3d.xml (reference: src/mujoco/humanoid_deepmimic/envs/asset/
+ * deepmimic_humanoid3d.xml:1-157), and what both the HIP library
+ * (include/deepmimic_hip.h: dm_create) and the CPU oracle (oracle/dm_oracle.h)
+ * consume.  In the reference this role is played by mujoco-py's `MjModel`
+ * loaded by gym's MujocoEnv (src/deepmimic_env.py:301).
+ *
+ * Dimensions of the 34-DoF humanoid3d model are compile-time constants so the
+ * HIP kernels can keep per-row Jacobians in registers with static indexing.
+ * Everything is double; the HIP library converts to fp32 tables internally.
+ */
+#ifndef DM_MODEL_H
+#define DM_MODEL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DM_NQ 35
+#define DM_NV 34
+#define DM_NU 28
+#define DM_NBODY 14     /* incl. world body 0 */
+#define DM_NGEOM 16     /* incl. floor plane 0 */
+#define DM_NJNT 29      /* free root + 28 hinges */
+#define DM_NM 310       /* non-zeros of the sparse joint-space inertia */
+#define DM_MAXPAIR 128  /* capacity of the collision candidate table (104 used) */
+#define DM_NOBS 67      /* DPEnv observation (src/deepmimic_env.py:33-45) */
+#define DM_NEE 4        /* end-effector geoms (src/config.py:12) */
+#define DM_MAXCON 64    /* contact slots kept per env per forward evaluation */
+#define DM_MAXROW 128   /* constraint rows kept per env per forward evaluation */
+
+/* geom types follow MuJoCo's mjtGeom numbering [EXT] so that the
+ * "lower type first" pair ordering is reproduced. */
+#define DM_GEOM_PLANE 0
+#define DM_GEOM_SPHERE 2
+#define DM_GEOM_CAPSULE 3
+#define DM_GEOM_BOX 6
+
+#define DM_JNT_FREE 0
+#define DM_JNT_HINGE 3
+
+#define DM_INT_EULER 0
+#define DM_INT_RK4 1
+
+typedef struct DmModel {
+  int32_t nq, nv, nu, nbody, ngeom, njnt, npair, nM;
+  int32_t integrator;   /* DM_INT_* (xml :9 integrator="RK4") */
+  int32_t iterations;   /* PGS sweeps cap (xml :9 iterations="50") */
+  int32_t pad0, pad1;
+  double timestep;      /* xml :9 */
+  double tolerance;     /* MuJoCo default 1e-8 [EXT] */
+  double gravity[3];
+  double meaninertia;   /* mean diag(M(qpos0)) — PGS termination scale [EXT] */
+  double solref[2];     /* (0.02, 1) [EXT default] */
+  double solimp[5];     /* (0.9, 0.95, 0.001, 0.5, 2) [EXT default] */
+  double qpos0[DM_NQ];
+
+  /* bodies */
+  int32_t body_parent[DM_NBODY];
+  int32_t body_jntadr[DM_NBODY];
+  int32_t body_jntnum[DM_NBODY];
+  int32_t body_dofadr[DM_NBODY];
+  int32_t body_dofnum[DM_NBODY];
+  int32_t body_depth[DM_NBODY];       /* world 0, root 1, ... */
+  double body_pos[DM_NBODY][3];       /* in parent frame */
+  double body_quat[DM_NBODY][4];      /* wxyz, in parent frame */
+  double body_ipos[DM_NBODY][3];      /* COM in body frame */
+  double body_inertia[DM_NBODY][6];   /* about COM, body axes: xx yy zz xy xz yz */
+  double body_mass[DM_NBODY];
+  double body_invweight0[DM_NBODY][2];/* translational, rotational [EXT mj_setConst] */
+
+  /* joints */
+  int32_t jnt_type[DM_NJNT];
+  int32_t jnt_body[DM_NJNT];
+  int32_t jnt_qposadr[DM_NJNT];
+  int32_t jnt_dofadr[DM_NJNT];
+  int32_t jnt_limited[DM_NJNT];
+  double jnt_pos[DM_NJNT][3];
+  double jnt_axis[DM_NJNT][3];
+  double jnt_range[DM_NJNT][2];
+
+  /* dofs */
+  int32_t dof_body[DM_NV];
+  int32_t dof_jnt[DM_NV];
+  int32_t dof_parent[DM_NV];          /* -1 for none */
+  int32_t dof_Madr[DM_NV];            /* start of row i in the sparse M: M(i,i), M(i,parent), ... */
+  double dof_armature[DM_NV];
+  double dof_damping[DM_NV];
+  double dof_invweight0[DM_NV];
+
+  /* geoms */
+  int32_t geom_type[DM_NGEOM];
+  int32_t geom_body[DM_NGEOM];
+  int32_t geom_condim[DM_NGEOM];
+  double geom_pos[DM_NGEOM][3];       /* in body frame */
+  double geom_quat[DM_NGEOM][4];
+  double geom_size[DM_NGEOM][3];
+  double geom_friction[DM_NGEOM][3];
+  double geom_margin[DM_NGEOM];
+  double geom_rbound[DM_NGEOM];
+
+  /* actuators (motors on hinges) */
+  int32_t act_dof[DM_NU];
+  double act_gear[DM_NU];
+  double act_ctrlrange[DM_NU][2];
+
+  /* collision candidates in canonical contact order: sorted by
+   * (body1, body2), then geom order inside the bodies; inside one pair the
+   * geom with the lower type id is geom1 [EXT mj_collideGeoms]. */
+  int32_t pair_geom1[DM_MAXPAIR];
+  int32_t pair_geom2[DM_MAXPAIR];
+
+  /* task constants (src/config.py:6-13, src/deepmimic_env.py:258-270) */
+  int32_t ee_geom[DM_NEE];            /* left_ankle,right_ankle,left_wrist,right_wrist */
+  int32_t torso_body;                 /* chest */
+  int32_t rfoot_geom, lfoot_geom, floor_geom;
+} DmModel;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DM_MODEL_H */

@@ -1,0 +1,128 @@
+/*
+ * dm_oracle.h — CPU oracle (TEST INFRASTRUCTURE, not product code).
+ *
+ * A scalar fp64 restatement, one environment at a time, of the reference hot
+ * path: DPEnv.step() (src/deepmimic_env.py:335-484) down through
+ * MujocoEnv.do_simulation -> mujoco_py.MjSim.step -> libmujoco mj_step.
+ *
+ * PARITY STATUS: the physics arithmetic of the reference lives in MuJoCo
+ * 2.0/2.1.0 (closed binary at those versions, absent from /root/reference,
+ * README.md:24, src/sb3_ppo.py:345).  It is restated here from MuJoCo's
+ * published "Computation" documentation.  No golden
+ * vector produced by MuJoCo exists in the reference tree, so the physics part
+ * is "PARITY UNPINNED"; the env semantics, mocap pipeline and policy MLP are
+ * pinned by fixtures under tests/golden.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * call into this library.
+ */
+#ifndef DM_ORACLE_H
+#define DM_ORACLE_H
+
+#include "../include/dm_model.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMO_MAXCON 100 /* MuJoCo default nconmax [EXT] */
+#define DMO_MAXROW 500 /* MuJoCo default njmax [EXT] */
+
+typedef struct DmoContact {
+  double dist;
+  double pos[3];
+  double frame[9]; /* rows: normal (geom1->geom2), tangent1, tangent2 */
+  double includemargin;
+  double mu;
+  int32_t geom1, geom2, dim, pair;
+  int32_t efc_address, pad;
+} DmoContact;
+
+typedef struct DmoData {
+  /* ---- state (what persists between steps) ---- */
+  double qpos[DM_NQ];
+  double qvel[DM_NV];
+  double ctrl[DM_NU];
+  double qacc_warmstart[DM_NV];
+  double time;
+  /* ---- caps (runtime; default MuJoCo's, tests may lower to match the HIP build) ---- */
+  int32_t maxcon, maxrow;
+  /* ---- derived by the last forward evaluation ---- */
+  double xpos[DM_NBODY][3], xquat[DM_NBODY][4], xmat[DM_NBODY][9], xipos[DM_NBODY][3];
+  double xanchor[DM_NJNT][3], xaxis[DM_NJNT][3];
+  double geom_xpos[DM_NGEOM][3], geom_xmat[DM_NGEOM][9];
+  double subtree_com[3]; /* COM of the whole kinematic tree (root body 1) */
+  double cinert[DM_NBODY][10], crb[DM_NBODY][10];
+  double cdof[DM_NV][6], cdof_dot[DM_NV][6];
+  double cvel[DM_NBODY][6];
+  double qM[DM_NM], qLD[DM_NM], qLDiagInv[DM_NV], qLDiagSqrtInv[DM_NV];
+  double qfrc_bias[DM_NV], qfrc_passive[DM_NV], qfrc_actuator[DM_NV], qfrc_smooth[DM_NV];
+  double qfrc_constraint[DM_NV];
+  double qacc_smooth[DM_NV], qacc[DM_NV];
+  int32_t ncon, nefc, solver_iter, nlimit;
+  int32_t overflow_con, overflow_row; /* counts of dropped contacts / rows */
+  DmoContact contact[DMO_MAXCON];
+  int32_t efc_type[DMO_MAXROW], efc_id[DMO_MAXROW]; /* 0 limit, 1 frictionless, 2 pyramidal */
+  double efc_pos[DMO_MAXROW], efc_margin[DMO_MAXROW], efc_diagApprox[DMO_MAXROW];
+  double efc_R[DMO_MAXROW], efc_D[DMO_MAXROW], efc_vel[DMO_MAXROW], efc_aref[DMO_MAXROW];
+  double efc_b[DMO_MAXROW], efc_force[DMO_MAXROW];
+  double *efc_J;  /* maxrow x nv  (heap) */
+  double *efc_AR; /* maxrow x maxrow (heap) */
+} DmoData;
+
+/* motion clip tables (src/mujoco/mocap_v2.py:338-348 getters) */
+typedef struct DmoClip {
+  int32_t L;
+  const double *qpos;      /* L x 35 */
+  const double *qvel;      /* L x 34 */
+  const double *body_xpos; /* L x 14 x 3 */
+  const double *geom_xpos; /* L x 16 x 3 */
+} DmoClip;
+
+/* per-env task state (DPEnv attributes idx_curr, episode_length, ...) */
+typedef struct DmoEnv {
+  int32_t idx_curr, episode_length;
+  double episode_reward;
+} DmoEnv;
+
+enum { DMO_REASON_NONE = 0, DMO_REASON_LOW_Z = 1, DMO_REASON_HIGH_Z = 2,
+       DMO_REASON_MAX_EP_LEN = 3, DMO_REASON_ACYCLIC_END = 4,
+       DMO_REASON_SIM_ERROR = 5, DMO_REASON_OBS_BOUNDS = 6 };
+
+DmoData *dmo_data_new(const DmModel *m);
+void dmo_data_free(DmoData *d);
+void dmo_data_reset(const DmModel *m, DmoData *d); /* qpos0, zeros */
+
+/* mj_forward / mj_step equivalents; return 0, or 1 if a NaN/huge value was met
+ * (MuJoCo would reset and mujoco-py raise MujocoException [EXT]). */
+int dmo_forward(const DmModel *m, DmoData *d);
+int dmo_step(const DmModel *m, DmoData *d);
+
+/* MujocoEnv.set_state + sim.forward (src/deepmimic_env.py:355-357,508) */
+int dmo_set_state(const DmModel *m, DmoData *d, const double *qpos, const double *qvel);
+
+/* src/deepmimic_env.py:33-45 (DPEnvConfig flags of :258-270) */
+void dmo_get_obs(const DmModel *m, const DmoData *d, int idx_curr, int L, double *obs67);
+/* src/deepmimic_env.py:193-256; terms5 = reward_config, qvel, end_eff, com, joint_limit */
+double dmo_reward(const DmModel *m, const DmoData *d, const DmoClip *clip, int idx, double *terms5);
+
+/* Full DPEnv.step (src/deepmimic_env.py:335-484).  force_qpos/force_qvel may be NULL.
+ * Outputs: obs67, *reward, terms5, *reason; returns done (0/1). */
+int dmo_env_step(const DmModel *m, DmoData *d, DmoEnv *e, const DmoClip *clip,
+                 const double *action, const double *force_qpos, const double *force_qvel,
+                 double *obs67, double *reward, double *terms5, int32_t *reason);
+/* DPEnv.reset / reset_model(idx_init) (src/deepmimic_env.py:496-510) */
+int dmo_env_reset(const DmModel *m, DmoData *d, DmoEnv *e, const DmoClip *clip, int idx_init,
+                  double *obs67);
+
+/* rotation helpers exposed for tests */
+void dmo_quat_to_rpy(const double *wxyz, double *rpy);
+
+/* Batched CPU baseline driver used by bench.py: runs `nsteps` random-torque
+ * DPEnv.step()s on `nenv` envs (auto-reset to frame (env+step) %% L), single thread. */
+double dmo_bench_steps(const DmModel *m, const DmoClip *clip, int nenv, int nsteps, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,185 @@
+"""ctypes wrapper around oracle/libdm_oracle.so — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product package (deepmimic_mujoco_amd) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from deepmimic_mujoco_amd.model import NQ, NV, NBODY, NGEOM, NOBS
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class _Clip(C.Structure):
+    _fields_ = [("L", C.c_int32), ("qpos", C.c_void_p), ("qvel", C.c_void_p),
+                ("body_xpos", C.c_void_p), ("geom_xpos", C.c_void_p)]
+
+
+class _Env(C.Structure):
+    _fields_ = [("idx_curr", C.c_int32), ("episode_length", C.c_int32),
+                ("episode_reward", C.c_double)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libdm_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.dmo_data_new.restype = C.c_void_p
+        L.dmo_data_new.argtypes = [C.c_void_p]
+        L.dmo_data_free.argtypes = [C.c_void_p]
+        L.dmo_data_reset.argtypes = [C.c_void_p, C.c_void_p]
+        for f in (L.dmo_forward, L.dmo_step):
+            f.argtypes = [C.c_void_p, C.c_void_p]
+            f.restype = C.c_int
+        L.dmo_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dmo_get_obs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.dmo_reward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.dmo_reward.restype = C.c_double
+        L.dmo_env_step.argtypes = [C.c_void_p] * 11
+        L.dmo_env_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.dmo_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
+        L.dmo_set.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
+        L.dmo_get_int.argtypes = [C.c_void_p, C.c_char_p]
+        L.dmo_set_caps.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.dmo_quat_to_rpy.argtypes = [C.c_void_p, C.c_void_p]
+        L.dmo_bench_steps.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64]
+        L.dmo_bench_steps.restype = C.c_double
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleClip:
+    def __init__(self, qpos, qvel, body_xpos, geom_xpos):
+        self.qpos = np.ascontiguousarray(qpos, np.float64).reshape(-1, NQ)
+        self.qvel = np.ascontiguousarray(qvel, np.float64).reshape(-1, NV)
+        self.body_xpos = np.ascontiguousarray(body_xpos, np.float64).reshape(-1, NBODY, 3)
+        self.geom_xpos = np.ascontiguousarray(geom_xpos, np.float64).reshape(-1, NGEOM, 3)
+        self.L = len(self.qpos)
+        self.c = _Clip(self.L, _p(self.qpos).value, _p(self.qvel).value,
+                       _p(self.body_xpos).value, _p(self.geom_xpos).value)
+
+
+class OracleSim:
+    """One fp64 environment: physics state + DPEnv task state."""
+
+    SHAPES = {"xpos": (NBODY, 3), "xquat": (NBODY, 4), "xmat": (NBODY, 9), "xipos": (NBODY, 3),
+              "geom_xpos": (NGEOM, 3), "geom_xmat": (NGEOM, 9), "cvel": (NBODY, 6),
+              "cdof": (NV, 6), "cdof_dot": (NV, 6), "cinert": (NBODY, 10)}
+
+    def __init__(self, model):
+        self.model = model
+        self.cm = model.cstruct
+        self.L = lib()
+        self.d = self.L.dmo_data_new(C.byref(self.cm))
+        self.env = _Env(0, 0, 0.0)
+
+    def __del__(self):
+        try:
+            self.L.dmo_data_free(self.d)
+        except Exception:
+            pass
+
+    def get(self, name):
+        buf = np.zeros(500 * 500, np.float64)
+        n = self.L.dmo_get(self.d, name.encode(), _p(buf), buf.size)
+        if n < 0:
+            raise KeyError(name)
+        out = buf[:n].copy()
+        if name in self.SHAPES:
+            out = out.reshape(self.SHAPES[name])
+        elif name == "efc_J":
+            out = out.reshape(-1, NV)
+        elif name == "efc_AR":
+            k = self.nefc
+            out = out.reshape(k, k)
+        elif name == "contact":
+            out = out.reshape(-1, 17)
+        return out
+
+    def set(self, name, val):
+        a = np.ascontiguousarray(val, np.float64).ravel()
+        if self.L.dmo_set(self.d, name.encode(), _p(a), a.size) != 0:
+            raise KeyError(name)
+
+    def geti(self, name):
+        return self.L.dmo_get_int(self.d, name.encode())
+
+    ncon = property(lambda s: s.geti("ncon"))
+    nefc = property(lambda s: s.geti("nefc"))
+
+    def set_caps(self, maxcon, maxrow):
+        assert self.L.dmo_set_caps(self.d, maxcon, maxrow) == 0
+
+    def reset_data(self):
+        self.L.dmo_data_reset(C.byref(self.cm), self.d)
+
+    def forward(self):
+        return self.L.dmo_forward(C.byref(self.cm), self.d)
+
+    def step(self):
+        return self.L.dmo_step(C.byref(self.cm), self.d)
+
+    def set_state(self, qpos, qvel):
+        q = np.ascontiguousarray(qpos, np.float64)
+        v = np.ascontiguousarray(qvel, np.float64)
+        return self.L.dmo_set_state(C.byref(self.cm), self.d, _p(q), _p(v))
+
+    def get_obs(self, idx_curr, L):
+        obs = np.zeros(NOBS)
+        self.L.dmo_get_obs(C.byref(self.cm), self.d, idx_curr, L, _p(obs))
+        return obs
+
+    def reward(self, clip, idx):
+        t = np.zeros(5)
+        r = self.L.dmo_reward(C.byref(self.cm), self.d, C.byref(clip.c), idx, _p(t))
+        return r, t
+
+    def env_reset(self, clip, idx_init):
+        obs = np.zeros(NOBS)
+        self.L.dmo_env_reset(C.byref(self.cm), self.d, C.byref(self.env), C.byref(clip.c), idx_init, _p(obs))
+        return obs
+
+    def env_step(self, clip, action, force_state=None):
+        obs = np.zeros(NOBS)
+        rew = C.c_double(0)
+        terms = np.zeros(5)
+        reason = C.c_int32(0)
+        a = np.ascontiguousarray(action, np.float64)
+        if force_state is not None:
+            fq = np.ascontiguousarray(force_state[0], np.float64)
+            fv = np.ascontiguousarray(force_state[1], np.float64)
+            pq, pv = _p(fq), _p(fv)
+        else:
+            pq = pv = None
+        done = self.L.dmo_env_step(C.byref(self.cm), self.d, C.byref(self.env), C.byref(clip.c), _p(a),
+                                   pq, pv, _p(obs), C.byref(rew), _p(terms), C.byref(reason))
+        return obs, rew.value, bool(done), terms, reason.value
+
+
+def quat_to_rpy(q):
+    q = np.ascontiguousarray(q, np.float64)
+    out = np.zeros(3)
+    lib().dmo_quat_to_rpy(_p(q), _p(out))
+    return out
+
+
+def bench_steps(model, clip, nenv, nsteps, seed=1234):
+    return lib().dmo_bench_steps(C.byref(model.cstruct), C.byref(clip.c), nenv, nsteps, seed)
