@@ -1,0 +1,210 @@
+"""ctypes binding of libdeepmimic_hip.so (include/deepmimic_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing or no MI355X is visible
+the constructor of :class:`HipEngine` raises.  PyTorch is used only as the owner
+of device buffers (``tensor.data_ptr()``) and of the HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .model import DmModel, NQ, NV, NU, NOBS
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdeepmimic_hip.so")
+DEBUG_STRIDE = 416
+
+REASONS = {0: None, 1: "low_z", 2: "high_z", 3: "max_ep_len", 4: "acyclical_end",
+           5: "sim_error", 6: "obs_out_of_bounds"}
+
+EXPORTS = ["dm_default_config", "dm_create", "dm_destroy", "dm_last_error", "dm_num_envs",
+           "dm_load_clip", "dm_set_env_clips", "dm_reset", "dm_step", "dm_step_forced",
+           "dm_set_state", "dm_get_state", "dm_get_counters", "dm_set_counters", "dm_set_debug",
+           "dm_fill_random_actions", "dm_last_step_ms", "dm_enable_timing"]
+
+
+class DmConfig(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("max_ep_length", C.c_int32),
+                ("vel_obs_scale", C.c_float), ("low_z", C.c_float), ("high_z", C.c_float),
+                ("w_pose", C.c_float), ("w_vel", C.c_float), ("w_end_eff", C.c_float),
+                ("w_com", C.c_float), ("w_joint_limit", C.c_float), ("obs_bound", C.c_float),
+                ("seed", C.c_uint64), ("auto_reset", C.c_int32), ("device", C.c_int32)]
+
+
+_LIB = None
+
+
+def load_library():
+    """dlopen the in-tree HIP library; raise loudly if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libdeepmimic_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C deepmimic_mujoco_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int
+    L.dm_default_config.argtypes = [C.POINTER(DmConfig)]
+    L.dm_default_config.restype = None
+    L.dm_create.argtypes = [C.POINTER(DmModel), C.POINTER(DmConfig), C.POINTER(vp)]
+    L.dm_destroy.argtypes = [vp]
+    L.dm_last_error.argtypes = [vp]
+    L.dm_last_error.restype = C.c_char_p
+    L.dm_num_envs.argtypes = [vp]
+    L.dm_load_clip.argtypes = [vp, i32, i32, vp, vp, vp, vp]
+    L.dm_set_env_clips.argtypes = [vp, vp, vp]
+    L.dm_reset.argtypes = [vp, vp, vp, vp, vp]
+    L.dm_step.argtypes = [vp] * 9
+    L.dm_step_forced.argtypes = [vp] * 9
+    L.dm_set_state.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp]
+    L.dm_get_state.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
+    L.dm_get_counters.argtypes = [vp, vp, vp, vp, vp]
+    L.dm_set_counters.argtypes = [vp, vp, vp, vp]
+    L.dm_set_debug.argtypes = [vp, vp]
+    L.dm_fill_random_actions.argtypes = [vp, vp, C.c_uint32, vp]
+    L.dm_last_step_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.dm_enable_timing.argtypes = [vp, i32]
+    for name in EXPORTS:
+        if name not in ("dm_default_config", "dm_last_error"):
+            getattr(L, name).restype = C.c_int
+    _LIB = L
+    return L
+
+
+def default_config(**kw) -> DmConfig:
+    cfg = DmConfig()
+    load_library().dm_default_config(C.byref(cfg))
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class HipEngine:
+    """Thin object wrapper over a DmHandle; all tensors are torch CUDA tensors owned by the caller."""
+
+    def __init__(self, model, num_envs, device=0, seed=1234, auto_reset=True, **cfg_kw):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("no MI355X visible to HIP: the DeepMimic engine has no CPU fallback")
+        self.torch = torch
+        self.L = load_library()
+        self.model = model
+        self.N = int(num_envs)
+        self.device = torch.device("cuda", device)
+        self.cfg = default_config(num_envs=self.N, device=device, seed=seed,
+                                  auto_reset=1 if auto_reset else 0, **cfg_kw)
+        h = C.c_void_p()
+        rc = self.L.dm_create(C.byref(model.cstruct), C.byref(self.cfg), C.byref(h))
+        if rc != 0:
+            raise RuntimeError("dm_create failed with code %d" % rc)
+        self.h = h
+        self.clip_len = {}
+        self._debug = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.dm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            msg = self.L.dm_last_error(self.h)
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- clips
+    def load_clip(self, clip_id, mocap):
+        q, v, b, g = [np.ascontiguousarray(a, np.float64) for a in mocap.tables()]
+        self._chk(self.L.dm_load_clip(self.h, clip_id, len(q), q.ctypes.data_as(C.c_void_p),
+                                      v.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
+                                      g.ctypes.data_as(C.c_void_p)), "dm_load_clip")
+        self.clip_len[clip_id] = len(q)
+
+    def set_env_clips(self, clip_ids):
+        t = None if clip_ids is None else clip_ids.to(self.device, self.torch.int32).contiguous()
+        self._chk(self.L.dm_set_env_clips(self.h, _ptr(t), self._stream()), "dm_set_env_clips")
+        self._keep = t
+
+    # ---- buffers
+    def alloc_outputs(self):
+        t, d = self.torch, self.device
+        return dict(obs=t.zeros(self.N, NOBS, device=d), rew=t.zeros(self.N, device=d),
+                    done=t.zeros(self.N, dtype=t.uint8, device=d), terms=t.zeros(self.N, 5, device=d),
+                    reason=t.zeros(self.N, dtype=t.int32, device=d),
+                    terminal_obs=t.zeros(self.N, NOBS, device=d))
+
+    def enable_debug(self, on=True):
+        if on:
+            self._debug = self.torch.zeros(self.N, DEBUG_STRIDE, device=self.device)
+            self._chk(self.L.dm_set_debug(self.h, _ptr(self._debug)), "dm_set_debug")
+        else:
+            self._chk(self.L.dm_set_debug(self.h, None), "dm_set_debug")
+            self._debug = None
+        return self._debug
+
+    # ---- hot path
+    def reset(self, obs, mask=None, idx_init=None):
+        self._chk(self.L.dm_reset(self.h, _ptr(mask), _ptr(idx_init), _ptr(obs), self._stream()), "dm_reset")
+
+    def step(self, actions, out):
+        self._chk(self.L.dm_step(self.h, _ptr(actions), _ptr(out["obs"]), _ptr(out["rew"]), _ptr(out["done"]),
+                                 _ptr(out.get("terms")), _ptr(out.get("reason")), _ptr(out.get("terminal_obs")),
+                                 self._stream()), "dm_step")
+
+    def step_forced(self, qpos, qvel, out):
+        self._chk(self.L.dm_step_forced(self.h, _ptr(qpos), _ptr(qvel), _ptr(out["obs"]), _ptr(out["rew"]),
+                                        _ptr(out["done"]), _ptr(out.get("terms")), _ptr(out.get("reason")),
+                                        self._stream()), "dm_step_forced")
+
+    def set_state(self, qpos, qvel, warm=None, ctrl=None, env_ids=None, run_forward=False):
+        n = qpos.shape[0]
+        self._chk(self.L.dm_set_state(self.h, _ptr(env_ids), n, _ptr(qpos), _ptr(qvel), _ptr(warm), _ptr(ctrl),
+                                      1 if run_forward else 0, self._stream()), "dm_set_state")
+
+    def get_state(self, env_ids=None, n=None):
+        t, d = self.torch, self.device
+        n = self.N if n is None else n
+        qpos, qvel = t.zeros(n, NQ, device=d), t.zeros(n, NV, device=d)
+        warm, ctrl = t.zeros(n, NV, device=d), t.zeros(n, NU, device=d)
+        self._chk(self.L.dm_get_state(self.h, _ptr(env_ids), n, _ptr(qpos), _ptr(qvel), _ptr(warm), _ptr(ctrl),
+                                      self._stream()), "dm_get_state")
+        return qpos, qvel, warm, ctrl
+
+    def get_counters(self):
+        t, d = self.torch, self.device
+        idx = t.zeros(self.N, dtype=t.int32, device=d)
+        ln = t.zeros(self.N, dtype=t.int32, device=d)
+        rew = t.zeros(self.N, device=d)
+        self._chk(self.L.dm_get_counters(self.h, _ptr(idx), _ptr(ln), _ptr(rew), self._stream()), "dm_get_counters")
+        return idx, ln, rew
+
+    def set_counters(self, idx=None, ep_len=None):
+        self._chk(self.L.dm_set_counters(self.h, _ptr(idx), _ptr(ep_len), self._stream()), "dm_set_counters")
+
+    def fill_random_actions(self, actions, step_index):
+        self._chk(self.L.dm_fill_random_actions(self.h, _ptr(actions), int(step_index), self._stream()),
+                  "dm_fill_random_actions")
+
+    def enable_timing(self, on=True):
+        self._chk(self.L.dm_enable_timing(self.h, 1 if on else 0), "dm_enable_timing")
+
+    def last_step_ms(self):
+        ms = C.c_float(0)
+        self._chk(self.L.dm_last_step_ms(self.h, C.byref(ms)), "dm_last_step_ms")
+        return ms.value

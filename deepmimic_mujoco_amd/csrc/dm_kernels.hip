@@ -1,0 +1,1339 @@
+// dm_kernels.hip — fused DPEnv.step() kernel for gfx950 (CDNA4), one wavefront per environment.
+//
+// Reference path being replaced:
+//   DPEnv.step                  src/deepmimic_env.py:335-484
+//     do_simulation -> mj_step  [EXT] MuJoCo RK4 x (kinematics, inertia, collision, PGS)
+//     get_obs                   src/deepmimic_env.py:33-143
+//     calc_imitation_reward     src/deepmimic_env.py:193-256
+//     termination, counters     src/deepmimic_env.py:418-476
+//   VecEnv worker auto-reset    [EXT] SubprocVecEnv (src/sb3_ppo.py:275)
+//
+// Lane roles per phase are described in dm_device.h / DESIGN.md §3.  The physics
+// algorithm is the one restated in SURVEY.md Appendix B; the fp64 oracle
+// (oracle/dm_oracle.c) is an independent scalar implementation of the same spec.
+#include "../../include/deepmimic_hip.h"
+#include "dm_device.h"
+
+#include <math.h>
+
+#define SYNC() __syncthreads()
+#define MINVALF 1e-15f
+#define MAXVALF 1e10f
+
+namespace {
+
+__device__ __forceinline__ float rl(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 64 lanes, result uniform in every lane
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
+}
+__device__ __forceinline__ unsigned long long lanemask_lt(int lane) {
+  return (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+}
+__device__ __forceinline__ int prefix_count(bool flag, int lane, int *total) {
+  unsigned long long m = __ballot(flag);
+  *total = __popcll(m);
+  return __popcll(m & lanemask_lt(lane));
+}
+
+__device__ __forceinline__ void cross3(float *r, const float *a, const float *b) {
+  float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ float dot3(const float *a, const float *b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+__device__ __forceinline__ void quat_mul(float *r, const float *a, const float *b) {
+  float w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  float x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  float y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  float z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+__device__ __forceinline__ void quat_rot(float *r, const float *q, const float *v) {
+  float t[3], u[3];
+  cross3(t, q + 1, v);
+  t[0] *= 2.f; t[1] *= 2.f; t[2] *= 2.f;
+  cross3(u, q + 1, t);
+  r[0] = v[0] + q[0] * t[0] + u[0];
+  r[1] = v[1] + q[0] * t[1] + u[1];
+  r[2] = v[2] + q[0] * t[2] + u[2];
+}
+__device__ __forceinline__ void quat2mat(float *m, const float *q) {
+  float w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+__device__ __forceinline__ void quat_normalize(float *q) {
+  float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < MINVALF) { q[0] = 1; q[1] = q[2] = q[3] = 0; }
+  else { float i = 1.0f / n; q[0] *= i; q[1] *= i; q[2] *= i; q[3] *= i; }
+}
+__device__ __forceinline__ void mat_vec(float *r, const float *m, const float *v) {
+  float x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
+  float y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
+  float z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ void mat_t_vec(float *r, const float *m, const float *v) {
+  float x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2];
+  float y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2];
+  float z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ void mul_inert_vec(float *r, const float *I, const float *v) {
+  r[0] = I[0] * v[0] + I[3] * v[1] + I[4] * v[2] - I[8] * v[4] + I[7] * v[5];
+  r[1] = I[3] * v[0] + I[1] * v[1] + I[5] * v[2] - I[6] * v[5] + I[8] * v[3];
+  r[2] = I[4] * v[0] + I[5] * v[1] + I[2] * v[2] - I[7] * v[3] + I[6] * v[4];
+  r[3] = I[8] * v[1] - I[7] * v[2] + I[9] * v[3];
+  r[4] = I[6] * v[2] - I[8] * v[0] + I[9] * v[4];
+  r[5] = I[7] * v[0] - I[6] * v[1] + I[9] * v[5];
+}
+__device__ __forceinline__ void cross_motion(float *r, const float *vel, const float *v) {
+  float a[3], b[3], c[3];
+  cross3(a, vel, v);
+  cross3(b, vel, v + 3);
+  cross3(c, vel + 3, v);
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2];
+  r[3] = b[0] + c[0]; r[4] = b[1] + c[1]; r[5] = b[2] + c[2];
+}
+__device__ __forceinline__ void cross_force(float *r, const float *vel, const float *f) {
+  float a[3], b[3], c[3];
+  cross3(a, vel, f);
+  cross3(b, vel + 3, f + 3);
+  cross3(c, vel, f + 3);
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2];
+  r[3] = c[0]; r[4] = c[1]; r[5] = c[2];
+}
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+// py3dtf.Quaternion(x,y,z,w).to_rpy() restated: standard ZYX, no normalisation
+__device__ __forceinline__ void quat_to_rpy(const float *q, float *rpy) {
+  float w = q[0], x = q[1], y = q[2], z = q[3];
+  rpy[0] = atan2f(2 * (w * x + y * z), 1 - 2 * (x * x + y * y));
+  rpy[1] = asinf(clampf(2 * (w * y - z * x), -1.f, 1.f));
+  rpy[2] = atan2f(2 * (w * z + x * y), 1 - 2 * (y * y + z * z));
+}
+
+// counter-based generator shared with oracle/dm_oracle.c (hash32)
+__device__ __host__ __forceinline__ uint32_t dm_hash32(uint64_t seed, uint32_t env, uint32_t step, uint32_t j) {
+  uint64_t x = seed ^ ((uint64_t)env * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)step * 0xBF58476D1CE4E5B9ull) ^
+               ((uint64_t)j * 0x94D049BB133111EBull);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (uint32_t)(x >> 32);
+}
+
+// ---------------------------------------------------------------- narrowphase (per lane)
+// up to 4 candidate contacts per lane in registers (static slots)
+struct Cand {
+  float d[4], p[4][3], n[4][3], t[3];
+  int valid;  // bit s: slot s holds a contact
+};
+
+template <int S>
+__device__ __forceinline__ void np_plane_sphere(Cand &c, float margin, const float *ppos, const float *pn,
+                                                const float *spos, float r) {
+  float df[3] = {spos[0] - ppos[0], spos[1] - ppos[1], spos[2] - ppos[2]};
+  float dist = dot3(df, pn) - r;
+  if (dist > margin) return;
+  c.valid |= 1 << S;
+  c.d[S] = dist;
+  for (int i = 0; i < 3; i++) { c.n[S][i] = pn[i]; c.p[S][i] = spos[i] - pn[i] * (r + 0.5f * dist); }
+}
+template <int S>
+__device__ __forceinline__ void np_sphere_sphere(Cand &c, float margin, const float *p1, float r1,
+                                                 const float *p2, float r2) {
+  float df[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  float cd = sqrtf(dot3(df, df)), dist = cd - r1 - r2;
+  if (dist > margin) return;
+  c.valid |= 1 << S;
+  c.d[S] = dist;
+  float inv = (cd < MINVALF) ? 0.f : 1.0f / cd;
+  c.n[S][0] = (cd < MINVALF) ? 1.f : df[0] * inv;
+  c.n[S][1] = df[1] * inv;
+  c.n[S][2] = df[2] * inv;
+  for (int i = 0; i < 3; i++) c.p[S][i] = p1[i] + c.n[S][i] * (r1 + 0.5f * dist);
+}
+template <int S>
+__device__ __forceinline__ void np_sphere_box(Cand &c, float margin, const float *spos, float r,
+                                              const float *bpos, const float *bmat, const float *size) {
+  float t[3] = {spos[0] - bpos[0], spos[1] - bpos[1], spos[2] - bpos[2]}, ctr[3], cl[3], nl[3];
+  mat_t_vec(ctr, bmat, t);
+  for (int i = 0; i < 3; i++) { cl[i] = clampf(ctr[i], -size[i], size[i]); nl[i] = cl[i] - ctr[i]; }
+  float dd = sqrtf(dot3(nl, nl)), dist;
+  if (dd - r > margin) return;
+  if (dd <= MINVALF) {
+    float closest = 2 * (size[0] + size[1] + size[2]);
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      float test = size[i / 2] - ((i % 2) ? -1.0f : 1.0f) * ctr[i / 2];
+      if (test < closest) { closest = test; k = i; }
+    }
+    nl[0] = nl[1] = nl[2] = 0;
+    float sgn = (k % 2) ? 1.0f : -1.0f;
+    if (k / 2 == 0) nl[0] = sgn; else if (k / 2 == 1) nl[1] = sgn; else nl[2] = sgn;
+    dist = -closest - r;
+  } else {
+    float inv = 1.0f / dd;
+    nl[0] *= inv; nl[1] *= inv; nl[2] *= inv;
+    dist = dd - r;
+  }
+  float pl[3] = {ctr[0] + nl[0] * (r + 0.5f * dist), ctr[1] + nl[1] * (r + 0.5f * dist),
+                 ctr[2] + nl[2] * (r + 0.5f * dist)};
+  c.valid |= 1 << S;
+  c.d[S] = dist;
+  mat_vec(c.n[S], bmat, nl);
+  mat_vec(t, bmat, pl);
+  for (int i = 0; i < 3; i++) c.p[S][i] = t[i] + bpos[i];
+}
+__device__ __forceinline__ float cb_grad(const float *p, const float *a, const float *size, float t) {
+  float g = 0;
+  for (int i = 0; i < 3; i++) {
+    float x = p[i] + a[i] * t;
+    g += a[i] * (x - clampf(x, -size[i], size[i]));
+  }
+  return g;
+}
+
+__device__ __forceinline__ void make_frame(float *f) {  // [EXT] mju_makeFrame
+  float n = sqrtf(dot3(f, f));
+  if (n < MINVALF) { f[0] = 1; f[1] = 0; f[2] = 0; }
+  else { float i = 1.f / n; f[0] *= i; f[1] *= i; f[2] *= i; }
+  if (sqrtf(dot3(f + 3, f + 3)) < 0.5f) {
+    f[3] = f[4] = f[5] = 0;
+    if (f[1] < 0.5f && f[1] > -0.5f) f[4] = 1; else f[5] = 1;
+  }
+  float t = dot3(f, f + 3);
+  f[3] -= t * f[0]; f[4] -= t * f[1]; f[5] -= t * f[2];
+  n = sqrtf(dot3(f + 3, f + 3));
+  if (n < MINVALF) { f[3] = 1; f[4] = 0; f[5] = 0; }
+  else { float i = 1.f / n; f[3] *= i; f[4] *= i; f[5] *= i; }
+  cross3(f + 6, f, f + 3);
+}
+
+// Box-box for the single foot-foot pair: SAT over 15 axes, then reference-face clipping
+// (polygon scratch in LDS) or closest points of two edges.  Same construction as the oracle.
+__device__ __noinline__ void np_box_box(EnvLds &S, float margin, const float *p1, const float *R1, const float *s1,
+                                        const float *p2, const float *R2, const float *s2) {
+  S.u.bb.ncand = 0;
+  float R[9], AR[9], t[3], tw[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  mat_t_vec(t, R1, tw);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      R[3 * i + j] = R1[i] * R2[j] + R1[3 + i] * R2[3 + j] + R1[6 + i] * R2[6 + j];
+      AR[3 * i + j] = fabsf(R[3 * i + j]) + 1e-9f;
+    }
+  float best = -1e30f, bn[3] = {0, 0, 0};
+  int code = -1;
+  for (int i = 0; i < 3; i++) {
+    float s = fabsf(t[i]) - (s1[i] + s2[0] * AR[3 * i] + s2[1] * AR[3 * i + 1] + s2[2] * AR[3 * i + 2]);
+    if (s > margin) return;
+    if (s > best) { best = s; code = i; }
+  }
+  for (int j = 0; j < 3; j++) {
+    float tj = t[0] * R[j] + t[1] * R[3 + j] + t[2] * R[6 + j];
+    float s = fabsf(tj) - (s2[j] + s1[0] * AR[j] + s1[1] * AR[3 + j] + s1[2] * AR[6 + j]);
+    if (s > margin) return;
+    if (s > best) { best = s; code = 3 + j; }
+  }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      float ei[3] = {0, 0, 0}, ej[3] = {R[j], R[3 + j], R[6 + j]}, ax[3];
+      ei[i] = 1;
+      cross3(ax, ei, ej);
+      float l = sqrtf(dot3(ax, ax));
+      if (l < 1e-6f) continue;
+      ax[0] /= l; ax[1] /= l; ax[2] /= l;
+      float ra = s1[0] * fabsf(ax[0]) + s1[1] * fabsf(ax[1]) + s1[2] * fabsf(ax[2]), rb = 0;
+      for (int k = 0; k < 3; k++) {
+        float ek[3] = {R[k], R[3 + k], R[6 + k]};
+        rb += s2[k] * fabsf(dot3(ax, ek));
+      }
+      float s = fabsf(dot3(t, ax)) - (ra + rb);
+      if (s > margin) return;
+      if (s > best + 0.05f * fabsf(best) + 1e-6f) { best = s; code = 6 + 3 * i + j; bn[0] = ax[0]; bn[1] = ax[1]; bn[2] = ax[2]; }
+    }
+  if (code < 0) return;
+  float (*cand)[8] = S.u.bb.cand;
+  if (code >= 6) {
+    int i = (code - 6) / 3, j = (code - 6) % 3;
+    float n1[3] = {bn[0], bn[1], bn[2]};
+    if (dot3(n1, t) < 0) { n1[0] = -n1[0]; n1[1] = -n1[1]; n1[2] = -n1[2]; }
+    float pa[3], pb[3] = {t[0], t[1], t[2]};
+    for (int k = 0; k < 3; k++) pa[k] = (k == i) ? 0.f : ((n1[k] > 0) ? s1[k] : -s1[k]);
+    for (int k = 0; k < 3; k++) {
+      if (k == j) continue;
+      float ek[3] = {R[k], R[3 + k], R[6 + k]};
+      float sg = (dot3(n1, ek) > 0) ? -s2[k] : s2[k];
+      pb[0] += sg * ek[0]; pb[1] += sg * ek[1]; pb[2] += sg * ek[2];
+    }
+    float ua[3] = {0, 0, 0}, ub[3] = {R[j], R[3 + j], R[6 + j]}, w[3];
+    ua[i] = 1;
+    for (int k = 0; k < 3; k++) w[k] = pb[k] - pa[k];
+    float uaub = dot3(ua, ub), q1 = dot3(ua, w), q2 = -dot3(ub, w), dd = 1 - uaub * uaub;
+    float alpha = 0, beta = 0;
+    if (dd > 1e-12f) { alpha = (q1 + uaub * q2) / dd; beta = (uaub * q1 + q2) / dd; }
+    alpha = clampf(alpha, -s1[i], s1[i]);
+    beta = clampf(beta, -s2[j], s2[j]);
+    float mid[3], mw[3], nw[3];
+    for (int k = 0; k < 3; k++) mid[k] = 0.5f * ((pa[k] + ua[k] * alpha) + (pb[k] + ub[k] * beta));
+    mat_vec(mw, R1, mid);
+    mat_vec(nw, R1, n1);
+    cand[0][0] = best;
+    for (int k = 0; k < 3; k++) { cand[0][1 + k] = mw[k] + p1[k]; cand[0][4 + k] = nw[k]; }
+    S.u.bb.ncand = 1;
+    return;
+  }
+  const float *Ra, *Rb, *sa, *sb, *pa, *pb;
+  int ax, flip;
+  if (code < 3) { Ra = R1; Rb = R2; sa = s1; sb = s2; pa = p1; pb = p2; ax = code; flip = 0; }
+  else { Ra = R2; Rb = R1; sa = s2; sb = s1; pa = p2; pb = p1; ax = code - 3; flip = 1; }
+  float nrm[3] = {Ra[ax], Ra[3 + ax], Ra[6 + ax]}, dab[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+  if (dot3(nrm, dab) < 0) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; }
+  int ib = 0;
+  float bestd = -1, nb[3];
+  mat_t_vec(nb, Rb, nrm);
+  for (int k = 0; k < 3; k++) if (fabsf(nb[k]) > bestd) { bestd = fabsf(nb[k]); ib = k; }
+  float sgn = (nb[ib] > 0) ? -1.0f : 1.0f;
+  int u = (ib + 1) % 3, v = (ib + 2) % 3;
+  float (*poly)[3] = S.u.bb.poly[0];
+  float (*tmp)[3] = S.u.bb.poly[1];
+  int np = 4;
+  for (int q = 0; q < 4; q++) {
+    float su = (q == 0 || q == 3) ? -sb[u] : sb[u], sv = (q < 2) ? -sb[v] : sb[v];
+    float loc[3];
+    loc[ib] = sgn * sb[ib]; loc[u] = su; loc[v] = sv;
+    float w[3], rel[3], pq[3];
+    mat_vec(w, Rb, loc);
+    for (int k = 0; k < 3; k++) rel[k] = w[k] + pb[k] - pa[k];
+    mat_t_vec(pq, Ra, rel);
+    poly[q][0] = pq[0]; poly[q][1] = pq[1]; poly[q][2] = pq[2];
+  }
+  int axes[2] = {(ax + 1) % 3, (ax + 2) % 3};
+  for (int e = 0; e < 2; e++)
+    for (int sd = -1; sd <= 1; sd += 2) {
+      int a = axes[e], nn = 0;
+      for (int q = 0; q < np; q++) {
+        float *Pq = poly[q], *Qq = poly[(q + 1) % np];
+        float dp = sd * Pq[a] - sa[a], dq = sd * Qq[a] - sa[a];
+        if (dp <= 0) { tmp[nn][0] = Pq[0]; tmp[nn][1] = Pq[1]; tmp[nn][2] = Pq[2]; nn++; }
+        if ((dp < 0 && dq > 0) || (dp > 0 && dq < 0)) {
+          float f = dp / (dp - dq);
+          for (int k = 0; k < 3; k++) tmp[nn][k] = Pq[k] + f * (Qq[k] - Pq[k]);
+          nn++;
+        }
+        if (nn >= 15) break;
+      }
+      np = nn;
+      for (int q = 0; q < np; q++) { poly[q][0] = tmp[q][0]; poly[q][1] = tmp[q][1]; poly[q][2] = tmp[q][2]; }
+      if (np == 0) return;
+    }
+  float nl[3];
+  mat_t_vec(nl, Ra, nrm);
+  int cnt = 0;
+  for (int q = 0; q < np && cnt < 8; q++) {
+    float pq[3] = {poly[q][0], poly[q][1], poly[q][2]};
+    float depth = dot3(nl, pq) - sa[ax];
+    if (depth > margin) continue;
+    float pl[3], pw[3];
+    for (int k = 0; k < 3; k++) pl[k] = pq[k] - nl[k] * 0.5f * depth;
+    mat_vec(pw, Ra, pl);
+    cand[cnt][0] = depth;
+    for (int k = 0; k < 3; k++) { cand[cnt][1 + k] = pw[k] + pa[k]; cand[cnt][4 + k] = flip ? -nrm[k] : nrm[k]; }
+    cnt++;
+  }
+  // keep the 4 deepest, preserving polygon order
+  while (cnt > 4) {
+    int w = 0;
+    for (int q = 1; q < cnt; q++) if (cand[q][0] >= cand[w][0]) w = q;
+    for (int q = w; q < cnt - 1; q++)
+      for (int k = 0; k < 7; k++) cand[q][k] = cand[q + 1][k];
+    cnt--;
+  }
+  S.u.bb.ncand = cnt;
+}
+
+__device__ __forceinline__ float impedance(const float *solimp, float pos, float margin) {
+  float dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
+  if (dmin == dmax || width <= MINVALF) return 0.5f * (dmin + dmax);
+  float x = fabsf(pos - margin) / width;
+  if (x >= 1) return dmax;
+  if (x <= 0) return dmin;
+  float y;
+  if (power == 1) y = x;
+  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1);
+  else y = 1 - powf(1 - x, power) / powf(1 - mid, power - 1);
+  return dmin + y * (dmax - dmin);
+}
+
+}  // namespace
+
+// ======================================================================================
+extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
+  __shared__ EnvLds S;
+  const int lane = threadIdx.x;
+  const int slot = blockIdx.x;
+  const DmDev &T = *P.T;
+  const int env = P.env_ids ? P.env_ids[slot] : slot;
+  if (env < 0 || env >= P.N) return;
+  const int mode = P.mode;
+  if (mode == DMK_MODE_RESET && P.mask && !P.mask[env]) return;
+  float *st = P.state + (size_t)env * DMK_STATE_STRIDE;
+  int *sti = reinterpret_cast<int *>(st);
+
+  // ---------------------------------------------------------------- role constants (registers)
+  const int lb = lane < DMK_NB ? lane : 0;       // lane as body
+  const int lk = lane < DMK_NV ? lane : 0;       // lane as dof
+  const int lg = lane < DMK_NG ? lane : 0;       // lane as geom
+  const int bp = T.b_parent[lb], bdep = (lane < DMK_NB) ? T.b_depth[lb] : -1;
+  const int bdofadr = T.b_dofadr[lb], bdofnum = T.b_dofnum[lb];
+  const float bpos[3] = {T.b_pos[lb][0], T.b_pos[lb][1], T.b_pos[lb][2]};
+  const float bipos[3] = {T.b_ipos[lb][0], T.b_ipos[lb][1], T.b_ipos[lb][2]};
+  float binert[6];
+  for (int i = 0; i < 6; i++) binert[i] = T.b_inertia[lb][i];
+  const float bmass = (lane < DMK_NB) ? T.b_mass[lb] : 0.f;
+  const unsigned bsub = T.b_subtree[lb];
+  float baxis[3][3];
+  for (int j = 0; j < 3; j++) {
+    int k = bdofadr + j;
+    k = (k >= 0 && k < DMK_NV && j < bdofnum && lb > 1) ? k : 0;
+    for (int i = 0; i < 3; i++) baxis[j][i] = T.d_axis[k][i];
+  }
+  const int dbody = T.d_body[lk], dnanc = T.d_nanc[lk], dact = T.d_act[lk], dlimited = T.d_limited[lk];
+  const float darm = T.d_arm[lk], ddamp = T.d_damp[lk], dlo = T.d_lo[lk], dhi = T.d_hi[lk];
+  const float dgear = T.d_gear[lk], dclo = T.d_clo[lk], dchi = T.d_chi[lk];
+  const int gbody = T.g_body[lg];
+  float gposl[3], gmatl[9];
+  for (int i = 0; i < 3; i++) gposl[i] = T.g_pos[lg][i];
+  for (int i = 0; i < 9; i++) gmatl[i] = T.g_mat[lg][i];
+  const float h = T.timestep;
+  const float mtot_inv = T.total_mass_inv;
+
+  // ---------------------------------------------------------------- LDS init
+  for (int i = lane; i < DMK_NV * DMK_MSTRIDE; i += 64) S.M[i] = 0.f;
+  for (int i = lane; i < DMK_NV * DMK_MAXANC; i += 64) (&S.d_anc[0][0])[i] = (&T.d_anc[0][0])[i];
+  for (int i = lane; i < 80; i += 64) { S.tri_a[i] = T.tri_a[i]; S.tri_b[i] = T.tri_b[i]; }
+  if (lane < 16) S.b_chain[lane] = T.b_chain[lane];
+  if (lane < 36) S.d_nanc[lane] = (lane < DMK_NV) ? T.d_nanc[lane] : 0;
+  if (lane == 0) {
+    S.xpos[0][0] = S.xpos[0][1] = S.xpos[0][2] = 0;
+    S.xquat[0][0] = 1; S.xquat[0][1] = S.xquat[0][2] = S.xquat[0][3] = 0;
+    for (int i = 0; i < 9; i++) S.xmat[0][i] = (i % 4 == 0) ? 1.f : 0.f;
+    S.xipos[0][0] = S.xipos[0][1] = S.xipos[0][2] = 0;
+    for (int i = 0; i < 6; i++) S.cvel[0][i] = 0;
+    for (int i = 0; i < 10; i++) S.cinert[0][i] = 0;
+  }
+
+  // ---------------------------------------------------------------- load state
+  const int clip_id = sti[DMS_CLIP];
+  const DmClipDev clip = P.clips[(clip_id >= 0 && clip_id < 8) ? clip_id : 0];
+  if (clip.L < 1 || clip.rows == nullptr) return;  // no clip loaded for this env's clip id
+  int idx_curr = sti[DMS_IDX], ep_len = sti[DMS_EPLEN], rcnt = sti[DMS_RCNT];
+  idx_curr = idx_curr < 0 ? 0 : (idx_curr >= clip.L ? clip.L - 1 : idx_curr);
+  float ep_rew = st[DMS_EPREW];
+  if (lane < DMK_NQ) S.qpos[lane] = st[DMS_QPOS + lane];
+  if (lane < DMK_NV) { S.qvel[lane] = st[DMS_QVEL + lane]; S.warm[lane] = st[DMS_WARM + lane]; }
+  if (lane < DMK_NU) S.ctrl[lane] = st[DMS_CTRL + lane];
+  SYNC();
+  if (mode == DMK_MODE_STEP) {
+    if (lane < DMK_NU) S.ctrl[lane] = P.actions[(size_t)env * DMK_NU + lane];  // ctrl = action * 1.0 (:347)
+  } else if (mode == DMK_MODE_FORCED || mode == DMK_MODE_SETSTATE) {
+    if (lane < DMK_NQ) S.qpos[lane] = P.in_qpos[(size_t)slot * DMK_NQ + lane];
+    if (lane < DMK_NV) S.qvel[lane] = P.in_qvel[(size_t)slot * DMK_NV + lane];
+    if (mode == DMK_MODE_SETSTATE) {
+      if (P.in_warm && lane < DMK_NV) S.warm[lane] = P.in_warm[(size_t)slot * DMK_NV + lane];
+      if (P.in_ctrl && lane < DMK_NU) S.ctrl[lane] = P.in_ctrl[(size_t)slot * DMK_NU + lane];
+    }
+  } else if (mode == DMK_MODE_RESET) {
+    int fi = P.idx_init ? P.idx_init[env] : (int)(dm_hash32(P.seed, env, rcnt, 0x5EED) % (uint32_t)clip.L);
+    fi = fi < 0 ? 0 : (fi >= clip.L ? clip.L - 1 : fi);
+    const float *rr = clip.reset + (size_t)fi * DMK_RESET_ROW;
+    if (lane < DMK_NQ) S.qpos[lane] = rr[lane];
+    if (lane < DMK_NV) S.qvel[lane] = rr[35 + lane];
+    idx_curr = fi; ep_len = 0; ep_rew = 0; rcnt++;
+  }
+  SYNC();
+
+  // RK4 bookkeeping, lane = dof (k<3 root translation, 3..5 root rotation, >=6 hinges)
+  float x0q = 0, x0v = 0, accq = 0, accv = 0, curv = 0;
+  float q0[4] = {1, 0, 0, 0};
+  int it = (mode == DMK_MODE_STEP) ? 0 : 4;
+  bool after_reset = false, done = false, sim_err = false;
+  int reason = DM_REASON_NONE;
+  float reward = 0;
+  int ncon = 0, nefc = 0, nlimit = 0, solver_iter = 0, overflow = 0;
+  float com[3] = {0, 0, 0};
+  unsigned stage_ncon = 0, stage_nefc = 0;  // byte i = count at RK stage i (debug)
+
+  if (mode == DMK_MODE_SETSTATE && !P.run_forward) {  // store only
+    if (lane < DMK_NQ) st[DMS_QPOS + lane] = S.qpos[lane];
+    if (lane < DMK_NV) { st[DMS_QVEL + lane] = S.qvel[lane]; st[DMS_WARM + lane] = S.warm[lane]; }
+    if (lane < DMK_NU) st[DMS_CTRL + lane] = S.ctrl[lane];
+    return;
+  }
+  if (mode == DMK_MODE_STEP || mode == DMK_MODE_FORCED) {  // mj_checkPos / mj_checkVel
+    float a = (lane < DMK_NQ) ? S.qpos[lane] : 0.f, b = (lane < DMK_NV) ? S.qvel[lk] : 0.f;
+    sim_err = __any(!(fabsf(a) <= MAXVALF) || !(fabsf(b) <= MAXVALF));
+  }
+
+  for (;;) {
+   float qacc_out = 0;
+   if (!sim_err) {
+    // ============================================================== forward evaluation
+    // stage state is in S.qpos / S.qvel / S.ctrl / S.warm
+    {  // normalise the free-joint quaternion in place (mj_kinematics does)
+      float q[4] = {S.qpos[3], S.qpos[4], S.qpos[5], S.qpos[6]};
+      quat_normalize(q);
+      SYNC();
+      if (lane < 4) S.qpos[3 + lane] = (lane == 0) ? q[0] : (lane == 1) ? q[1] : (lane == 2) ? q[2] : q[3];
+      if (lane >= 6 && lane < DMK_NV) {
+        float s, c;
+        sincosf(0.5f * S.qpos[lane + 1], &s, &c);
+        S.cs[lane][0] = c; S.cs[lane][1] = s;
+      }
+      SYNC();
+    }
+    if (it == 0) {  // capture X0 (after normalisation)
+      x0v = (lane < DMK_NV) ? S.qvel[lk] : 0.f;
+      x0q = (lane < 3) ? S.qpos[lane] : ((lane >= 6 && lane < DMK_NV) ? S.qpos[lane + 1] : 0.f);
+      for (int i = 0; i < 4; i++) q0[i] = S.qpos[3 + i];
+      curv = x0v;
+    }
+    // ---- kinematics, level by level (lane = body)
+    for (int lev = 1; lev <= 4; lev++) {
+      if (bdep == lev) {
+        float pos[3], q[4];
+        if (lev == 1) {
+          for (int i = 0; i < 3; i++) pos[i] = S.qpos[i];
+          for (int i = 0; i < 4; i++) q[i] = S.qpos[3 + i];
+        } else {
+          float pm[9], pp[3], tv[3];
+          for (int i = 0; i < 9; i++) pm[i] = S.xmat[bp][i];
+          for (int i = 0; i < 3; i++) pp[i] = S.xpos[bp][i];
+          for (int i = 0; i < 4; i++) q[i] = S.xquat[bp][i];
+          mat_vec(tv, pm, bpos);
+          for (int i = 0; i < 3; i++) pos[i] = pp[i] + tv[i];
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            if (j < bdofnum) {
+              int k = bdofadr + j;
+              float ax[3], ql[4], qn[4];
+              quat_rot(ax, q, baxis[j]);
+              S.xaxis[k][0] = ax[0]; S.xaxis[k][1] = ax[1]; S.xaxis[k][2] = ax[2];
+              float c = S.cs[k][0], s = S.cs[k][1];
+              ql[0] = c; ql[1] = baxis[j][0] * s; ql[2] = baxis[j][1] * s; ql[3] = baxis[j][2] * s;
+              quat_mul(qn, q, ql);
+              q[0] = qn[0]; q[1] = qn[1]; q[2] = qn[2]; q[3] = qn[3];
+            }
+          }
+        }
+        quat_normalize(q);
+        float m9[9], tv[3];
+        quat2mat(m9, q);
+        for (int i = 0; i < 3; i++) S.xpos[lb][i] = pos[i];
+        for (int i = 0; i < 4; i++) S.xquat[lb][i] = q[i];
+        for (int i = 0; i < 9; i++) S.xmat[lb][i] = m9[i];
+        mat_vec(tv, m9, bipos);
+        for (int i = 0; i < 3; i++) S.xipos[lb][i] = pos[i] + tv[i];
+        if (lev == 1)
+          for (int j = 0; j < 3; j++) { S.xaxis[3 + j][0] = m9[j]; S.xaxis[3 + j][1] = m9[3 + j]; S.xaxis[3 + j][2] = m9[6 + j]; }
+      }
+      SYNC();
+    }
+    // ---- geoms (lane = geom), COM
+    if (lane < DMK_NG) {
+      float bm[9], tv[3];
+      for (int i = 0; i < 9; i++) bm[i] = S.xmat[gbody][i];
+      mat_vec(tv, bm, gposl);
+      for (int i = 0; i < 3; i++) S.gpos[lg][i] = S.xpos[gbody][i] + tv[i];
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+          S.gmat[lg][3 * i + j] = bm[3 * i] * gmatl[j] + bm[3 * i + 1] * gmatl[3 + j] + bm[3 * i + 2] * gmatl[6 + j];
+    }
+    {
+      float xi[3] = {S.xipos[lb][0], S.xipos[lb][1], S.xipos[lb][2]};
+      for (int i = 0; i < 3; i++) com[i] = wave_sum(bmass * xi[i]) * mtot_inv;
+      if (lane == 0) { S.com[0] = com[0]; S.com[1] = com[1]; S.com[2] = com[2]; }
+    }
+    // ---- cinert (lane = body), cdof (lane = dof)
+    if (lane >= 1 && lane < DMK_NB) {
+      float R[9], Tm[9], W[6];
+      for (int i = 0; i < 9; i++) R[i] = S.xmat[lb][i];
+      const float Ib[9] = {binert[0], binert[3], binert[4], binert[3], binert[1], binert[5], binert[4], binert[5], binert[2]};
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) Tm[3 * i + j] = R[3 * i] * Ib[j] + R[3 * i + 1] * Ib[3 + j] + R[3 * i + 2] * Ib[6 + j];
+      // W = Tm R^T, unique entries xx yy zz xy xz yz
+      W[0] = Tm[0] * R[0] + Tm[1] * R[1] + Tm[2] * R[2];
+      W[1] = Tm[3] * R[3] + Tm[4] * R[4] + Tm[5] * R[5];
+      W[2] = Tm[6] * R[6] + Tm[7] * R[7] + Tm[8] * R[8];
+      W[3] = Tm[0] * R[3] + Tm[1] * R[4] + Tm[2] * R[5];
+      W[4] = Tm[0] * R[6] + Tm[1] * R[7] + Tm[2] * R[8];
+      W[5] = Tm[3] * R[6] + Tm[4] * R[7] + Tm[5] * R[8];
+      float o[3] = {S.xipos[lb][0] - com[0], S.xipos[lb][1] - com[1], S.xipos[lb][2] - com[2]};
+      float oo = dot3(o, o);
+      float *ci = S.cinert[lb];
+      ci[0] = W[0] + bmass * (oo - o[0] * o[0]);
+      ci[1] = W[1] + bmass * (oo - o[1] * o[1]);
+      ci[2] = W[2] + bmass * (oo - o[2] * o[2]);
+      ci[3] = W[3] - bmass * o[0] * o[1];
+      ci[4] = W[4] - bmass * o[0] * o[2];
+      ci[5] = W[5] - bmass * o[1] * o[2];
+      ci[6] = bmass * o[0]; ci[7] = bmass * o[1]; ci[8] = bmass * o[2];
+      ci[9] = bmass;
+    }
+    if (lane < DMK_NV) {
+      float cd[6] = {0, 0, 0, 0, 0, 0};
+      if (lane < 3) {
+        cd[3 + lane] = 1.f;
+      } else {
+        float ax[3] = {S.xaxis[lk][0], S.xaxis[lk][1], S.xaxis[lk][2]};
+        float off[3] = {com[0] - S.xpos[dbody][0], com[1] - S.xpos[dbody][1], com[2] - S.xpos[dbody][2]};
+        cd[0] = ax[0]; cd[1] = ax[1]; cd[2] = ax[2];
+        cross3(cd + 3, ax, off);
+      }
+      for (int i = 0; i < 6; i++) S.cdof[lk][i] = cd[i];
+      S.cdof[lk][6] = 0; S.cdof[lk][7] = 0;
+    }
+    SYNC();
+    // ---- composite inertia per body via the subtree mask, then rows of M (lane = dof)
+    if (lane >= 1 && lane < DMK_NB) {
+      float acc[10];
+      for (int i = 0; i < 10; i++) acc[i] = 0;
+      for (int c = 1; c < DMK_NB; c++)
+        if ((bsub >> c) & 1u)
+          for (int i = 0; i < 10; i++) acc[i] += S.cinert[c][i];
+      for (int i = 0; i < 10; i++) S.u.v.crb[lb][i] = acc[i];
+    }
+    SYNC();
+    if (lane < DMK_NV) {
+      float buf[6], cd[6], I[10];
+      for (int i = 0; i < 10; i++) I[i] = S.u.v.crb[dbody][i];
+      for (int i = 0; i < 6; i++) cd[i] = S.cdof[lk][i];
+      mul_inert_vec(buf, I, cd);
+      int j = lk;
+      for (int a = 0; a <= dnanc; a++) {
+        if (a > 0) j = S.d_anc[lk][a - 1];
+        float v = 0;
+        for (int i = 0; i < 6; i++) v += S.cdof[j][i] * buf[i];
+        if (a == 0) v += darm;
+        S.M[lk * DMK_MSTRIDE + j] = v;
+      }
+    }
+    SYNC();
+    // ---- L^T D L factorisation in place; one dof per step, ancestor pairs across lanes
+    for (int kk = DMK_NV - 1; kk >= 1; kk--) {
+      int n = S.d_nanc[kk];
+      int npair = n * (n + 1) / 2;
+      float rk = 1.0f / S.M[kk * DMK_MSTRIDE + kk];
+      for (int p = lane; p < npair; p += 64) {
+        int a = S.tri_a[p], b = S.tri_b[p];
+        int i = S.d_anc[kk][a], j = S.d_anc[kk][b];
+        S.M[i * DMK_MSTRIDE + j] -= S.M[kk * DMK_MSTRIDE + j] * S.M[kk * DMK_MSTRIDE + i] * rk;
+      }
+      SYNC();
+    }
+    if (lane < DMK_NV) {
+      float dd = S.M[lk * DMK_MSTRIDE + lk];
+      float di = 1.0f / dd;
+      S.dinv[lk] = di;
+      S.dsqrtinv[lk] = 1.0f / sqrtf(dd);
+      for (int a = 0; a < dnanc; a++) S.M[lk * DMK_MSTRIDE + S.d_anc[lk][a]] *= di;
+    }
+    if (lane == 0) {
+      for (int i = 0; i < 3; i++) { S.u.v.cacc[0][i] = 0; S.u.v.cacc[0][3 + i] = -T.gravity[i]; }
+    }
+    SYNC();
+    // ---- velocity stage: cvel, cdof_dot, cacc, cfrc (lane = body, level by level)
+    for (int lev = 1; lev <= 4; lev++) {
+      if (bdep == lev) {
+        float cv[6], ca[6];
+        for (int i = 0; i < 6; i++) { cv[i] = S.cvel[bp][i]; ca[i] = S.u.v.cacc[bp][i]; }
+        if (lev == 1) {
+          for (int k = 0; k < 3; k++) {
+            float qv = S.qvel[k];
+            for (int i = 0; i < 6; i++) { S.u.v.cdofdot[k][i] = 0; cv[i] += S.cdof[k][i] * qv; }
+          }
+          float dd[3][6];
+          for (int k = 3; k < 6; k++) {
+            float cd[6];
+            for (int i = 0; i < 6; i++) cd[i] = S.cdof[k][i];
+            cross_motion(dd[k - 3], cv, cd);
+          }
+          for (int k = 3; k < 6; k++) {
+            float qv = S.qvel[k];
+            for (int i = 0; i < 6; i++) {
+              S.u.v.cdofdot[k][i] = dd[k - 3][i];
+              ca[i] += dd[k - 3][i] * qv;
+            }
+          }
+          for (int k = 3; k < 6; k++) {
+            float qv = S.qvel[k];
+            for (int i = 0; i < 6; i++) cv[i] += S.cdof[k][i] * qv;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            if (j < bdofnum) {
+              int k = bdofadr + j;
+              float cd[6], dd[6], qv = S.qvel[k];
+              for (int i = 0; i < 6; i++) cd[i] = S.cdof[k][i];
+              cross_motion(dd, cv, cd);
+              for (int i = 0; i < 6; i++) {
+                S.u.v.cdofdot[k][i] = dd[i];
+                ca[i] += dd[i] * qv;
+                cv[i] += cd[i] * qv;
+              }
+            }
+          }
+        }
+        float I[10], f0[6], t0[6], t1[6];
+        for (int i = 0; i < 10; i++) I[i] = S.cinert[lb][i];
+        mul_inert_vec(f0, I, ca);
+        mul_inert_vec(t0, I, cv);
+        cross_force(t1, cv, t0);
+        for (int i = 0; i < 6; i++) {
+          S.cvel[lb][i] = cv[i];
+          S.u.v.cacc[lb][i] = ca[i];
+          S.u.v.cfrc[lb][i] = f0[i] + t1[i];
+        }
+      }
+      SYNC();
+    }
+    if (lane >= 1 && lane < DMK_NB) {
+      float acc[6] = {0, 0, 0, 0, 0, 0};
+      for (int c = 1; c < DMK_NB; c++)
+        if ((bsub >> c) & 1u)
+          for (int i = 0; i < 6; i++) acc[i] += S.u.v.cfrc[c][i];
+      for (int i = 0; i < 6; i++) S.u.v.cfrcsub[lb][i] = acc[i];
+    }
+    SYNC();
+    // ---- smooth forces and qacc_smooth = M^-1 (passive - bias + actuation)   (lane = dof)
+    float xs = 0;
+    if (lane < DMK_NV) {
+      float bias = 0;
+      for (int i = 0; i < 6; i++) bias += S.cdof[lk][i] * S.u.v.cfrcsub[dbody][i];
+      float act = 0;
+      if (dact >= 0) act = dgear * clampf(S.ctrl[dact], dclo, dchi);
+      xs = -ddamp * S.qvel[lk] - bias + act;
+    }
+#pragma unroll
+    for (int i = DMK_NV - 1; i >= 1; i--) {
+      float xi = rl(xs, i);
+      float l = S.M[i * DMK_MSTRIDE + lk];
+      if (lane < i) xs -= l * xi;
+    }
+    xs *= S.dinv[lk];
+#pragma unroll
+    for (int j = 0; j < DMK_NV - 1; j++) {
+      float xj = rl(xs, j);
+      float l = S.M[lk * DMK_MSTRIDE + j];
+      if (lane > j && lane < DMK_NV) xs -= l * xj;
+    }
+    if (lane < DMK_NV) S.qacc_smooth[lk] = xs;
+    SYNC();
+
+    // ---- collision: lane = candidate pair, two rounds in canonical order
+    int base = 0;
+    overflow = 0;
+    for (int round = 0; round < 2; round++) {
+      const int p = round * 64 + lane;
+      Cand c;
+      c.valid = 0;
+      c.t[0] = c.t[1] = c.t[2] = 0;
+      for (int s = 0; s < 4; s++) { c.d[s] = 0; for (int i = 0; i < 3; i++) { c.p[s][i] = 0; c.n[s][i] = 0; } }
+      int g1 = 0, g2 = 0;
+      bool isbb = false;
+      float margin = 0;
+      if (p < T.npair) {
+        g1 = T.p_g1[p]; g2 = T.p_g2[p];
+        const int t1 = T.g_type[g1], t2 = T.g_type[g2];
+        margin = fmaxf(T.g_margin[g1], T.g_margin[g2]);
+        float x1[3], x2[3], M1[9], M2[9], z1[3], z2[3];
+        for (int i = 0; i < 3; i++) { x1[i] = S.gpos[g1][i]; x2[i] = S.gpos[g2][i]; z1[i] = T.g_size[g1][i]; z2[i] = T.g_size[g2][i]; }
+        for (int i = 0; i < 9; i++) { M1[i] = S.gmat[g1][i]; M2[i] = S.gmat[g2][i]; }
+        bool act;
+        if (t1 == DM_GEOM_PLANE) {
+          float pn[3] = {M1[2], M1[5], M1[8]}, df[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
+          act = dot3(df, pn) - T.g_rbound[g2] <= margin;
+        } else {
+          float df[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
+          act = !(sqrtf(dot3(df, df)) > T.g_rbound[g1] + T.g_rbound[g2] + margin);
+        }
+        if (act) {
+          if (t1 == DM_GEOM_PLANE) {
+            float pn[3] = {M1[2], M1[5], M1[8]};
+            if (t2 == DM_GEOM_SPHERE) {
+              np_plane_sphere<0>(c, margin, x1, pn, x2, z2[0]);
+            } else if (t2 == DM_GEOM_CAPSULE) {
+              float ax[3] = {M2[2], M2[5], M2[8]}, e[3];
+              for (int i = 0; i < 3; i++) e[i] = x2[i] + ax[i] * z2[1];
+              np_plane_sphere<0>(c, margin, x1, pn, e, z2[0]);
+              for (int i = 0; i < 3; i++) e[i] = x2[i] - ax[i] * z2[1];
+              np_plane_sphere<1>(c, margin, x1, pn, e, z2[0]);
+              c.t[0] = ax[0]; c.t[1] = ax[1]; c.t[2] = ax[2];
+            } else {  // box: the (at most 4) corners below the centre and within margin
+              float df[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
+              float dist = dot3(df, pn);
+              int cnt = 0;
+#pragma unroll
+              for (int i = 0; i < 8; i++) {
+                float v[3] = {z2[0] * ((i & 1) ? 1.f : -1.f), z2[1] * ((i & 2) ? 1.f : -1.f), z2[2] * ((i & 4) ? 1.f : -1.f)};
+                float corner[3];
+                mat_vec(corner, M2, v);
+                float ld = dot3(pn, corner);
+                bool ok = !(dist + ld > margin || ld > 0) && cnt < 4;
+                float cdist = dist + ld;
+                float cp[3] = {corner[0] + x2[0] - pn[0] * 0.5f * cdist, corner[1] + x2[1] - pn[1] * 0.5f * cdist,
+                               corner[2] + x2[2] - pn[2] * 0.5f * cdist};
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+                  if (ok && cnt == s) {
+                    c.d[s] = cdist;
+                    for (int q = 0; q < 3; q++) { c.p[s][q] = cp[q]; c.n[s][q] = pn[q]; }
+                    c.valid |= 1 << s;
+                  }
+                cnt += ok ? 1 : 0;
+              }
+            }
+          } else if (t2 != DM_GEOM_BOX) {  // sphere/capsule vs sphere/capsule
+            float r1 = z1[0], r2 = z2[0];
+            if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_SPHERE) {
+              np_sphere_sphere<0>(c, margin, x1, r1, x2, r2);
+            } else if (t1 == DM_GEOM_SPHERE) {  // sphere - capsule
+              float ax[3] = {M2[2], M2[5], M2[8]}, v[3] = {x1[0] - x2[0], x1[1] - x2[1], x1[2] - x2[2]}, pt[3];
+              float x = clampf(dot3(ax, v), -z2[1], z2[1]);
+              for (int i = 0; i < 3; i++) pt[i] = x2[i] + ax[i] * x;
+              np_sphere_sphere<0>(c, margin, x1, r1, pt, r2);
+            } else {  // capsule - capsule
+              float a1[3] = {M1[2], M1[5], M1[8]}, a2[3] = {M2[2], M2[5], M2[8]};
+              float df[3] = {x1[0] - x2[0], x1[1] - x2[1], x1[2] - x2[2]};
+              float ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2);
+              float u = -dot3(a1, df), v = dot3(a2, df);
+              float det = ma * mc - mb * mb;
+              float v1[3], v2[3];
+              if (fabsf(det) >= MINVALF) {
+                float xx1 = (mc * u - mb * v) / det, xx2 = (ma * v - mb * u) / det;
+                if (xx1 > z1[1]) { xx1 = z1[1]; xx2 = (v - mb * z1[1]) / mc; }
+                else if (xx1 < -z1[1]) { xx1 = -z1[1]; xx2 = (v + mb * z1[1]) / mc; }
+                if (xx2 > z2[1]) { xx2 = z2[1]; xx1 = clampf((u - mb * z2[1]) / ma, -z1[1], z1[1]); }
+                else if (xx2 < -z2[1]) { xx2 = -z2[1]; xx1 = clampf((u + mb * z2[1]) / ma, -z1[1], z1[1]); }
+                for (int i = 0; i < 3; i++) { v1[i] = x1[i] + a1[i] * xx1; v2[i] = x2[i] + a2[i] * xx2; }
+                np_sphere_sphere<0>(c, margin, v1, r1, v2, r2);
+              } else {  // parallel axes: ends of capsule 1, then of capsule 2, at most 2 contacts
+                Cand e;
+                e.valid = 0;
+                for (int i = 0; i < 3; i++) v1[i] = x1[i] + a1[i] * z1[1];
+                float d2[3] = {v1[0] - x2[0], v1[1] - x2[1], v1[2] - x2[2]};
+                float xx2 = clampf(dot3(d2, a2), -z2[1], z2[1]);
+                for (int i = 0; i < 3; i++) v2[i] = x2[i] + a2[i] * xx2;
+                np_sphere_sphere<0>(e, margin, v1, r1, v2, r2);
+                for (int i = 0; i < 3; i++) v1[i] = x1[i] - a1[i] * z1[1];
+                for (int i = 0; i < 3; i++) d2[i] = v1[i] - x2[i];
+                xx2 = clampf(dot3(d2, a2), -z2[1], z2[1]);
+                for (int i = 0; i < 3; i++) v2[i] = x2[i] + a2[i] * xx2;
+                np_sphere_sphere<1>(e, margin, v1, r1, v2, r2);
+                for (int i = 0; i < 3; i++) v2[i] = x2[i] + a2[i] * z2[1];
+                float d1[3] = {v2[0] - x1[0], v2[1] - x1[1], v2[2] - x1[2]};
+                float xx1 = clampf(dot3(d1, a1), -z1[1], z1[1]);
+                for (int i = 0; i < 3; i++) v1[i] = x1[i] + a1[i] * xx1;
+                np_sphere_sphere<2>(e, margin, v1, r1, v2, r2);
+                for (int i = 0; i < 3; i++) v2[i] = x2[i] - a2[i] * z2[1];
+                for (int i = 0; i < 3; i++) d1[i] = v2[i] - x1[i];
+                xx1 = clampf(dot3(d1, a1), -z1[1], z1[1]);
+                for (int i = 0; i < 3; i++) v1[i] = x1[i] + a1[i] * xx1;
+                np_sphere_sphere<3>(e, margin, v1, r1, v2, r2);
+                int cnt = 0;  // keep the first two, in test order
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                  bool ok = ((e.valid >> s) & 1) && cnt < 2;
+#pragma unroll
+                  for (int o = 0; o < 2; o++)
+                    if (ok && cnt == o) {
+                      c.d[o] = e.d[s];
+                      for (int q = 0; q < 3; q++) { c.p[o][q] = e.p[s][q]; c.n[o][q] = e.n[s][q]; }
+                      c.valid |= 1 << o;
+                    }
+                  cnt += ok ? 1 : 0;
+                }
+              }
+            }
+          } else if (t1 == DM_GEOM_SPHERE) {
+            np_sphere_box<0>(c, margin, x1, z1[0], x2, M2, z2);
+          } else if (t1 == DM_GEOM_CAPSULE) {  // capsule - box (see oracle c_capsule_box)
+            float axw[3] = {M1[2], M1[5], M1[8]}, tt[3] = {x1[0] - x2[0], x1[1] - x2[1], x1[2] - x2[2]}, pp[3], aa[3];
+            float hl = z1[1], r = z1[0];
+            mat_t_vec(pp, M2, tt);
+            mat_t_vec(aa, M2, axw);
+            float lo = -hl, hi = hl, ts;
+            if (cb_grad(pp, aa, z2, lo) >= 0) ts = lo;
+            else if (cb_grad(pp, aa, z2, hi) <= 0) ts = hi;
+            else {
+              for (int q = 0; q < 26; q++) {
+                float mid = 0.5f * (lo + hi);
+                if (cb_grad(pp, aa, z2, mid) < 0) lo = mid; else hi = mid;
+              }
+              ts = 0.5f * (lo + hi);
+            }
+            float pt[3];
+            for (int i = 0; i < 3; i++) pt[i] = x1[i] + axw[i] * ts;
+            np_sphere_box<0>(c, margin, pt, r, x2, M2, z2);
+            float te = (ts > 0) ? -hl : hl;
+            if (fabsf(te - ts) > 1e-3f * hl) {
+              for (int i = 0; i < 3; i++) pt[i] = x1[i] + axw[i] * te;
+              np_sphere_box<1>(c, margin, pt, r, x2, M2, z2);
+            }
+          } else {
+            isbb = true;
+          }
+        }
+        if (isbb) {
+          np_box_box(S, margin, x1, M1, z1, x2, M2, z2);
+          int nc = S.u.bb.ncand;
+#pragma unroll
+          for (int s = 0; s < 4; s++)
+            if (s < nc) {
+              c.valid |= 1 << s;
+              c.d[s] = S.u.bb.cand[s][0];
+              for (int q = 0; q < 3; q++) { c.p[s][q] = S.u.bb.cand[s][1 + q]; c.n[s][q] = S.u.bb.cand[s][4 + q]; }
+            }
+        }
+      }
+      // compaction in canonical order: exclusive prefix of the per-lane contact counts
+      int cnt = __popc(c.valid);
+      unsigned long long lt = lanemask_lt(lane);
+      unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
+      int off = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+      int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+      int w = base + off;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        if ((c.valid >> s) & 1) {
+          if (w < DMK_MAXCON) {
+            float fr[9] = {c.n[s][0], c.n[s][1], c.n[s][2], c.t[0], c.t[1], c.t[2], 0, 0, 0};
+            make_frame(fr);
+            S.c_dist[w] = c.d[s];
+            for (int q = 0; q < 3; q++) S.c_pos[w][q] = c.p[s][q];
+            for (int q = 0; q < 9; q++) S.c_frame[w][q] = fr[q];
+            S.c_g1[w] = g1; S.c_g2[w] = g2;
+          }
+          w++;
+        }
+      }
+      base += total;
+    }
+    if (base > DMK_MAXCON) { overflow |= 1; base = DMK_MAXCON; }
+    ncon = base;
+    SYNC();
+
+    // ---- constraint rows: limits in joint order, then contacts in contact order
+    {
+      bool lim = false;
+      float ldist = 0;
+      int lneg = 0;
+      if (lane >= 6 && lane < DMK_NV && dlimited) {
+        float q = S.qpos[lane + 1];
+        if (q < dlo) { lim = true; ldist = q - dlo; lneg = 0; }
+        else if (q > dhi) { lim = true; ldist = dhi - q; lneg = 1; }
+      }
+      int myrow = prefix_count(lim, lane, &nlimit);
+      if (lim) { S.rowinfo[myrow] = -(((lane << 1) | lneg) + 1); }
+      int dim3 = 0, have = lane < ncon;
+      if (have) {
+        int cd1 = T.g_condim[S.c_g1[lane]], cd2 = T.g_condim[S.c_g2[lane]];
+        dim3 = (cd1 > cd2 ? cd1 : cd2) >= 3;
+      }
+      unsigned long long lt = lanemask_lt(lane);
+      unsigned long long m1 = __ballot(have && !dim3), m4 = __ballot(have && dim3);
+      int roff = nlimit + __popcll(m1 & lt) + 4 * __popcll(m4 & lt);
+      int rtot = nlimit + __popcll(m1) + 4 * __popcll(m4);
+      if (have) {
+        int nr = dim3 ? 4 : 1;
+        for (int e = 0; e < nr; e++)
+          if (roff + e < DMK_MAXROW) S.rowinfo[roff + e] = (lane << 3) | e | (((roff + nr) <= DMK_MAXROW) ? 0x4000 : 0);
+      }
+      if (rtot > DMK_MAXROW) { overflow |= 2; rtot = DMK_MAXROW; }
+      nefc = rtot;
+    }
+    SYNC();
+
+    qacc_out = xs;  // qacc = qacc_smooth when there is no constraint
+    solver_iter = 0;
+    if (nefc > 0) {
+      // ---- Jacobian row, reference acceleration, regulariser (lane = row)
+      float J[DMK_NV];
+      float rpos = 0, rmargin = 0, rdiag = 1, mu = 0;
+      int rtype = -1, full = 0;
+      float wl[3] = {0, 0, 0}, wa[3] = {0, 0, 0};
+      unsigned long long cm1 = 0, cm2 = 0;
+      int ldof = -1;
+      float lsign = 0;
+      if (lane < nefc) {
+        int info = S.rowinfo[lane];
+        if (info < 0) {
+          int v = -info - 1;
+          ldof = v >> 1;
+          lsign = (v & 1) ? -1.f : 1.f;
+          rtype = 0;
+          float q = S.qpos[ldof + 1];
+          rpos = (v & 1) ? (T.d_hi[ldof] - q) : (q - T.d_lo[ldof]);
+          rmargin = 0;
+          rdiag = T.d_invw[ldof];
+        } else {
+          int ci = (info >> 3) & 0x3F, e = info & 7;
+          full = (info & 0x4000) ? 1 : 0;
+          int g1 = S.c_g1[ci], g2 = S.c_g2[ci];
+          int b1 = T.g_body[g1], b2 = T.g_body[g2];
+          int cd1 = T.g_condim[g1], cd2 = T.g_condim[g2];
+          int dim = cd1 > cd2 ? cd1 : cd2;
+          mu = fmaxf(T.g_mu[g1], T.g_mu[g2]);
+          float fr[9];
+          for (int i = 0; i < 9; i++) fr[i] = S.c_frame[ci][i];
+          float tran = T.b_invw[b1] + T.b_invw[b2];
+          if (dim < 3) {
+            rtype = 1;
+            wl[0] = fr[0]; wl[1] = fr[1]; wl[2] = fr[2];
+            rdiag = tran;
+          } else {
+            rtype = 2;
+            int tsel = 3 + 3 * (e >> 1);
+            float sg = (e & 1) ? -mu : mu;
+            wl[0] = fr[0] + sg * fr[tsel]; wl[1] = fr[1] + sg * fr[tsel + 1]; wl[2] = fr[2] + sg * fr[tsel + 2];
+            rdiag = tran + mu * mu * tran;
+          }
+          float off[3] = {S.c_pos[ci][0] - com[0], S.c_pos[ci][1] - com[1], S.c_pos[ci][2] - com[2]};
+          cross3(wa, off, wl);
+          cm1 = S.b_chain[b1]; cm2 = S.b_chain[b2];
+          rpos = S.c_dist[ci];
+          rmargin = fmaxf(T.g_margin[g1], T.g_margin[g2]);
+        }
+      }
+      float vel = 0, jqs = 0, jw = 0;
+#pragma unroll
+      for (int k = 0; k < DMK_NV; k++) {
+        const float4 ca = *reinterpret_cast<const float4 *>(&S.cdof[k][0]);
+        const float2 cb = *reinterpret_cast<const float2 *>(&S.cdof[k][4]);
+        float val = ca.x * wa[0] + ca.y * wa[1] + ca.z * wa[2] + ca.w * wl[0] + cb.x * wl[1] + cb.y * wl[2];
+        float sg = (float)((int)((cm2 >> k) & 1ull) - (int)((cm1 >> k) & 1ull));
+        float j = sg * val;
+        if (rtype == 0) j = (k == ldof) ? lsign : 0.f;
+        if (rtype < 0) j = 0.f;
+        J[k] = j;
+        vel += j * S.qvel[k];
+        jqs += j * S.qacc_smooth[k];
+        jw += j * S.warm[k];
+      }
+      float R = 1, Dd = 0, aref = 0, bb = 0;
+      if (lane < nefc) {
+        float sol[5] = {T.solimp[0], T.solimp[1], T.solimp[2], T.solimp[3], T.solimp[4]};
+        float imp = impedance(sol, rpos, rmargin);
+        R = fmaxf(MINVALF, (1 - imp) * rdiag / imp);
+        if (rtype == 2 && full) R = 2 * mu * mu * R;
+        aref = -T.B * vel - T.K * imp * (rpos - rmargin);
+        bb = jqs - aref;
+        Dd = 1.0f / R;
+      }
+      // ---- B row = D^-1/2 L^-T J^T, in place (lane = row)
+#pragma unroll
+      for (int i = DMK_NV - 1; i >= 1; i--) {
+        const float xi = J[i];
+#pragma unroll
+        for (int j = 0; j < i; j++) J[j] -= S.M[i * DMK_MSTRIDE + j] * xi;
+      }
+#pragma unroll
+      for (int k = 0; k < DMK_NV; k++) J[k] *= S.dsqrtinv[k];
+      // ---- A row: AR[i] = B_lane . B_i (+ R on the diagonal)
+      float AR[DMK_MAXROW];
+      float ARd = R;
+#pragma unroll
+      for (int k = 0; k < DMK_NV; k++) ARd += J[k] * J[k];
+#pragma unroll
+      for (int i = 0; i < DMK_MAXROW; i++) {
+        float acc = 0;
+        if (i < nefc) {
+#pragma unroll
+          for (int k = 0; k < DMK_NV; k++) acc += J[k] * rl(J[k], i);
+          if (lane == i) acc += R;
+        }
+        AR[i] = acc;
+      }
+      const float ARinv = (lane < nefc) ? 1.0f / ARd : 0.f;
+      // ---- warm start (mj_fwdConstraint): forces implied by qacc_warmstart if their dual cost < 0
+      float f = 0, r = bb;
+      {
+        float jar = jw - aref;
+        float fw = (lane < nefc && jar < 0) ? -Dd * jar : 0.f;
+        float rw = bb;
+#pragma unroll
+        for (int i = 0; i < DMK_MAXROW; i++)
+          if (i < nefc) rw += AR[i] * rl(fw, i);
+        float cost = wave_sum(fw * (0.5f * (rw - bb) + bb));
+        if (!(cost > 0)) { f = fw; r = rw; }
+      }
+      // ---- projected Gauss-Seidel: row i's update is broadcast, every lane keeps its own residual
+      const float scale = T.pgs_scale, tol = T.tolerance;
+      int iter = 0;
+      while (iter < T.iterations) {
+        float impv = 0;
+#pragma unroll
+        for (int i = 0; i < DMK_MAXROW; i++) {
+          if (i < nefc) {
+            float fn = fmaxf(0.f, f - r * ARinv);
+            float dl = fn - f;
+            float dli = rl(dl, i);
+            if (dli != 0.f) {
+              float ri = rl(r, i), aii = rl(ARd, i);
+              impv -= 0.5f * dli * dli * aii + dli * ri;
+              r = fmaf(AR[i], dli, r);
+              if (lane == i) f = fn;
+            }
+          }
+        }
+        iter++;
+        if (impv * scale < tol) break;
+      }
+      solver_iter = iter;
+      // ---- qacc = qacc_smooth + L^-1 D^-1/2 sum_r f_r B_r
+      float v = 0;
+#pragma unroll
+      for (int k = 0; k < DMK_NV; k++) {
+        float s = wave_sum(f * J[k]);
+        if (lane == k) v = s;
+      }
+      v *= S.dsqrtinv[lk];
+#pragma unroll
+      for (int j = 0; j < DMK_NV - 1; j++) {
+        float xj = rl(v, j);
+        float l = S.M[lk * DMK_MSTRIDE + j];
+        if (lane > j && lane < DMK_NV) v -= l * xj;
+      }
+      qacc_out = xs + v;
+      if (P.debug && lane < DMK_MAXROW) P.debug[(size_t)env * DM_DEBUG_STRIDE + 352 + lane] = (lane < nefc) ? f : 0.f;
+    }
+    SYNC();
+    if (lane < DMK_NV) { S.qacc[lk] = qacc_out; S.warm[lk] = qacc_out; }
+    SYNC();
+    if (it < 4) { stage_ncon |= (unsigned)(ncon & 0xFF) << (8 * it); stage_nefc |= (unsigned)(nefc & 0xFF) << (8 * it); }
+    // ============================================================== end of forward evaluation
+    if (it == 0 || (it == 4 && mode == DMK_MODE_FORCED && !after_reset)) {  // mj_checkAcc
+      bool badv = (lane < DMK_NV) && !(fabsf(qacc_out) <= MAXVALF);
+      sim_err = __any(badv);
+    }
+   }  // !sim_err
+
+    if (!sim_err && it < 3) {  // RK4 intermediate stages (tableau A = diag(1/2, 1/2, 1), B = 1/6 1/3 1/3 1/6)
+      const float Bw = (it == 0) ? (1.f / 6.f) : (1.f / 3.f);
+      const float Aw = (it == 2) ? 1.f : 0.5f;
+      accq += Bw * curv;
+      accv += Bw * qacc_out;
+      float dq = Aw * curv, dv = Aw * qacc_out;
+      curv = x0v + h * dv;
+      float w3[3] = {rl(dq, 3), rl(dq, 4), rl(dq, 5)};
+      float wn = sqrtf(dot3(w3, w3));
+      float qr[4] = {1, 0, 0, 0}, qn[4];
+      if (wn >= MINVALF) {
+        float s, c;
+        sincosf(0.5f * h * wn, &s, &c);
+        float inv = s / wn;
+        qr[0] = c; qr[1] = w3[0] * inv; qr[2] = w3[1] * inv; qr[3] = w3[2] * inv;
+      }
+      quat_mul(qn, q0, qr);
+      quat_normalize(qn);
+      if (lane < DMK_NV) S.qvel[lk] = curv;
+      if (lane < 3) S.qpos[lane] = x0q + h * dq;
+      if (lane >= 6 && lane < DMK_NV) S.qpos[lane + 1] = x0q + h * dq;
+      if (lane < 4) S.qpos[3 + lane] = (lane == 0) ? qn[0] : (lane == 1) ? qn[1] : (lane == 2) ? qn[2] : qn[3];
+      SYNC();
+      it++;
+      continue;
+    }
+    if (!sim_err && it == 3) {  // final combination (mj_advance with the RK4 weights)
+      accq += (1.f / 6.f) * curv;
+      accv += (1.f / 6.f) * qacc_out;
+      float w3[3] = {rl(accq, 3), rl(accq, 4), rl(accq, 5)};
+      float wn = sqrtf(dot3(w3, w3));
+      float qr[4] = {1, 0, 0, 0}, qn[4];
+      if (wn >= MINVALF) {
+        float s, c;
+        sincosf(0.5f * h * wn, &s, &c);
+        float inv = s / wn;
+        qr[0] = c; qr[1] = w3[0] * inv; qr[2] = w3[1] * inv; qr[3] = w3[2] * inv;
+      }
+      quat_mul(qn, q0, qr);
+      quat_normalize(qn);
+      if (lane < DMK_NV) S.qvel[lk] = x0v + h * accv;
+      if (lane < 3) S.qpos[lane] = x0q + h * accq;
+      if (lane >= 6 && lane < DMK_NV) S.qpos[lane + 1] = x0q + h * accq;
+      if (lane < 4) S.qpos[3 + lane] = (lane == 0) ? qn[0] : (lane == 1) ? qn[1] : (lane == 2) ? qn[2] : qn[3];
+      SYNC();
+    }
+
+    // ============================================================== task layer: obs, reward, done
+    // (derived arrays are those of the LAST forward evaluation: SURVEY F6)
+    const bool task_pass = !after_reset && (mode == DMK_MODE_STEP || mode == DMK_MODE_FORCED);
+    float obs_a = 0, obs_b = 0;  // obs[lane], obs[64 + lane]
+    float terms[5] = {0, 0, 0, 0, 0};
+    if (sim_err) {
+      // MujocoException path (:366-378): zero obs, zero reward, done, empty info; MuJoCo resets mjData
+      reward = 0; done = true; reason = DM_REASON_SIM_ERROR;
+      SYNC();
+      if (lane < DMK_NQ) S.qpos[lane] = T.qpos0[lane];
+      if (lane < DMK_NV) { S.qvel[lane] = 0; S.warm[lane] = 0; }
+      if (lane < DMK_NU) S.ctrl[lane] = 0;
+      SYNC();
+    } else {
+      // ---- get_obs (:33-45): qpos[7:], 0.1*qvel[6:], torso(8), foot contacts(2), phase(1)
+      const float Sc = P.vel_obs_scale;
+      if (lane < 28) obs_a = S.qpos[7 + lane];
+      else if (lane < 56) obs_a = S.qvel[6 + lane - 28] * Sc;
+      const int tb = T.torso_body;
+      float rpy[3], tq[4] = {S.xquat[tb][0], S.xquat[tb][1], S.xquat[tb][2], S.xquat[tb][3]};
+      quat_to_rpy(tq, rpy);
+      float cv[6];
+      for (int i = 0; i < 6; i++) cv[i] = S.cvel[tb][i];
+      float sy, cy;
+      sincosf(-rpy[2], &sy, &cy);
+      const float tor[8] = {rpy[0] * Sc, rpy[1] * Sc, (cy * cv[3] - sy * cv[4]) * Sc, (sy * cv[3] + cy * cv[4]) * Sc,
+                            cv[5] * Sc, cv[0] * Sc, cv[1] * Sc, cv[2] * Sc};
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        if (lane == 56 + i) obs_a = tor[i];
+      bool rf = false, lf = false;
+      if (lane < ncon) {
+        int g1 = S.c_g1[lane], g2 = S.c_g2[lane];
+        bool fl = (g1 == T.floor_geom || g2 == T.floor_geom);
+        rf = fl && (g1 == T.rfoot_geom || g2 == T.rfoot_geom);
+        lf = fl && (g1 == T.lfoot_geom || g2 == T.lfoot_geom);
+      }
+      const float rff = __any(rf) ? 1.f : 0.f, lff = __any(lf) ? 1.f : 0.f;
+      const float ph = clampf((float)idx_curr / (float)clip.L, 0.f, 1.f);
+      if (lane == 0) obs_b = rff;
+      if (lane == 1) obs_b = lff;
+      if (lane == 2) obs_b = ph;
+
+      if (task_pass) {
+        // ---- calc_imitation_reward (:193-256) against clip row idx_curr
+        // row: [0:28) qpos[7:] | [28:56) qvel[6:] | [56:60) root quat | [60:72) ee xpos | [72:75) com
+        const float *row = clip.rows + (size_t)idx_curr * DMK_CLIP_ROW;
+        const float ra = row[lane];
+        float ecfg = wave_sum((lane < 28) ? fabsf(S.qpos[7 + (lane < 28 ? lane : 0)] - ra) : 0.f);
+        const float evel = wave_sum((lane >= 28 && lane < 56) ? fabsf(ra - S.qvel[6 + ((lane >= 28 && lane < 56) ? lane - 28 : 0)]) : 0.f);
+        const float tquat[4] = {rl(ra, 56), rl(ra, 57), rl(ra, 58), rl(ra, 59)};
+        const float cq[4] = {S.qpos[3], S.qpos[4], S.qpos[5], S.qpos[6]};
+        float rc[3], rt[3];
+        quat_to_rpy(cq, rc);
+        quat_to_rpy(tquat, rt);
+        ecfg += fabsf(rc[1] - rt[1]);
+        const float r_cfg = expf(-ecfg);
+        const float r_vel = expf(-0.1f * evel);
+        float df = 0;
+        if (lane < 12) {
+          int e = lane / 3, cc = lane % 3;
+          df = S.gpos[T.ee_geom[e]][cc] - row[60 + lane];
+        }
+        const float r_ee = expf(-40.f * wave_sum(df * df));
+        float ce = 0;
+        for (int i = 0; i < 3; i++) {
+          float d2 = row[72 + i] - wave_sum(bmass * S.xpos[lb][i]) * mtot_inv;
+          ce += d2 * d2;
+        }
+        const float r_com = expf(-10.f * ce);
+        float viol = 0;
+        if (lane >= 6 && lane < DMK_NV) {
+          float q = S.qpos[lane + 1];
+          viol = ((q <= dlo * 0.99f) ? 1.f : 0.f) + ((q >= dhi * 0.99f) ? 1.f : 0.f);
+        }
+        const float qlim = wave_sum(viol) / 28.0f;
+        terms[0] = r_cfg; terms[1] = r_vel; terms[2] = r_ee; terms[3] = r_com; terms[4] = qlim;
+        reward = P.w_pose * r_cfg + P.w_vel * r_vel + P.w_ee * r_ee + P.w_com * r_com + P.w_jl * qlim;
+        // ---- termination (:418-442)
+        const float zc = S.com[2];
+        done = (zc < P.low_z) || (zc > P.high_z);
+        reason = (zc < P.low_z) ? DM_REASON_LOW_Z : DM_REASON_HIGH_Z;
+        if (P.max_ep_length != 0 && ep_len >= P.max_ep_length) { done = true; reason = DM_REASON_MAX_EP_LEN; }
+        // ---- post-step counters (:452-455)
+        idx_curr = (idx_curr + 1) % clip.L;
+        ep_rew += reward;
+        ep_len += 1;
+        // ---- observation guard (:465-476)
+        bool ob = !(fabsf(obs_a) <= P.obs_bound) || !(fabsf(obs_b) <= P.obs_bound);
+        if (__any(ob)) {
+          obs_a = 0; obs_b = 0; reward = 0; done = true; reason = DM_REASON_OBS_BOUNDS;
+          for (int i = 0; i < 5; i++) terms[i] = 0;
+        }
+      }
+    }
+    if (P.debug && !after_reset) {
+      float *dbg = P.debug + (size_t)env * DM_DEBUG_STRIDE;
+      if (lane < 42) dbg[lane] = (&S.xpos[0][0])[lane];
+      if (lane < 48) dbg[42 + lane] = (&S.gpos[0][0])[lane];
+      for (int i = lane; i < 84; i += 64) dbg[90 + i] = (&S.cvel[0][0])[i];
+      if (lane < DMK_NV) { dbg[174 + lane] = S.qacc[lane]; dbg[208 + lane] = S.qacc_smooth[lane]; }
+      if (lane == 0) { dbg[242] = ncon; dbg[243] = nefc; dbg[244] = solver_iter; dbg[245] = nlimit; dbg[246] = overflow;
+                       dbg[247] = __int_as_float((int)stage_ncon); dbg[248] = __int_as_float((int)stage_nefc); }
+      if (lane < DMK_MAXCON) {
+        dbg[256 + 3 * lane] = (lane < ncon) ? (float)S.c_g1[lane] : -1.f;
+        dbg[257 + 3 * lane] = (lane < ncon) ? (float)S.c_g2[lane] : -1.f;
+        dbg[258 + 3 * lane] = (lane < ncon) ? S.c_dist[lane] : 0.f;
+      }
+    }
+    if (task_pass) {
+      if (P.rew && lane == 0) P.rew[env] = reward;
+      if (P.done && lane == 0) P.done[env] = done ? 1 : 0;
+      if (P.reason && lane == 0) P.reason[env] = reason;
+      if (P.terms && lane < 5)
+        P.terms[(size_t)env * 5 + lane] = (lane == 0) ? terms[0] : (lane == 1) ? terms[1] : (lane == 2) ? terms[2] : (lane == 3) ? terms[3] : terms[4];
+      if (done && P.auto_reset && mode == DMK_MODE_STEP) {
+        // VecEnv worker: info["terminal_observation"] = obs; obs = env.reset()
+        if (P.terminal_obs) {
+          P.terminal_obs[(size_t)env * DM_NOBS + lane] = obs_a;
+          if (lane < 3) P.terminal_obs[(size_t)env * DM_NOBS + 64 + lane] = obs_b;
+        }
+        const int fi = (int)(dm_hash32(P.seed, env, rcnt, 0x5EED) % (uint32_t)clip.L);
+        rcnt++;
+        const float *rr = clip.reset + (size_t)fi * DMK_RESET_ROW;
+        SYNC();
+        if (lane < DMK_NQ) S.qpos[lane] = rr[lane];
+        if (lane < DMK_NV) S.qvel[lane] = rr[35 + lane];
+        idx_curr = fi; ep_len = 0; ep_rew = 0;
+        SYNC();
+        after_reset = true;
+        sim_err = false;
+        it = 4;
+        continue;  // one more forward evaluation at the reset state (set_state -> sim.forward)
+      }
+    }
+    if (P.obs) {
+      P.obs[(size_t)env * DM_NOBS + lane] = obs_a;
+      if (lane < 3) P.obs[(size_t)env * DM_NOBS + 64 + lane] = obs_b;
+    }
+    break;
+  }
+
+  // ---------------------------------------------------------------- state write-back
+  if (lane < DMK_NQ) st[DMS_QPOS + lane] = S.qpos[lane];
+  if (lane < DMK_NV) { st[DMS_QVEL + lane] = S.qvel[lane]; st[DMS_WARM + lane] = S.warm[lane]; }
+  if (lane < DMK_NU) st[DMS_CTRL + lane] = S.ctrl[lane];
+  if (lane == 0) { sti[DMS_IDX] = idx_curr; sti[DMS_EPLEN] = ep_len; st[DMS_EPREW] = ep_rew; sti[DMS_RCNT] = rcnt; }
+}
+
+// Uniform random actions in [-2, 2) for bench.py config 2 (same generator as the oracle driver).
+extern "C" __global__ void dm_fill_actions_kernel(float *actions, int n, uint64_t seed, uint32_t step) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * DMK_NU) return;
+  int env = i / DMK_NU, j = i % DMK_NU;
+  actions[i] = -2.0f + 4.0f * (float)(dm_hash32(seed, env, step, j) >> 8) * (1.0f / 16777216.0f);
+}

@@ -1,0 +1,130 @@
+/*
+ * deepmimic_hip.h — C-ABI of libdeepmimic_hip.so (MI355X / gfx950).
+ *
+ * The reference has no FFI boundary of its own on this path: DPEnv.step() calls
+ * gym's MujocoEnv.do_simulation -> mujoco_py.MjSim.step (Cython) -> libmujoco
+ * (src/deepmimic_env.py:301,357,362).  This header is the boundary the build adds
+ * underneath the reference's two Python protocol surfaces (gym.Env per-env,
+ * SB3 VecEnv batched).  Each entry point cites what it replaces.
+ *
+ * Conventions: plain pointers and sizes only; returns 0 on success or a negative
+ * DM_E* code, never throws; every buffer pointer is CALLER-OWNED DEVICE memory
+ * (e.g. torch.Tensor.data_ptr()) unless the name says `host_`; work is
+ * stream-ordered on the hipStream_t passed as `void* stream` (NULL = default
+ * stream); the library owns only its internal per-env state.  Re-entrant per
+ * handle, no global mutable state (an eval env may live on another thread,
+ * src/sb3_ppo.py:173-174).
+ */
+#ifndef DEEPMIMIC_HIP_H
+#define DEEPMIMIC_HIP_H
+
+#include <stdint.h>
+
+#include "dm_model.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct DmEngine *DmHandle;
+
+#define DM_OK 0
+#define DM_EINVAL (-22)
+#define DM_ENOMEM (-12)
+#define DM_EHIP (-5)
+#define DM_ENODEV (-19)
+
+#define DM_MAX_CLIPS 8
+
+/* done_reason codes (src/deepmimic_env.py:424,438,442 strings; :366-378 and :465-476 early-outs) */
+#define DM_REASON_NONE 0
+#define DM_REASON_LOW_Z 1
+#define DM_REASON_HIGH_Z 2
+#define DM_REASON_MAX_EP_LEN 3
+#define DM_REASON_ACYCLIC_END 4
+#define DM_REASON_SIM_ERROR 5
+#define DM_REASON_OBS_BOUNDS 6
+
+/* Task configuration — DPEnvConfig (src/deepmimic_env.py:258-270), RobotConfig.low_z
+ * (src/config.py:13) and the reward weights hard-coded in step() (:400-404). */
+typedef struct DmConfig {
+  int32_t num_envs;
+  int32_t max_ep_length;   /* 1000 */
+  float vel_obs_scale;     /* 0.1 */
+  float low_z, high_z;     /* 0.7, 2.0 */
+  float w_pose, w_vel, w_end_eff, w_com, w_joint_limit; /* 0.75 0.1 0.15 0.0 -0.1 */
+  float obs_bound;         /* 100.0 */
+  uint64_t seed;           /* counter-based RNG seed for reference-state-init resets */
+  int32_t auto_reset;      /* 1: SubprocVecEnv worker semantics (reset inside step when done) */
+  int32_t device;          /* HIP device ordinal */
+} DmConfig;
+
+void dm_default_config(DmConfig *cfg);
+
+/* Replaces: MujocoEnv.__init__(xml, 6) -> load_model_from_path + MjSim (deepmimic_env.py:301),
+ * one instance per batch instead of one per SubprocVecEnv worker (src/sb3_ppo.py:275). */
+int dm_create(const DmModel *model, const DmConfig *cfg, DmHandle *out);
+int dm_destroy(DmHandle h);
+const char *dm_last_error(DmHandle h);
+int dm_num_envs(DmHandle h);
+
+/* Replaces: DPEnv.load_mocap -> MocapDM tables (deepmimic_env.py:321-324; mocap_v2.py:338-348).
+ * HOST float64 tables: qpos[L*35], qvel[L*34], body_xpos[L*14*3], geom_xpos[L*16*3]. */
+int dm_load_clip(DmHandle h, int clip_id, int L, const double *host_qpos, const double *host_qvel,
+                 const double *host_body_xpos, const double *host_geom_xpos);
+/* Per-env clip assignment (device int32[N]; NULL = all envs use clip 0). */
+int dm_set_env_clips(DmHandle h, const int32_t *clip_ids, void *stream);
+
+/* Replaces: DPEnv.reset()/reset_model(idx_init) (deepmimic_env.py:496-510) for the envs with
+ * mask[i] != 0 (mask NULL = all).  idx_init NULL = random frame from the engine RNG
+ * (reference_state_init, :312-316).  obs_out float[N*67] (rows of unmasked envs untouched). */
+int dm_reset(DmHandle h, const uint8_t *mask, const int32_t *idx_init, float *obs_out, void *stream);
+
+/* Replaces: DPEnv.step(action) for every env (deepmimic_env.py:335-484) plus the VecEnv worker's
+ * auto-reset.  actions float[N*28]; obs float[N*67]; rew float[N]; done uint8[N];
+ * terms float[N*5] = reward_config, reward_qvel, reward_end_eff, reward_com, reward_joint_limit
+ * (:251-255); reason int32[N]; terminal_obs float[N*67] (written for done envs).  terms, reason,
+ * terminal_obs may be NULL. */
+int dm_step(DmHandle h, const float *actions, float *obs, float *rew, uint8_t *done, float *terms,
+            int32_t *reason, float *terminal_obs, void *stream);
+
+/* Replaces: DPEnv.step(action, force_state=(qpos, qvel)) (deepmimic_env.py:355-357): set_state +
+ * sim.forward, then obs/reward/done exactly as step().  qpos float[N*35], qvel float[N*34].
+ * No auto-reset on this path. */
+int dm_step_forced(DmHandle h, const float *qpos, const float *qvel, float *obs, float *rew,
+                   uint8_t *done, float *terms, int32_t *reason, void *stream);
+
+/* Replaces: MujocoEnv.set_state (+ sim.forward) and sim.get_state for n envs listed in env_ids
+ * (device int32[n]; NULL = envs 0..n-1).  qacc_warmstart/ctrl may be NULL (left unchanged / not
+ * returned).  Used for teacher-forced parity tests and checkpointing of the env batch. */
+int dm_set_state(DmHandle h, const int32_t *env_ids, int n, const float *qpos, const float *qvel,
+                 const float *qacc_warmstart, const float *ctrl, int run_forward, void *stream);
+int dm_get_state(DmHandle h, const int32_t *env_ids, int n, float *qpos, float *qvel,
+                 float *qacc_warmstart, float *ctrl, void *stream);
+/* task counters: idx_curr, episode_length int32[N]; episode_reward float[N] (deepmimic_env.py:452-455) */
+int dm_get_counters(DmHandle h, int32_t *idx_curr, int32_t *episode_length, float *episode_reward,
+                    void *stream);
+int dm_set_counters(DmHandle h, const int32_t *idx_curr, const int32_t *episode_length, void *stream);
+
+/* Derived quantities of the LAST forward evaluation of every env, for parity tests:
+ * sim.data.body_xpos/geom_xpos/cvel/qacc and the contact list.  Layout per env (floats):
+ *   [0:42) xpos 14x3 | [42:90) geom_xpos 16x3 | [90:174) cvel 14x6 | [174:208) qacc |
+ *   [208:242) qacc_smooth | 242 ncon | 243 nefc | 244 solver_iter | 245 nlimit | 246 overflow |
+ *   247/248 per-RK-stage ncon / nefc packed one byte per stage (int32 bit pattern) |
+ *   [256:256+3*32) contacts: (geom1, geom2, dist) x 32 | [352:416) efc_force
+ * => DM_DEBUG_STRIDE floats per env. Enabled by dm_set_debug(h, buf) with buf float[N*stride] or NULL. */
+#define DM_DEBUG_STRIDE 416
+int dm_set_debug(DmHandle h, float *debug_buf);
+
+/* Device-side uniform random actions in [-2,2) from the counter-based generator shared with the
+ * oracle's baseline driver (oracle/dm_oracle.c: hash32), for bench.py config 2. */
+int dm_fill_random_actions(DmHandle h, float *actions, uint32_t step_index, void *stream);
+
+/* Timing of the step kernel on the engine's stream with HIP events (ms of the last dm_step). */
+int dm_last_step_ms(DmHandle h, float *ms);
+int dm_enable_timing(DmHandle h, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPMIMIC_HIP_H */

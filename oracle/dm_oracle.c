@@ -619,6 +619,12 @@ static int c_box_box(RawCon *c, double margin, const double *p1, const double *R
     memset(c[cnt].tangent, 0, sizeof c[cnt].tangent);
     cnt++;
   }
+  while (cnt > 4) { /* keep the 4 deepest, preserving polygon order (one lane holds 4 slots on the GPU) */
+    int w = 0;
+    for (int q = 1; q < cnt; q++) if (c[q].dist >= c[w].dist) w = q;
+    for (int q = w; q < cnt - 1; q++) c[q] = c[q + 1];
+    cnt--;
+  }
   return cnt;
 }
 
@@ -965,6 +971,7 @@ int dmo_step(const DmModel *m, DmoData *d) { /* [EXT] mj_step with mj_RungeKutta
   if (bad(d->qpos, NQ) || bad(d->qvel, NV)) return 1;
   forward_nocheck(m, d);
   if (bad(d->qacc, NV)) return 1;
+  d->stage_ncon[0] = d->ncon; d->stage_nefc[0] = d->nefc;
   double h = m->timestep;
   if (m->integrator == DM_INT_RK4) {
     static const double A[3][3] = {{0.5, 0, 0}, {0, 0.5, 0}, {0, 0, 1}};
@@ -987,6 +994,7 @@ int dmo_step(const DmModel *m, DmoData *d) { /* [EXT] mj_step with mj_RungeKutta
       memcpy(Xv[i], d->qvel, sizeof X0v);
       d->time = t0 + Ct[i - 1] * h;
       forward_nocheck(m, d);
+      d->stage_ncon[i] = d->ncon; d->stage_nefc[i] = d->nefc;
       memcpy(F[i], d->qacc, sizeof X0v);
     }
     double dq[NV], dv[NV];
@@ -1226,6 +1234,8 @@ int dmo_get_int(const DmoData *d, const char *name) {
   if (!strcmp(name, "overflow_row")) return d->overflow_row;
   if (!strcmp(name, "maxcon")) return d->maxcon;
   if (!strcmp(name, "maxrow")) return d->maxrow;
+  if (!strncmp(name, "stage_ncon", 10)) return d->stage_ncon[name[10] - '0'];
+  if (!strncmp(name, "stage_nefc", 10)) return d->stage_nefc[name[10] - '0'];
   return -1;
 }
 int dmo_set_caps(DmoData *d, int maxcon, int maxrow) {

@@ -61,6 +61,7 @@ typedef struct DmoData {
   double qacc_smooth[DM_NV], qacc[DM_NV];
   int32_t ncon, nefc, solver_iter, nlimit;
   int32_t overflow_con, overflow_row; /* counts of dropped contacts / rows */
+  int32_t stage_ncon[4], stage_nefc[4]; /* per RK stage of the last dmo_step (test diagnostics) */
   DmoContact contact[DMO_MAXCON];
   int32_t efc_type[DMO_MAXROW], efc_id[DMO_MAXROW]; /* 0 limit, 1 frictionless, 2 pyramidal */
   double efc_pos[DMO_MAXROW], efc_margin[DMO_MAXROW], efc_diagApprox[DMO_MAXROW];
