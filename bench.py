@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the HIP DPEnv.step() path (BASELINE.json configs[1]).
+
+Workload ("cfg2_random_torque"): 4096 humanoid3d envs per GPU on the `walk` clip, each reset to
+frame env%L, actions ~ U(-2,2)^28 from the counter-based generator shared with the oracle,
+full step() = RK4 mj_step-equivalent + obs + imitation reward + termination + auto-reset.
+One "step" = one dm_step over the whole batch; inputs/outputs stay resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement) with `roofline`
+(HBM-bound accounting of the step kernel, measured live with HIP events on the launch stream)
+and `cpu_baseline` (the fp64 oracle timed on this box's host cores, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_ENV_STEP = 1260      # 315 fp32 words of state in/out
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(model, mocap, budget_s=12.0):
+    """Oracle DPEnv.step() on host cores: 1 thread, bounded sample of the same workload."""
+    from oracle.oracle import OracleClip, bench_steps
+    clip = OracleClip(*mocap.tables())
+    nenv, nsteps = 4, 250
+    t0 = time.perf_counter()
+    bench_steps(model, clip, nenv, nsteps, 1234)
+    dt = time.perf_counter() - t0
+    rate = nenv * nsteps / dt
+    # scale the sample to the budget and time again for the reported figure
+    nenv2 = max(4, min(256, int(rate * budget_s / 1000)))
+    t0 = time.perf_counter()
+    bench_steps(model, clip, nenv2, 1000, 1234)
+    dt = time.perf_counter() - t0
+    return {"value": nenv2 * 1000 / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d envs x 1000 random-torque steps, walk clip, fp64 oracle (oracle/dm_oracle.c), 1 thread" % nenv2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (BASELINE: 4096)")
+    ap.add_argument("--motion", default="walk")
+    ap.add_argument("--actions", default="random", choices=["random", "zero"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from deepmimic_mujoco_amd.model import load_model
+    from deepmimic_mujoco_amd.mocap import MocapDM
+    from deepmimic_mujoco_amd.config import MotionConfig
+    from deepmimic_mujoco_amd._lib import HipEngine
+
+    model = load_model()
+    mocap = MocapDM(model=model)
+    mocap.load_mocap(MotionConfig(args.motion).mocap_path)
+    N = args.envs
+    eng = HipEngine(model, N, device=local_rank, seed=1234 + rank, auto_reset=True)
+    eng.load_clip(0, mocap)
+    L = eng.clip_len[0]
+    out = eng.alloc_outputs()
+    actions = torch.zeros(N, 28, device=dev)
+    eng.reset(out["obs"], idx_init=(torch.arange(N, device=dev) % L).to(torch.int32))
+
+    def one_step(i):
+        if args.actions == "random":
+            eng.fill_random_actions(actions, i)
+        eng.step(actions, out)
+
+    for i in range(args.warmup):
+        one_step(i)
+    eng.enable_timing(True)
+    kernel_ms = []
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+        if i % 8 == 7 or i == args.steps - 1:   # sample the kernel duration (event sync drains the stream)
+            kernel_ms.append(eng.last_step_ms())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    done_frac = float(out["done"].float().mean().item())
+
+    if rank == 0:
+        total_steps = args.steps * N * world
+        value = total_steps / dt
+        kms = float(np.mean(kernel_ms))
+        achieved = N * ALGO_BYTES_PER_ENV_STEP / (kms * 1e-3) / 1e9
+        line = {
+            "metric": "env-steps/sec (whole node), 34-DoF humanoid, 4096 envs, at 1/2/4/8 MI355X",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg2_random_torque: %d envs/GPU, humanoid3d, clip %s, RK4 h=0.0166 PGS<=50, "
+                                   "full DPEnv.step (physics+obs+reward+done+auto-reset), actions %s"
+                                   % (N, args.motion, "U(-2,2) device RNG" if args.actions == "random" else "zero"),
+                       "envs_per_gpu": N, "parallelism": "env-sharded x%d, no data-path collective" % world,
+                       "done_fraction_last_step": done_frac},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "dm_step_kernel", "kernel_ms": kms,
+                         "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(model, mocap)
+        print(json.dumps(line))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -46,6 +46,9 @@ def load_library():
         raise RuntimeError(
             "libdeepmimic_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C deepmimic_mujoco_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    # PyTorch bundles its own libamdhip64.so.7; import it first so this library binds to the SAME
+    # HIP runtime instance (two runtimes in one process cannot share a device context).
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i32 = C.c_void_p, C.c_int
     L.dm_default_config.argtypes = [C.POINTER(DmConfig)]

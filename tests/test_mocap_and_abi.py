@@ -1,0 +1,96 @@
+"""CPU tests: mocap loader behaviour, package surfaces, C-ABI exports (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_clip_lengths_and_singularity_fix_counts(clips):
+    # L = 76 / 48 / 153 / 78 and the continuity fix fires 1 / 17 / 51 / 97 times
+    assert {k: len(v.data_config) for k, v in clips.items()} == {"walk": 76, "run": 48, "dance_b": 153, "spinkick": 78}
+    assert {k: v.singularity_fired for k, v in clips.items()} == {"walk": 1, "run": 17, "dance_b": 51, "spinkick": 97}
+
+
+def test_clip_tables_are_consistent(model, clips):
+    from deepmimic_mujoco_amd.model import forward_kinematics
+    for name, mc in clips.items():
+        q, v, b, g = mc.tables()
+        assert q.shape[1] == 35 and v.shape[1] == 34 and b.shape[1:] == (14, 3) and g.shape[1:] == (16, 3)
+        assert not v[0].any()                                  # frame 0 velocity is zero (mocap_v2.py:278-279)
+        step = 2 if name in ("walk", "run") else 1             # raw (non-lerped) frames
+        for i in range(0, len(q), step * 5):
+            kin = forward_kinematics(model, q[i])
+            assert np.abs(kin["geom_xpos"] - g[i]).max() < 1e-12   # intent of deepmimic_env.py:540-554
+        # joint angles stay inside the model's ranges (the purpose of the singularity fix)
+        lo, hi = model.jnt_range[1:, 0], model.jnt_range[1:, 1]
+        viol = ((q[:, 7:] < lo - 0.2) | (q[:, 7:] > hi + 0.2)).mean()
+        assert viol < 0.02
+
+
+def test_interpolation_and_invalid_dt(tmp_path, model):
+    import json
+    from deepmimic_mujoco_amd.config import MotionConfig
+    from deepmimic_mujoco_amd.mocap import MocapDM
+    data = json.load(open(MotionConfig("walk").mocap_path))
+    for fr in data["Frames"]:
+        fr[0] = 0.0625                                          # humanoid3d_backflip's dt: ratio 3.75 -> must raise
+    p = tmp_path / "humanoid3d_bad.txt"
+    p.write_text(json.dumps(data))
+    with pytest.raises(Exception, match="Invalid dt ratio"):
+        MocapDM(model=model).load_mocap(str(p))
+
+
+def test_rot_vel_is_body_frame_angular_velocity():
+    from deepmimic_mujoco_amd.mocap import calc_rot_vel
+    from deepmimic_mujoco_amd.model import axis_angle_quat, quat_mul
+    q0 = axis_angle_quat(np.array([0, 0, 1.0]), 0.7)
+    dq = axis_angle_quat(np.array([1.0, 0, 0]), 0.02)
+    w = calc_rot_vel(q0, quat_mul(q0, dq), 0.01)
+    assert np.allclose(w, [2.0, 0, 0], atol=1e-9)
+    assert calc_rot_vel(q0, q0, 0.01) == [0.0, 0.0, 0.0]
+
+
+def test_config_mirrors_reference_names():
+    from deepmimic_mujoco_amd.config import MotionConfig, RobotConfig
+    rc = RobotConfig()
+    assert rc.torso_body_name == "chest" and rc.low_z == 0.7
+    assert rc.endeffector_geom_names == ["left_ankle", "right_ankle", "left_wrist", "right_wrist"]
+    mc = MotionConfig()
+    assert mc.motion == "walk" and os.path.exists(mc.mocap_path) and os.path.exists(mc.xml_path)
+    assert "getup_facedown" in mc.floor_motions and "walk" not in mc.acyclical_motions
+    with pytest.raises(NotImplementedError):
+        RobotConfig("unitree_g1")
+
+
+def test_c_abi_library_loads_and_exports_every_declared_symbol():
+    from deepmimic_mujoco_amd import _lib
+    L = _lib.load_library()
+    hdr = open(os.path.join(ROOT, "include", "deepmimic_hip.h")).read()
+    declared = set(re.findall(r"\b(dm_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert getattr(L, name) is not None
+    cfg = _lib.default_config()
+    assert cfg.max_ep_length == 1000 and abs(cfg.vel_obs_scale - 0.1) < 1e-7 and abs(cfg.w_joint_limit + 0.1) < 1e-7
+
+
+def test_engine_fails_loudly_without_gpu(model):
+    import torch
+    from deepmimic_mujoco_amd._lib import HipEngine
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        HipEngine(model, 4)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "deepmimic_mujoco_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "dm_oracle.h" not in src, f
