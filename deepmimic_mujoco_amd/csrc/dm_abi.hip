@@ -273,12 +273,13 @@ static void fill_launch(DmEngine *e, DmLaunch &P, int mode) {
   P.debug = e->debug;
 }
 
-static int launch(DmEngine *e, const DmLaunch &P, int nblocks, void *stream) {
+static int launch(DmEngine *e, DmLaunch &P, int nslots, void *stream) {
+  P.nslots = nslots;
   if (e->clipL[0] < 1) return fail(e, DM_EINVAL, "no clip loaded (dm_load_clip clip 0 first)");
   HIPCHK(e, hipSetDevice(e->cfg.device));
   hipStream_t s = (hipStream_t)stream;
   if (e->timing) hipEventRecord(e->ev0, s);
-  hipLaunchKernelGGL(dm_step_kernel, dim3(nblocks), dim3(64), 0, s, P);
+  hipLaunchKernelGGL(dm_step_kernel, dim3((P.nslots + DMK_ENVS_PER_BLOCK - 1) / DMK_ENVS_PER_BLOCK), dim3(64 * DMK_ENVS_PER_BLOCK), 0, s, P);
   if (e->timing) hipEventRecord(e->ev1, s);
   HIPCHK(e, hipGetLastError());
   return DM_OK;

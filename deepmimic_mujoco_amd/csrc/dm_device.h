@@ -74,10 +74,6 @@ struct EnvLds {
   float c_dist[DMK_MAXCON], c_pos[DMK_MAXCON][3], c_frame[DMK_MAXCON][9];
   int32_t c_g1[DMK_MAXCON], c_g2[DMK_MAXCON];
   int32_t rowinfo[DMK_MAXROW];        // contact rows: (contact << 3) | edge ; limit rows: -1
-  uint64_t b_chain[16];
-  uint8_t d_anc[DMK_NV][DMK_MAXANC];
-  uint8_t tri_a[80], tri_b[80];
-  int32_t d_nanc[36];
   // velocity-stage scratch (dead before the constraint stage) / box-box polygon scratch
   union {
     struct {
@@ -124,7 +120,7 @@ struct DmLaunch {
   const DmDev *T;
   float *state;                 // N x DMK_STATE_STRIDE
   DmClipDev clips[8];
-  int32_t N, mode, auto_reset, max_ep_length;
+  int32_t N, nslots, mode, auto_reset, max_ep_length;
   float vel_obs_scale, low_z, high_z, obs_bound;
   float w_pose, w_vel, w_ee, w_com, w_jl;
   uint64_t seed;

@@ -16,7 +16,25 @@
 
 #include <math.h>
 
-#define SYNC() __syncthreads()
+// One wavefront owns one environment, so LDS hand-offs between phases only need ordering inside the
+// wave: DS operations of a wave execute in order; the fences stop the compiler moving LDS accesses.
+#define SYNC()                                              \
+  do {                                                      \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+    __builtin_amdgcn_wave_barrier();                        \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+  } while (0)
+#define DMK_ENVS_PER_BLOCK 4
+// Diagnostic build only (-DDM_PROFILE): per-phase cycle stamps, written to the debug buffer
+// [352:368).  The shipped library never executes a stamp.
+#ifdef DM_PROFILE
+#define PROF_DECL unsigned prof_acc[16] = {0}; unsigned long long prof_t = __builtin_amdgcn_s_memtime();
+#define PROF(i) do { unsigned long long _t = __builtin_amdgcn_s_memtime(); prof_acc[i] += (unsigned)(_t - prof_t); prof_t = _t; } while (0)
+#else
+#define PROF_DECL
+#define PROF(i) do {} while (0)
+#endif
+typedef __attribute__((address_space(3))) const float *lds_cfloat_p;
 #define MINVALF 1e-15f
 #define MAXVALF 1e10f
 
@@ -383,11 +401,20 @@ __device__ __forceinline__ float impedance(const float *solimp, float pos, float
 }  // namespace
 
 // ======================================================================================
-extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
-  __shared__ EnvLds S;
-  const int lane = threadIdx.x;
-  const int slot = blockIdx.x;
-  const DmDev &T = *P.T;
+extern "C" __global__ void __launch_bounds__(256, 2) dm_step_kernel(DmLaunch P) {
+  __shared__ DmDev T;                          // model tables, staged once per block (4 envs share them)
+  __shared__ EnvLds SS[DMK_ENVS_PER_BLOCK];
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(P.T);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&T);
+    for (int i = threadIdx.x; i < (int)(sizeof(DmDev) / 4); i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  EnvLds &S = SS[wave];
+  const int slot = blockIdx.x * DMK_ENVS_PER_BLOCK + wave;
+  if (slot >= P.nslots) return;
   const int env = P.env_ids ? P.env_ids[slot] : slot;
   if (env < 0 || env >= P.N) return;
   const int mode = P.mode;
@@ -395,40 +422,41 @@ extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
   float *st = P.state + (size_t)env * DMK_STATE_STRIDE;
   int *sti = reinterpret_cast<int *>(st);
 
-  // ---------------------------------------------------------------- role constants (registers)
+  // ---------------------------------------------------------------- lane roles (values are read
+  // from the LDS-resident table at their use sites so they do not pin registers)
   const int lb = lane < DMK_NB ? lane : 0;       // lane as body
   const int lk = lane < DMK_NV ? lane : 0;       // lane as dof
   const int lg = lane < DMK_NG ? lane : 0;       // lane as geom
-  const int bp = T.b_parent[lb], bdep = (lane < DMK_NB) ? T.b_depth[lb] : -1;
-  const int bdofadr = T.b_dofadr[lb], bdofnum = T.b_dofnum[lb];
-  const float bpos[3] = {T.b_pos[lb][0], T.b_pos[lb][1], T.b_pos[lb][2]};
-  const float bipos[3] = {T.b_ipos[lb][0], T.b_ipos[lb][1], T.b_ipos[lb][2]};
-  float binert[6];
-  for (int i = 0; i < 6; i++) binert[i] = T.b_inertia[lb][i];
+  const int bdep = (lane < DMK_NB) ? T.b_depth[lb] : -1;
+#define bp (T.b_parent[lb])
+#define bdofadr (T.b_dofadr[lb])
+#define bdofnum (T.b_dofnum[lb])
+#define bpos (T.b_pos[lb])
+#define bipos (T.b_ipos[lb])
+#define binert (T.b_inertia[lb])
+#define bsub (T.b_subtree[lb])
+#define baxis(j) (T.d_axis[(bdofadr + (j)) < DMK_NV ? (bdofadr + (j)) : 0])
+#define dbody (T.d_body[lk])
+#define dnanc (T.d_nanc[lk])
+#define dact (T.d_act[lk])
+#define dlimited (T.d_limited[lk])
+#define darm (T.d_arm[lk])
+#define ddamp (T.d_damp[lk])
+#define dlo (T.d_lo[lk])
+#define dhi (T.d_hi[lk])
+#define dgear (T.d_gear[lk])
+#define dclo (T.d_clo[lk])
+#define dchi (T.d_chi[lk])
+#define gbody (T.g_body[lg])
+#define gposl (T.g_pos[lg])
+#define gmatl (T.g_mat[lg])
   const float bmass = (lane < DMK_NB) ? T.b_mass[lb] : 0.f;
-  const unsigned bsub = T.b_subtree[lb];
-  float baxis[3][3];
-  for (int j = 0; j < 3; j++) {
-    int k = bdofadr + j;
-    k = (k >= 0 && k < DMK_NV && j < bdofnum && lb > 1) ? k : 0;
-    for (int i = 0; i < 3; i++) baxis[j][i] = T.d_axis[k][i];
-  }
-  const int dbody = T.d_body[lk], dnanc = T.d_nanc[lk], dact = T.d_act[lk], dlimited = T.d_limited[lk];
-  const float darm = T.d_arm[lk], ddamp = T.d_damp[lk], dlo = T.d_lo[lk], dhi = T.d_hi[lk];
-  const float dgear = T.d_gear[lk], dclo = T.d_clo[lk], dchi = T.d_chi[lk];
-  const int gbody = T.g_body[lg];
-  float gposl[3], gmatl[9];
-  for (int i = 0; i < 3; i++) gposl[i] = T.g_pos[lg][i];
-  for (int i = 0; i < 9; i++) gmatl[i] = T.g_mat[lg][i];
   const float h = T.timestep;
   const float mtot_inv = T.total_mass_inv;
 
+  PROF_DECL
   // ---------------------------------------------------------------- LDS init
   for (int i = lane; i < DMK_NV * DMK_MSTRIDE; i += 64) S.M[i] = 0.f;
-  for (int i = lane; i < DMK_NV * DMK_MAXANC; i += 64) (&S.d_anc[0][0])[i] = (&T.d_anc[0][0])[i];
-  for (int i = lane; i < 80; i += 64) { S.tri_a[i] = T.tri_a[i]; S.tri_b[i] = T.tri_b[i]; }
-  if (lane < 16) S.b_chain[lane] = T.b_chain[lane];
-  if (lane < 36) S.d_nanc[lane] = (lane < DMK_NV) ? T.d_nanc[lane] : 0;
   if (lane == 0) {
     S.xpos[0][0] = S.xpos[0][1] = S.xpos[0][2] = 0;
     S.xquat[0][0] = 1; S.xquat[0][1] = S.xquat[0][2] = S.xquat[0][3] = 0;
@@ -490,6 +518,7 @@ extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
     sim_err = __any(!(fabsf(a) <= MAXVALF) || !(fabsf(b) <= MAXVALF));
   }
 
+  PROF(0);
   for (;;) {
    float qacc_out = 0;
    if (!sim_err) {
@@ -525,17 +554,17 @@ extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
           for (int i = 0; i < 9; i++) pm[i] = S.xmat[bp][i];
           for (int i = 0; i < 3; i++) pp[i] = S.xpos[bp][i];
           for (int i = 0; i < 4; i++) q[i] = S.xquat[bp][i];
-          mat_vec(tv, pm, bpos);
+          { const float bl[3] = {bpos[0], bpos[1], bpos[2]}; mat_vec(tv, pm, bl); }
           for (int i = 0; i < 3; i++) pos[i] = pp[i] + tv[i];
 #pragma unroll
           for (int j = 0; j < 3; j++) {
             if (j < bdofnum) {
               int k = bdofadr + j;
               float ax[3], ql[4], qn[4];
-              quat_rot(ax, q, baxis[j]);
+              { const float al[3] = {baxis(j)[0], baxis(j)[1], baxis(j)[2]}; quat_rot(ax, q, al); }
               S.xaxis[k][0] = ax[0]; S.xaxis[k][1] = ax[1]; S.xaxis[k][2] = ax[2];
               float c = S.cs[k][0], s = S.cs[k][1];
-              ql[0] = c; ql[1] = baxis[j][0] * s; ql[2] = baxis[j][1] * s; ql[3] = baxis[j][2] * s;
+              ql[0] = c; ql[1] = baxis(j)[0] * s; ql[2] = baxis(j)[1] * s; ql[3] = baxis(j)[2] * s;
               quat_mul(qn, q, ql);
               q[0] = qn[0]; q[1] = qn[1]; q[2] = qn[2]; q[3] = qn[3];
             }
@@ -547,7 +576,7 @@ extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
         for (int i = 0; i < 3; i++) S.xpos[lb][i] = pos[i];
         for (int i = 0; i < 4; i++) S.xquat[lb][i] = q[i];
         for (int i = 0; i < 9; i++) S.xmat[lb][i] = m9[i];
-        mat_vec(tv, m9, bipos);
+        { const float bl[3] = {bipos[0], bipos[1], bipos[2]}; mat_vec(tv, m9, bl); }
         for (int i = 0; i < 3; i++) S.xipos[lb][i] = pos[i] + tv[i];
         if (lev == 1)
           for (int j = 0; j < 3; j++) { S.xaxis[3 + j][0] = m9[j]; S.xaxis[3 + j][1] = m9[3 + j]; S.xaxis[3 + j][2] = m9[6 + j]; }
@@ -558,7 +587,7 @@ extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
     if (lane < DMK_NG) {
       float bm[9], tv[3];
       for (int i = 0; i < 9; i++) bm[i] = S.xmat[gbody][i];
-      mat_vec(tv, bm, gposl);
+      { const float gl[3] = {gposl[0], gposl[1], gposl[2]}; mat_vec(tv, bm, gl); }
       for (int i = 0; i < 3; i++) S.gpos[lg][i] = S.xpos[gbody][i] + tv[i];
       for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++)
@@ -609,6 +638,7 @@ extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
       S.cdof[lk][6] = 0; S.cdof[lk][7] = 0;
     }
     SYNC();
+    PROF(1);
     // ---- composite inertia per body via the subtree mask, then rows of M (lane = dof)
     if (lane >= 1 && lane < DMK_NB) {
       float acc[10];
@@ -626,7 +656,7 @@ extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
       mul_inert_vec(buf, I, cd);
       int j = lk;
       for (int a = 0; a <= dnanc; a++) {
-        if (a > 0) j = S.d_anc[lk][a - 1];
+        if (a > 0) j = T.d_anc[lk][a - 1];
         float v = 0;
         for (int i = 0; i < 6; i++) v += S.cdof[j][i] * buf[i];
         if (a == 0) v += darm;
@@ -634,14 +664,15 @@ extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
       }
     }
     SYNC();
+    PROF(2);
     // ---- L^T D L factorisation in place; one dof per step, ancestor pairs across lanes
     for (int kk = DMK_NV - 1; kk >= 1; kk--) {
-      int n = S.d_nanc[kk];
+      int n = T.d_nanc[kk];
       int npair = n * (n + 1) / 2;
       float rk = 1.0f / S.M[kk * DMK_MSTRIDE + kk];
       for (int p = lane; p < npair; p += 64) {
-        int a = S.tri_a[p], b = S.tri_b[p];
-        int i = S.d_anc[kk][a], j = S.d_anc[kk][b];
+        int a = T.tri_a[p], b = T.tri_b[p];
+        int i = T.d_anc[kk][a], j = T.d_anc[kk][b];
         S.M[i * DMK_MSTRIDE + j] -= S.M[kk * DMK_MSTRIDE + j] * S.M[kk * DMK_MSTRIDE + i] * rk;
       }
       SYNC();
@@ -651,8 +682,9 @@ extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
       float di = 1.0f / dd;
       S.dinv[lk] = di;
       S.dsqrtinv[lk] = 1.0f / sqrtf(dd);
-      for (int a = 0; a < dnanc; a++) S.M[lk * DMK_MSTRIDE + S.d_anc[lk][a]] *= di;
+      for (int a = 0; a < dnanc; a++) S.M[lk * DMK_MSTRIDE + T.d_anc[lk][a]] *= di;
     }
+    PROF(3);
     if (lane == 0) {
       for (int i = 0; i < 3; i++) { S.u.v.cacc[0][i] = 0; S.u.v.cacc[0][3 + i] = -T.gravity[i]; }
     }
@@ -746,6 +778,7 @@ extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
     if (lane < DMK_NV) S.qacc_smooth[lk] = xs;
     SYNC();
 
+    PROF(4);
     // ---- collision: lane = candidate pair, two rounds in canonical order
     int base = 0;
     overflow = 0;
@@ -939,6 +972,7 @@ extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
     ncon = base;
     SYNC();
 
+    PROF(5);
     // ---- constraint rows: limits in joint order, then contacts in contact order
     {
       bool lim = false;
@@ -1016,7 +1050,7 @@ extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
           }
           float off[3] = {S.c_pos[ci][0] - com[0], S.c_pos[ci][1] - com[1], S.c_pos[ci][2] - com[2]};
           cross3(wa, off, wl);
-          cm1 = S.b_chain[b1]; cm2 = S.b_chain[b2];
+          cm1 = T.b_chain[b1]; cm2 = T.b_chain[b2];
           rpos = S.c_dist[ci];
           rmargin = fmaxf(T.g_margin[g1], T.g_margin[g2]);
         }
@@ -1046,12 +1080,20 @@ extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
         bb = jqs - aref;
         Dd = 1.0f / R;
       }
+      PROF(6);
       // ---- B row = D^-1/2 L^-T J^T, in place (lane = row)
+      {
+        // The factor entries are wave-uniform LDS broadcasts.  Tie the row pointer of step i to the
+        // result of step i+1 so hipcc cannot hoist all 561 loads ahead of the FMAs (that costs >200
+        // VGPRs and spills to scratch).
+        lds_cfloat_p Mp = (lds_cfloat_p)S.M;
 #pragma unroll
-      for (int i = DMK_NV - 1; i >= 1; i--) {
-        const float xi = J[i];
+        for (int i = DMK_NV - 1; i >= 1; i--) {
+          const float xi = J[i];
+          asm volatile("" : "+v"(Mp), "+v"(J[0]));
 #pragma unroll
-        for (int j = 0; j < i; j++) J[j] -= S.M[i * DMK_MSTRIDE + j] * xi;
+          for (int j = 0; j < i; j++) J[j] -= Mp[i * DMK_MSTRIDE + j] * xi;
+        }
       }
 #pragma unroll
       for (int k = 0; k < DMK_NV; k++) J[k] *= S.dsqrtinv[k];
@@ -1062,15 +1104,19 @@ extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
       for (int k = 0; k < DMK_NV; k++) ARd += J[k] * J[k];
 #pragma unroll
       for (int i = 0; i < DMK_MAXROW; i++) {
-        float acc = 0;
-        if (i < nefc) {
+        if (i >= nefc) break;  // rows beyond nefc are never read
+        float acc0 = 0, acc1 = 0;
 #pragma unroll
-          for (int k = 0; k < DMK_NV; k++) acc += J[k] * rl(J[k], i);
-          if (lane == i) acc += R;
+        for (int k = 0; k < DMK_NV; k += 2) {
+          acc0 = fmaf(J[k], rl(J[k], i), acc0);
+          acc1 = fmaf(J[k + 1], rl(J[k + 1], i), acc1);
         }
+        float acc = acc0 + acc1;
+        if (lane == i) acc += R;
         AR[i] = acc;
       }
       const float ARinv = (lane < nefc) ? 1.0f / ARd : 0.f;
+      PROF(7);
       // ---- warm start (mj_fwdConstraint): forces implied by qacc_warmstart if their dual cost < 0
       float f = 0, r = bb;
       {
@@ -1078,8 +1124,10 @@ extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
         float fw = (lane < nefc && jar < 0) ? -Dd * jar : 0.f;
         float rw = bb;
 #pragma unroll
-        for (int i = 0; i < DMK_MAXROW; i++)
-          if (i < nefc) rw += AR[i] * rl(fw, i);
+        for (int i = 0; i < DMK_MAXROW; i++) {
+          if (i >= nefc) break;
+          rw += AR[i] * rl(fw, i);
+        }
         float cost = wave_sum(fw * (0.5f * (rw - bb) + bb));
         if (!(cost > 0)) { f = fw; r = rw; }
       }
@@ -1090,22 +1138,21 @@ extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
         float impv = 0;
 #pragma unroll
         for (int i = 0; i < DMK_MAXROW; i++) {
-          if (i < nefc) {
-            float fn = fmaxf(0.f, f - r * ARinv);
-            float dl = fn - f;
-            float dli = rl(dl, i);
-            if (dli != 0.f) {
-              float ri = rl(r, i), aii = rl(ARd, i);
-              impv -= 0.5f * dli * dli * aii + dli * ri;
-              r = fmaf(AR[i], dli, r);
-              if (lane == i) f = fn;
-            }
-          }
+          if (i >= nefc) break;
+          // every lane evaluates its own row; only row i's update is committed and broadcast
+          const float fn = fmaxf(0.f, fmaf(-r, ARinv, f));
+          const float dl = fn - f;
+          const float t = dl * fmaf(0.5f * dl, ARd, r);   // cost decrease of row i if lane == i
+          const float dli = rl(dl, i);
+          impv -= rl(t, i);
+          r = fmaf(AR[i], dli, r);
+          f = (lane == i) ? fn : f;
         }
         iter++;
         if (impv * scale < tol) break;
       }
       solver_iter = iter;
+      PROF(8);
       // ---- qacc = qacc_smooth + L^-1 D^-1/2 sum_r f_r B_r
       float v = 0;
 #pragma unroll
@@ -1127,6 +1174,7 @@ extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
     if (lane < DMK_NV) { S.qacc[lk] = qacc_out; S.warm[lk] = qacc_out; }
     SYNC();
     if (it < 4) { stage_ncon |= (unsigned)(ncon & 0xFF) << (8 * it); stage_nefc |= (unsigned)(nefc & 0xFF) << (8 * it); }
+    PROF(9);
     // ============================================================== end of forward evaluation
     if (it == 0 || (it == 4 && mode == DMK_MODE_FORCED && !after_reset)) {  // mj_checkAcc
       bool badv = (lane < DMK_NV) && !(fabsf(qacc_out) <= MAXVALF);
@@ -1181,6 +1229,7 @@ extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
       SYNC();
     }
 
+    PROF(10);
     // ============================================================== task layer: obs, reward, done
     // (derived arrays are those of the LAST forward evaluation: SURVEY F6)
     const bool task_pass = !after_reset && (mode == DMK_MODE_STEP || mode == DMK_MODE_FORCED);
@@ -1323,6 +1372,13 @@ extern "C" __global__ void __launch_bounds__(64, 2) dm_step_kernel(DmLaunch P) {
     break;
   }
 
+  PROF(11);
+#ifdef DM_PROFILE
+  if (P.debug && lane < 12) { unsigned v = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) if (lane == i) v = prof_acc[i];
+    P.debug[(size_t)env * DM_DEBUG_STRIDE + 352 + lane] = (float)v; }
+#endif
   // ---------------------------------------------------------------- state write-back
   if (lane < DMK_NQ) st[DMS_QPOS + lane] = S.qpos[lane];
   if (lane < DMK_NV) { st[DMS_QVEL + lane] = S.qvel[lane]; st[DMS_WARM + lane] = S.warm[lane]; }
