@@ -1,0 +1,367 @@
+"""DPEnv / HipDeepMimicVecEnv — host-side mirror of the reference's environment surfaces.
+
+Surface 1 (gym.Env, per env):   ``DPEnv``            <- src/deepmimic_env.py:273-538
+Surface 2 (SB3 VecEnv, batched): ``HipDeepMimicVecEnv`` <- what SubprocVecEnv([DPEnv]*N) gives
+                                                          src/sb3_ppo.py:273-278, src/ppo.py:32
+
+Both are thin: every number they return is produced by the HIP engine through the C-ABI
+(deepmimic_mujoco_amd/_lib.py).  Neither gym nor stable-baselines3 is needed; if
+stable_baselines3 is importable the VecEnv subclasses its ``VecEnv`` so it can be handed to
+``PPO(MlpPolicy, envs, ...)`` unchanged.
+"""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+
+from . import _lib
+from .config import MotionConfig, RobotConfig
+from .mocap import MocapDM
+from .model import NOBS, NQ, NU, NV, load_model
+
+try:  # optional: real SB3 base class when present (it is not in this image)
+    from stable_baselines3.common.vec_env.base_vec_env import VecEnv as _SB3VecEnv
+except Exception:  # pragma: no cover
+    _SB3VecEnv = object
+
+
+class Box:
+    """Minimal stand-in for gym.spaces.Box (gym is not installed here)."""
+
+    def __init__(self, low, high, shape=None, dtype=np.float32):
+        self.dtype = np.dtype(dtype)
+        if shape is None:
+            shape = np.shape(low)
+        self.shape = tuple(shape)
+        self.low = np.broadcast_to(np.asarray(low, self.dtype), self.shape).copy()
+        self.high = np.broadcast_to(np.asarray(high, self.dtype), self.shape).copy()
+        self._rng = np.random.default_rng()
+
+    def sample(self):
+        lo = np.where(np.isfinite(self.low), self.low, -1.0)
+        hi = np.where(np.isfinite(self.high), self.high, 1.0)
+        return self._rng.uniform(lo, hi).astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+    def seed(self, seed=None):
+        self._rng = np.random.default_rng(seed)
+
+    def __repr__(self):
+        return "Box(%s, %s, %s, %s)" % (self.low.min(), self.high.max(), self.shape, self.dtype)
+
+
+class DPEnvConfig:
+    """src/deepmimic_env.py:258-270 (the HIP kernels implement exactly this flag set)."""
+
+    def __init__(self):
+        self.MAX_EP_LENGTH = 1000
+        self.VEL_OBS_SCALE = 0.1
+        self.FRC_OBS_SCALE = 0.001
+        self.ADD_FOOT_CONTACT_OBS = True
+        self.ADD_EXTRA_CONTACT_OBS = False
+        self.ADD_TORSO_OBS = True
+        self.ADD_JOINT_FORCE_OBS = False
+        self.ADD_ABSPOS_OBS = False
+        self.ADD_PHASE_OBS = True
+        self.ADD_PLAYER_ACTION_OBS = False
+        self.MAX_PLAYER_ACTIONS = 3
+
+
+_INFO_KEYS = ["reward_config", "reward_qvel", "reward_end_eff", "reward_com", "reward_joint_limit"]
+
+
+def _make_info(terms, reason):
+    """info dict of deepmimic_env.py:251-255,424,438 (empty on the two early-out paths :378,:476)."""
+    if reason in (5, 6):
+        return {}
+    info = {k: float(v) for k, v in zip(_INFO_KEYS, terms)}
+    r = _lib.REASONS.get(int(reason))
+    if r is not None:
+        info["done_reason"] = r
+    return info
+
+
+class _SimView:
+    """`env.sim.data.qpos / qvel` as read by the reference's tools (deepmimic_env.py:591-597)."""
+
+    def __init__(self, env):
+        self._env = env
+        self.data = self
+
+    @property
+    def qpos(self):
+        return self._env._state()[0]
+
+    @property
+    def qvel(self):
+        return self._env._state()[1]
+
+    @property
+    def time(self):
+        return self._env._time
+
+    def forward(self):
+        q, v = self._env._state()
+        self._env.set_state(q, v)
+
+
+class DPEnv:
+    """Single-clip imitation env with the reference's public surface (deepmimic_env.py:273)."""
+
+    version = "v1.0"
+    ENV_CFG = DPEnvConfig()
+    metadata = {"render.modes": []}
+
+    def __init__(self, motion=None, load_mocap=True, robot="humanoid3d", _profile=False, device=0):
+        import torch
+        self.PROFILE = _profile
+        self.motion_config = MotionConfig(motion=motion, robot=robot)
+        self.robot_config = RobotConfig(robot=robot)
+        self.model = load_model(self.robot_config.xml_path)
+        self.mocap = MocapDM(robot=robot, model=self.model)
+        self._torch = torch
+        self._eng = _lib.HipEngine(self.model, 1, device=device, auto_reset=False,
+                                   max_ep_length=self.ENV_CFG.MAX_EP_LENGTH,
+                                   vel_obs_scale=self.ENV_CFG.VEL_OBS_SCALE, low_z=self.robot_config.low_z)
+        self._out = self._eng.alloc_outputs()
+        self._time = 0.0
+        if load_mocap:
+            self.load_mocap(self.motion_config.mocap_path)
+            self.reference_state_init()
+            assert len(self.mocap.data_config) != 0
+        else:  # deepmimic_env.py:287-293
+            self.mocap.data_config = None
+            self.mocap.data_vel = None
+            self.mocap_data_len = 1
+            self._load_rest_clip()
+        self.idx_curr = -1
+        self.episode_reward = 0
+        self.episode_length = 0
+        self.sim = _SimView(self)
+        lo = self.model.act_ctrlrange[:, 0].astype(np.float32)
+        hi = self.model.act_ctrlrange[:, 1].astype(np.float32)
+        self.action_space = Box(lo, hi, dtype=np.float32)                     # from ctrlrange [EXT]
+        self.observation_space = Box(-np.inf, np.inf, (NOBS,), np.float64)
+        self.init_qpos = self.model.qpos0.copy()
+        self.init_qvel = np.zeros(NV)
+
+    # ---- reference helpers -------------------------------------------------------------
+    def _load_rest_clip(self):
+        class _Rest:
+            def __init__(s, m):
+                from .model import forward_kinematics
+                kin = forward_kinematics(m, m.qpos0)
+                s.t = (m.qpos0[None], np.zeros((1, NV)), kin["xpos"][None], kin["geom_xpos"][None])
+
+            def tables(s):
+                return s.t
+        self._eng.load_clip(0, _Rest(self.model))
+
+    def load_mocap(self, filepath):
+        self.mocap.load_mocap(filepath)
+        self.mocap_dt = self.mocap.dt
+        self.mocap_data_len = len(self.mocap.data_config)
+        self._eng.load_clip(0, self.mocap)
+
+    def reference_state_init(self, idx_init=None):     # deepmimic_env.py:312-316
+        self.idx_init = random.randint(0, self.mocap_data_len - 1)
+        if idx_init is not None:
+            self.idx_init = idx_init
+        self.idx_curr = self.idx_init
+
+    def _push_counters(self):
+        t = self._torch
+        self._eng.set_counters(t.tensor([max(self.idx_curr, 0)], dtype=t.int32, device=self._eng.device),
+                               t.tensor([self.episode_length], dtype=t.int32, device=self._eng.device))
+
+    def _state(self):
+        q, v, _, _ = self._eng.get_state()
+        return q[0].double().cpu().numpy(), v[0].double().cpu().numpy()
+
+    def _get_obs(self):
+        raise NotImplementedError("observations are produced by dm_step/dm_reset; call step() or reset()")
+
+    # ---- gym.Env surface ------------------------------------------------------------------
+    def step(self, action, force_state=None):
+        t = self._torch
+        action = np.asarray(action, np.float64) * 1.0
+        assert action.shape == (NU,)                                          # deepmimic_env.py:352
+        self._push_counters()
+        if force_state is not None:
+            qpos, qvel = force_state
+            self._eng.step_forced(t.tensor(np.asarray(qpos)[None], dtype=t.float32, device=self._eng.device),
+                                  t.tensor(np.asarray(qvel)[None], dtype=t.float32, device=self._eng.device),
+                                  self._out)
+        else:
+            self._eng.step(t.tensor(action[None], dtype=t.float32, device=self._eng.device), self._out)
+            self._time += self.model.timestep
+        obs = self._out["obs"][0].double().cpu().numpy()
+        reason = int(self._out["reason"][0].item())
+        done = bool(self._out["done"][0].item())
+        if self.mocap.data_config is None:                                    # deepmimic_env.py:394-395
+            return obs, 0, False, {}
+        if reason in (5, 6):                                                  # :366-378 / :465-476
+            if reason == 6:
+                self.idx_curr = (self.idx_curr + 1) % self.mocap_data_len
+                self.episode_length += 1
+            return obs, 0, True, {}
+        reward = float(self._out["rew"][0].item())
+        info = _make_info(self._out["terms"][0].cpu().numpy(), reason)
+        self.idx_curr = (self.idx_curr + 1) % self.mocap_data_len              # :452-455
+        self.episode_reward += reward
+        self.episode_length += 1
+        return obs, reward, done, info
+
+    def reset(self):                                                          # :496-500
+        self.episode_reward = 0
+        self.episode_length = 0
+        return self.reset_model()
+
+    def reset_model(self, idx_init=None):                                     # :502-510
+        t = self._torch
+        self.reference_state_init(idx_init=idx_init)
+        obs = t.zeros(1, NOBS, device=self._eng.device)
+        self._eng.reset(obs, idx_init=t.tensor([self.idx_init], dtype=t.int32, device=self._eng.device))
+        self._eng.set_counters(None, t.tensor([self.episode_length], dtype=t.int32, device=self._eng.device))
+        return obs[0].double().cpu().numpy()
+
+    def set_state(self, qpos, qvel):                                          # MujocoEnv.set_state + sim.forward
+        t = self._torch
+        assert np.shape(qpos) == (NQ,) and np.shape(qvel) == (NV,)
+        self._eng.set_state(t.tensor(np.asarray(qpos)[None], dtype=t.float32, device=self._eng.device),
+                            t.tensor(np.asarray(qvel)[None], dtype=t.float32, device=self._eng.device),
+                            run_forward=True)
+
+    def get_time(self):                                                       # :493
+        return self._time
+
+    def render(self, mode=None):
+        raise NotImplementedError("rendering needs a MuJoCo viewer; out of scope (SURVEY §8f-4)")
+
+    def seed(self, seed=None):
+        random.seed(seed)
+        return [seed]
+
+    def close(self):
+        self._eng.close()
+
+
+class LazyInfos:
+    """`infos` list of a VecEnv step; dicts are built on access (4096 dicts/step would dominate)."""
+
+    def __init__(self, terms, reason, done, terminal_obs):
+        self._terms, self._reason, self._done, self._tobs = terms, reason, done, terminal_obs
+        self._cache = {}
+
+    def __len__(self):
+        return len(self._done)
+
+    def __getitem__(self, i):
+        if i not in self._cache:
+            info = _make_info(self._terms[i], self._reason[i])
+            if self._done[i]:
+                info["terminal_observation"] = self._tobs[i].copy()
+            self._cache[i] = info
+        return self._cache[i]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+class HipDeepMimicVecEnv(_SB3VecEnv):
+    """N DPEnv instances as one HIP batch with SubprocVecEnv semantics (auto-reset, terminal_observation).
+
+    ``motion`` may be one clip name or a list (per-env clip id = env index mod len(list): BASELINE
+    config 5).  ``step_tensor`` is the zero-copy path used by deepmimic_mujoco_amd.ppo.
+    """
+
+    def __init__(self, num_envs, motion=None, robot="humanoid3d", device=0, seed=1234, auto_reset=True):
+        import torch
+        self._torch = torch
+        self.robot_config = RobotConfig(robot)
+        self.model = load_model(self.robot_config.xml_path)
+        self.num_envs = int(num_envs)
+        motions = [motion] if (motion is None or isinstance(motion, str)) else list(motion)
+        self.motions = [MotionConfig(m, robot).motion for m in motions]
+        self.engine = _lib.HipEngine(self.model, self.num_envs, device=device, seed=seed, auto_reset=auto_reset,
+                                     low_z=self.robot_config.low_z)
+        self.mocaps = []
+        for cid, m in enumerate(self.motions):
+            mc = MocapDM(robot=robot, model=self.model)
+            mc.load_mocap(MotionConfig(m, robot).mocap_path)
+            self.engine.load_clip(cid, mc)
+            self.mocaps.append(mc)
+        if len(self.motions) > 1:
+            ids = torch.arange(self.num_envs, device=self.engine.device) % len(self.motions)
+            self.engine.set_env_clips(ids.to(torch.int32))
+        self.device = self.engine.device
+        self.out = self.engine.alloc_outputs()
+        lo = self.model.act_ctrlrange[:, 0].astype(np.float32)
+        hi = self.model.act_ctrlrange[:, 1].astype(np.float32)
+        self.action_space = Box(lo, hi, dtype=np.float32)
+        self.observation_space = Box(-np.inf, np.inf, (NOBS,), np.float32)
+        self._actions = torch.zeros(self.num_envs, NU, device=self.device)
+        self.version, self.ENV_CFG = DPEnv.version, DPEnv.ENV_CFG
+        if _SB3VecEnv is not object:  # pragma: no cover
+            _SB3VecEnv.__init__(self, self.num_envs, self.observation_space, self.action_space)
+
+    # ---- zero-copy tensor API
+    def reset_tensor(self, idx_init=None):
+        self.engine.reset(self.out["obs"], idx_init=idx_init)
+        return self.out["obs"]
+
+    def step_tensor(self, actions):
+        """actions: float32 CUDA tensor [N,28] -> dict of CUDA tensors (obs, rew, done, terms, reason, terminal_obs)."""
+        self.engine.step(actions.contiguous(), self.out)
+        return self.out
+
+    # ---- SB3 VecEnv protocol (numpy in / numpy out)
+    def reset(self):
+        return self.reset_tensor().cpu().numpy()
+
+    def step_async(self, actions):
+        t = self._torch
+        self._actions.copy_(t.as_tensor(np.asarray(actions), dtype=t.float32))
+
+    def step_wait(self):
+        out = self.step_tensor(self._actions)
+        obs = out["obs"].cpu().numpy()
+        rew = out["rew"].cpu().numpy()
+        done = out["done"].cpu().numpy().astype(bool)
+        infos = LazyInfos(out["terms"].cpu().numpy(), out["reason"].cpu().numpy(), done,
+                          out["terminal_obs"].cpu().numpy())
+        return obs, rew, done, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        self.engine.close()
+
+    def seed(self, seed=None):
+        return [None] * self.num_envs
+
+    def get_attr(self, attr_name, indices=None):
+        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
+        return [getattr(self, attr_name)] * n
+
+    def set_attr(self, attr_name, value, indices=None):
+        setattr(self, attr_name, value)
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        raise NotImplementedError("per-env method calls have no batched equivalent")
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
+        return [False] * n
+
+    def get_images(self):
+        raise NotImplementedError("rendering is out of scope (SURVEY §8f-4)")
+
+    def render(self, mode=None):
+        raise NotImplementedError("rendering is out of scope (SURVEY §8f-4)")

@@ -1,0 +1,261 @@
+"""PPO rollout + update loop on device tensors — the driver side of the hot path.
+
+Mirrors what the reference's training scripts ask Stable-Baselines to do:
+  src/sb3_ppo.py:254-271,307-312  PPO(MlpPolicy, envs, net_arch=[256,128], n_steps=4096, lr=4e-4,
+                                      n_epochs=20, batch_size=4096)
+  src/ppo.py:21-39                PPO2(MlpPolicy, n_steps=128, nminibatches=4, noptepochs=12, lr=2.5e-4)
+with SB3's defaults for everything the scripts leave unset [EXT]: gamma 0.99, gae_lambda 0.95,
+clip_range 0.2, ent_coef 0, vf_coef 0.5, max_grad_norm 0.5, per-minibatch advantage
+normalisation, tanh MLPs with separate policy / value trunks, orthogonal init, state-independent
+log-std initialised to 0, actions clipped to the action space before env.step.
+
+Differences by design (MI355X-first): observations, actions, rewards and dones never leave HBM
+(``HipDeepMimicVecEnv.step_tensor``); the MLP GEMMs run on MFMA through PyTorch-ROCm; multi-GPU is
+one process per GPU with ONE all-reduce of the flat gradient per optimizer step over RCCL/xGMI
+(``FlatGradAllReduce``), envs sharded across ranks with no other collective.
+"""
+from __future__ import annotations
+
+import math
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import nn
+
+
+class MlpPolicy(nn.Module):
+    """SB3 ``ActorCriticPolicy`` with ``net_arch=[h1, h2]`` (shared sizes, separate trunks), tanh."""
+
+    def __init__(self, obs_dim=67, act_dim=28, net_arch=(256, 128), log_std_init=0.0):
+        super().__init__()
+
+        def trunk():
+            layers, d = [], obs_dim
+            for hdim in net_arch:
+                layers += [nn.Linear(d, hdim), nn.Tanh()]
+                d = hdim
+            return nn.Sequential(*layers), d
+
+        self.pi, dpi = trunk()
+        self.vf, dvf = trunk()
+        self.action_net = nn.Linear(dpi, act_dim)
+        self.value_net = nn.Linear(dvf, 1)
+        self.log_std = nn.Parameter(torch.full((act_dim,), float(log_std_init)))
+        for seq in (self.pi, self.vf):
+            for m in seq:
+                if isinstance(m, nn.Linear):
+                    nn.init.orthogonal_(m.weight, gain=math.sqrt(2))
+                    nn.init.zeros_(m.bias)
+        nn.init.orthogonal_(self.action_net.weight, gain=0.01)
+        nn.init.zeros_(self.action_net.bias)
+        nn.init.orthogonal_(self.value_net.weight, gain=1.0)
+        nn.init.zeros_(self.value_net.bias)
+
+    def forward(self, obs, deterministic=False):
+        mean = self.action_net(self.pi(obs))
+        value = self.value_net(self.vf(obs)).squeeze(-1)
+        std = self.log_std.exp()
+        act = mean if deterministic else mean + std * torch.randn_like(mean)
+        logp = self._logp(act, mean)
+        return act, value, logp
+
+    def _logp(self, act, mean):
+        var = (2 * self.log_std).exp()
+        return (-0.5 * ((act - mean) ** 2 / var) - self.log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
+
+    def evaluate_actions(self, obs, act):
+        mean = self.action_net(self.pi(obs))
+        value = self.value_net(self.vf(obs)).squeeze(-1)
+        entropy = (0.5 + 0.5 * math.log(2 * math.pi) + self.log_std).sum().expand(obs.shape[0])
+        return value, self._logp(act, mean), entropy
+
+    def predict_values(self, obs):
+        return self.value_net(self.vf(obs)).squeeze(-1)
+
+
+class ExtractedPolicy:
+    """The reference's exported walk policy: a = tanh(tanh(o W0 + B0) W2 + B2) WA + BA
+    (src/extracted_policy.py:471-478; used with obs[:66] and clip +-0.5, src/play_extracted.py:36-38)."""
+
+    def __init__(self, npz_path, device="cpu"):
+        z = np.load(npz_path)
+        self.p = {k: torch.tensor(z[k], dtype=torch.float32, device=device) for k in ("W0", "B0", "W2", "B2", "WA", "BA")}
+        assert self.p["W0"].shape == (66, 256) and self.p["W2"].shape == (256, 128) and self.p["WA"].shape == (128, 28)
+        self.obs_shape, self.act_shape = 66, 28
+
+    def act(self, obs):
+        o = torch.as_tensor(obs, dtype=torch.float32, device=self.p["W0"].device)
+        f = torch.tanh(o @ self.p["W0"] + self.p["B0"])
+        f = torch.tanh(f @ self.p["W2"] + self.p["B2"])
+        return f @ self.p["WA"] + self.p["BA"]
+
+
+def compute_gae(rewards, values, dones, last_values, gamma, lam):
+    """SB3 ``RolloutBuffer.compute_returns_and_advantage`` [EXT]: tensors [T, N]; dones[t] is the done
+    flag returned by step t (so the value after it is not bootstrapped)."""
+    T = rewards.shape[0]
+    adv = torch.zeros_like(rewards)
+    last = torch.zeros_like(last_values)
+    for t in reversed(range(T)):
+        next_v = last_values if t == T - 1 else values[t + 1]
+        nonterm = 1.0 - dones[t]
+        delta = rewards[t] + gamma * next_v * nonterm - values[t]
+        last = delta + gamma * lam * nonterm * last
+        adv[t] = last
+    return adv, adv + values
+
+
+class FlatGradAllReduce:
+    """One collective per optimizer step: flatten every gradient into a single fp32 buffer,
+    all-reduce (sum) it over the process group (RCCL over xGMI on GPUs, gloo in CPU tests), divide by
+    the world size, scatter back.  104 377 floats for [256,128], 1 203 769 for [1024,512]."""
+
+    def __init__(self, params, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.calls = 0
+
+    def __call__(self):
+        if self.world == 1:
+            return
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.grad.reshape(-1) if p.grad is not None else torch.zeros(n, device=self.flat.device))
+            off += n
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.calls += 1
+        self.flat.div_(self.world)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+            p.grad.copy_(self.flat[off:off + n].view_as(p))
+            off += n
+
+
+class PPO:
+    def __init__(self, env, net_arch=(256, 128), n_steps=4096, batch_size=4096, n_epochs=20, learning_rate=4e-4,
+                 gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5,
+                 normalize_advantage=True, seed=0, device=None, buffer_dtype=torch.float32, policy=None):
+        self.env = env
+        self.device = device if device is not None else getattr(env, "device", torch.device("cpu"))
+        self.n_envs = env.num_envs if env is not None else 0
+        self.n_steps, self.batch_size, self.n_epochs = n_steps, batch_size, n_epochs
+        self.gamma, self.gae_lambda, self.clip_range = gamma, gae_lambda, clip_range
+        self.ent_coef, self.vf_coef, self.max_grad_norm = ent_coef, vf_coef, max_grad_norm
+        self.normalize_advantage = normalize_advantage
+        self.buffer_dtype = buffer_dtype
+        torch.manual_seed(seed)  # identical initial weights on every rank; no parameter broadcast needed
+        self.policy = (policy if policy is not None else MlpPolicy(net_arch=tuple(net_arch))).to(self.device)
+        self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5)
+        self.grad_sync = FlatGradAllReduce(self.policy.parameters())
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        if dist.is_initialized():  # decorrelate action noise across ranks after the common init
+            torch.manual_seed(seed + 1000 * (self.rank + 1))
+        lo = torch.as_tensor(env.action_space.low, device=self.device) if env is not None else None
+        hi = torch.as_tensor(env.action_space.high, device=self.device) if env is not None else None
+        self.act_lo, self.act_hi = lo, hi
+        self.num_timesteps = 0
+        self._last_obs = None
+        self.stats = {}
+
+    # ------------------------------------------------------------------ rollout
+    def collect_rollouts(self):
+        T, N, dev = self.n_steps, self.n_envs, self.device
+        bd = self.buffer_dtype
+        buf = dict(obs=torch.zeros(T, N, 67, device=dev, dtype=bd), act=torch.zeros(T, N, 28, device=dev, dtype=bd),
+                   rew=torch.zeros(T, N, device=dev), done=torch.zeros(T, N, device=dev),
+                   val=torch.zeros(T, N, device=dev), logp=torch.zeros(T, N, device=dev))
+        if self._last_obs is None:
+            self._last_obs = self.env.reset_tensor().clone()
+        ep_done = 0
+        with torch.no_grad():
+            for t in range(T):
+                obs = self._last_obs
+                act, val, logp = self.policy(obs)
+                out = self.env.step_tensor(torch.clamp(act, self.act_lo, self.act_hi))
+                buf["obs"][t] = obs
+                buf["act"][t] = act
+                buf["val"][t] = val
+                buf["logp"][t] = logp
+                buf["rew"][t] = out["rew"]
+                buf["done"][t] = out["done"].float()
+                self._last_obs = out["obs"].clone()
+            last_val = self.policy.predict_values(self._last_obs)
+            adv, ret = compute_gae(buf["rew"], buf["val"], buf["done"], last_val, self.gamma, self.gae_lambda)
+        buf["adv"], buf["ret"] = adv, ret
+        self.num_timesteps += T * N
+        self.stats["mean_reward"] = float(buf["rew"].mean())
+        self.stats["done_rate"] = float(buf["done"].mean())
+        return buf
+
+    # ------------------------------------------------------------------ update
+    def train(self, buf, generator=None):
+        """``n_epochs`` passes over the flattened rollout in minibatches of ``batch_size`` (SB3 PPO.train)."""
+        flat = {k: v.reshape(-1, *v.shape[2:]) for k, v in buf.items()}
+        n = flat["obs"].shape[0]
+        losses = []
+        for _ in range(self.n_epochs):
+            perm = torch.randperm(n, device=self.device, generator=generator)
+            for s in range(0, n, self.batch_size):
+                idx = perm[s:s + self.batch_size]
+                obs, act = flat["obs"][idx].float(), flat["act"][idx].float()
+                adv, ret, old_logp = flat["adv"][idx], flat["ret"][idx], flat["logp"][idx]
+                if self.normalize_advantage and len(idx) > 1:
+                    adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+                value, logp, entropy = self.policy.evaluate_actions(obs, act)
+                ratio = torch.exp(logp - old_logp)
+                pg = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - self.clip_range, 1 + self.clip_range)).mean()
+                vl = torch.nn.functional.mse_loss(ret, value)
+                loss = pg + self.vf_coef * vl - self.ent_coef * entropy.mean()
+                self.optimizer.zero_grad(set_to_none=False)
+                loss.backward()
+                self.grad_sync()                         # the ONE collective of the data-parallel learner
+                nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
+                self.optimizer.step()
+                losses.append(float(loss.detach()))
+        self.stats["loss"] = float(np.mean(losses)) if losses else 0.0
+        return self.stats["loss"]
+
+    def learn(self, total_timesteps, log_interval=1, callback=None):
+        it = 0
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        while self.num_timesteps * world < total_timesteps:
+            t0 = time.perf_counter()
+            buf = self.collect_rollouts()
+            t1 = time.perf_counter()
+            self.train(buf)
+            t2 = time.perf_counter()
+            it += 1
+            self.stats.update(rollout_s=t1 - t0, train_s=t2 - t1, iteration=it)
+            if callback is not None:
+                callback(self)
+            if self.rank == 0 and log_interval and it % log_interval == 0:
+                print("iter %d  steps %d  rew/step %.4f  done %.4f  loss %.4f  rollout %.2fs  train %.2fs" % (
+                    it, self.num_timesteps * world, self.stats["mean_reward"], self.stats["done_rate"],
+                    self.stats["loss"], t1 - t0, t2 - t1), flush=True)
+        return self
+
+    def predict(self, obs, deterministic=True):
+        with torch.no_grad():
+            o = torch.as_tensor(obs, dtype=torch.float32, device=self.device)
+            act, _, _ = self.policy(o, deterministic=deterministic)
+            return torch.clamp(act, self.act_lo, self.act_hi)
+
+    def save(self, path):
+        torch.save({"policy": self.policy.state_dict(), "optimizer": self.optimizer.state_dict(),
+                    "num_timesteps": self.num_timesteps}, path)
+
+    def load(self, path):
+        ck = torch.load(path, map_location=self.device)
+        self.policy.load_state_dict(ck["policy"])
+        self.optimizer.load_state_dict(ck["optimizer"])
+        self.num_timesteps = ck["num_timesteps"]
+        return self

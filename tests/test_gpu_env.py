@@ -1,0 +1,178 @@
+"""GPU tests of the reference-facing surfaces: DPEnv (gym.Env), HipDeepMimicVecEnv (SB3 VecEnv),
+auto-reset semantics, multi-clip batches, free-running rollouts and a short PPO run."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _hash32(seed, env, step, j):
+    M = (1 << 64) - 1
+    seed, env, step, j = int(seed), int(env), int(step), int(j)
+    x = (seed ^ (env * 0x9E3779B97F4A7C15) ^ (step * 0xBF58476D1CE4E5B9) ^ (j * 0x94D049BB133111EB)) & M
+    x ^= x >> 30; x = (x * 0xBF58476D1CE4E5B9) & M
+    x ^= x >> 27; x = (x * 0x94D049BB133111EB) & M
+    x ^= x >> 31
+    return x >> 32
+
+
+def test_dpenv_surface_matches_oracle(model, clips, oracle_clips):
+    from deepmimic_mujoco_amd.deepmimic_env import DPEnv
+    from oracle.oracle import OracleSim
+    env = DPEnv(motion="walk")
+    assert env.action_space.shape == (28,) and env.action_space.high.max() == 2.0
+    assert env.observation_space.shape == (67,) and env.mocap_data_len == 76 and env.version == "v1.0"
+    oc = oracle_clips["walk"]
+    s = OracleSim(model)
+    s.set_caps(32, 64)
+    obs = env.reset_model(idx_init=5)
+    eobs = s.env_reset(oc, 5)
+    assert obs.dtype == np.float64 and np.abs(obs - eobs).max() < 1e-5
+    rng = np.random.default_rng(0)
+    for t in range(40):
+        a = rng.uniform(-0.4, 0.4, 28)
+        o, r, d, info = env.step(a)
+        eo, er, ed, et, ereason = s.env_step(oc, a)
+        assert np.abs(o - eo).max() < 5e-3 and abs(r - er) < 1e-3 and d == ed
+        assert set(info) == {"reward_config", "reward_qvel", "reward_end_eff", "reward_com",
+                             "reward_joint_limit", "done_reason"}
+        assert info["done_reason"] in ("low_z", "high_z")
+        assert env.idx_curr == s.env.idx_curr and env.episode_length == s.env.episode_length
+        # teacher-force the oracle onto the device state so fp32 drift does not accumulate
+        q, v, w, c = [x[0].double().cpu().numpy() for x in env._eng.get_state()]
+        s.set("qpos", q); s.set("qvel", v); s.set("qacc_warmstart", w); s.set("ctrl", c)
+        if d:
+            break
+    i = env.idx_curr                      # the reward compares against clip row idx_curr
+    q = clips["walk"].data_config[i]
+    v = clips["walk"].data_vel[i]
+    o, r, d, info = env.step(np.zeros(28), force_state=(q, v))
+    assert abs(info["reward_qvel"] - 1.0) < 1e-6 and env.get_time() > 0
+    assert np.abs(env.sim.data.qpos[7:] - q[7:]).max() < 1e-6
+    with pytest.raises(AssertionError):
+        env.step(np.zeros(27))
+    env.close()
+
+
+def test_vecenv_autoreset_semantics(model, clips, oracle_clips):
+    """SubprocVecEnv worker: on done, infos[i]['terminal_observation'] = last obs and obs = reset obs."""
+    import torch
+    from deepmimic_mujoco_amd.deepmimic_env import HipDeepMimicVecEnv
+    from oracle.oracle import OracleSim
+    N, seed = 64, 4242
+    venv = HipDeepMimicVecEnv(N, motion="walk", seed=seed)
+    obs = venv.reset()
+    assert obs.shape == (N, 67) and venv.num_envs == N
+    oc = oracle_clips["walk"]
+    L = oc.L
+    # reset #0 of env i picks frame hash(seed, i, 0) % L
+    s = OracleSim(model)
+    s.set_caps(32, 64)
+    for i in (0, 17, 63):
+        fi = _hash32(seed, i, 0, 0x5EED) % L
+        assert np.abs(obs[i] - s.env_reset(oc, fi)).max() < 1e-5
+    rng = np.random.default_rng(1)
+    seen_done = 0
+    resets = np.ones(N, int)
+    for t in range(60):
+        act = rng.uniform(-2, 2, (N, 28)).astype(np.float32)
+        obs, rew, done, infos = venv.step(act)
+        assert len(infos) == N
+        for i in np.nonzero(done)[0]:
+            info = infos[i]
+            assert "terminal_observation" in info and info["terminal_observation"].shape == (67,)
+            fi = _hash32(seed, i, int(resets[i]), 0x5EED) % L
+            resets[i] += 1
+            assert abs(obs[i, 66] - fi / L) < 1e-6            # phase of the reset frame
+            assert np.abs(obs[i, :28] - oc.qpos[fi, 7:]).max() < 1e-5
+            assert info["done_reason"] in ("low_z", "high_z", "max_ep_len")
+            seen_done += 1
+        for i in np.nonzero(~done)[0][:3]:
+            assert "terminal_observation" not in infos[i]
+    assert seen_done > 10
+    idx, eplen, eprew = [x.cpu().numpy() for x in venv.engine.get_counters()]
+    assert (eplen >= 0).all() and (eplen <= 60).all()
+    venv.close()
+
+
+def test_multi_clip_batch(model, clips):
+    """BASELINE config 5 shape: clip id = env mod 4 over (walk, run, dance_b, spinkick)."""
+    import torch
+    from deepmimic_mujoco_amd.deepmimic_env import HipDeepMimicVecEnv
+    names = ["walk", "run", "dance_b", "spinkick"]
+    venv = HipDeepMimicVecEnv(32, motion=names, auto_reset=False)
+    idx = torch.full((32,), 3, dtype=torch.int32, device=venv.device)
+    obs = venv.reset_tensor(idx_init=idx).cpu().numpy()
+    for i in range(32):
+        mc = clips[names[i % 4]]
+        assert np.abs(obs[i, :28] - mc.data_config[3][7:]).max() < 1e-5
+        assert abs(obs[i, 66] - 3 / len(mc.data_config)) < 1e-6
+    venv.close()
+
+
+def test_free_running_rollout_stays_close_to_oracle(model, clips, oracle_clips):
+    """Free-running fp32 vs fp64 diverges chaotically in contact-rich motion; over a short horizon from a
+    clip frame with small torques the trajectories must still agree (reported, gated loosely)."""
+    import torch
+    from deepmimic_mujoco_amd._lib import HipEngine
+    from oracle.oracle import OracleSim
+    N, T = 16, 25
+    eng = HipEngine(model, N, auto_reset=False)
+    eng.load_clip(0, clips["walk"])
+    out = eng.alloc_outputs()
+    idx = (torch.arange(N, dtype=torch.int32, device=eng.device) * 4) % 76
+    eng.reset(out["obs"], idx_init=idx)
+    oc = oracle_clips["walk"]
+    sims = []
+    for i in range(N):
+        s = OracleSim(model)
+        s.set_caps(32, 64)
+        s.env_reset(oc, int(idx[i]))
+        sims.append(s)
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for t in range(T):
+        a = rng.uniform(-0.2, 0.2, (N, 28))
+        eng.step(torch.tensor(a, dtype=torch.float32, device=eng.device), out)
+        q = eng.get_state()[0].double().cpu().numpy()
+        for i, s in enumerate(sims):
+            s.env_step(oc, a[i])
+            worst = max(worst, np.abs(q[i] - s.get("qpos")).max())
+    print("free-running %d steps: max |qpos - oracle| = %.3g" % (T, worst))
+    assert worst < 5e-3
+    eng.close()
+
+
+def test_sim_error_and_obs_bound_paths(model, clips):
+    import torch
+    from deepmimic_mujoco_amd._lib import HipEngine
+    eng = HipEngine(model, 4, auto_reset=False)
+    eng.load_clip(0, clips["walk"])
+    out = eng.alloc_outputs()
+    eng.reset(out["obs"], idx_init=torch.zeros(4, dtype=torch.int32, device=eng.device))
+    q, v, w, c = eng.get_state()
+    q[1, 10] = float("nan")          # -> MujocoException path (deepmimic_env.py:366-378)
+    v[2, 8] = 5000.0                 # -> |obs| > 100 guard (:465-476): 0.1 * 5000 = 500
+    eng.set_state(q, v, w, c)
+    eng.step(torch.zeros(4, 28, device=eng.device), out)
+    torch.cuda.synchronize()
+    done, reason = out["done"].cpu().numpy(), out["reason"].cpu().numpy()
+    assert done[1] == 1 and reason[1] == 5 and not out["obs"][1].any() and out["rew"][1] == 0
+    assert done[2] == 1 and reason[2] == 6 and not out["obs"][2].any() and out["rew"][2] == 0
+    assert done[0] == 0 and reason[0] in (1, 2) and out["obs"][0].abs().max() > 0
+    q2 = eng.get_state()[0].cpu().numpy()
+    assert np.allclose(q2[1], model.qpos0, atol=1e-6)       # mjData reset after the warning
+    eng.close()
+
+
+def test_short_ppo_run_on_device():
+    import torch
+    from deepmimic_mujoco_amd.deepmimic_env import HipDeepMimicVecEnv
+    from deepmimic_mujoco_amd.ppo import PPO
+    venv = HipDeepMimicVecEnv(128, motion="walk")
+    ppo = PPO(venv, net_arch=(64, 32), n_steps=16, batch_size=512, n_epochs=2, learning_rate=3e-4)
+    ppo.learn(2 * 16 * 128, log_interval=0)
+    assert ppo.num_timesteps == 2 * 16 * 128 and np.isfinite(ppo.stats["loss"])
+    a = ppo.predict(venv.reset_tensor())
+    assert a.shape == (128, 28) and a.abs().max() <= 2.0
+    venv.close()
