@@ -24,7 +24,7 @@
     __builtin_amdgcn_wave_barrier();                        \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
   } while (0)
-#define DMK_ENVS_PER_BLOCK 4
+#define DMK_ENVS_PER_BLOCK 1
 // Diagnostic build only (-DDM_PROFILE): per-phase cycle stamps, written to the debug buffer
 // [352:368).  The shipped library never executes a stamp.
 #ifdef DM_PROFILE
@@ -401,15 +401,11 @@ __device__ __forceinline__ float impedance(const float *solimp, float pos, float
 }  // namespace
 
 // ======================================================================================
-extern "C" __global__ void __launch_bounds__(256, 2) dm_step_kernel(DmLaunch P) {
-  __shared__ DmDev T;                          // model tables, staged once per block (4 envs share them)
+extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, 2) dm_step_kernel(DmLaunch P) {
+  // Model tables are read from global memory at their use sites: 6 KB shared by every wave on the CU,
+  // so they sit in the vector L1 / scalar cache; keeping them out of LDS leaves room for more envs.
+  const DmDev &T = *P.T;
   __shared__ EnvLds SS[DMK_ENVS_PER_BLOCK];
-  {
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(P.T);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(&T);
-    for (int i = threadIdx.x; i < (int)(sizeof(DmDev) / 4); i += 256) dst[i] = src[i];
-  }
-  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   EnvLds &S = SS[wave];
@@ -665,24 +661,35 @@ extern "C" __global__ void __launch_bounds__(256, 2) dm_step_kernel(DmLaunch P) 
     }
     SYNC();
     PROF(2);
-    // ---- L^T D L factorisation in place; one dof per step, ancestor pairs across lanes
-    for (int kk = DMK_NV - 1; kk >= 1; kk--) {
+    // ---- L^T D L factorisation in place, rows left UNSCALED (L[i][j] = M[i][j] * dinv[i] is applied by
+    // the users).  One dof per step; its ancestor pairs (a <= b) are spread over the lanes; the ancestor
+    // indices of the NEXT step are fetched while this step's update is in flight.
+    {
+      const int ta0 = T.tri_a[lane], tb0 = T.tri_b[lane];
+      const int ta1 = T.tri_a[(lane + 64 < 80) ? lane + 64 : 79], tb1 = T.tri_b[(lane + 64 < 80) ? lane + 64 : 79];
+      int kk = DMK_NV - 1;
       int n = T.d_nanc[kk];
-      int npair = n * (n + 1) / 2;
-      float rk = 1.0f / S.M[kk * DMK_MSTRIDE + kk];
-      for (int p = lane; p < npair; p += 64) {
-        int a = T.tri_a[p], b = T.tri_b[p];
-        int i = T.d_anc[kk][a], j = T.d_anc[kk][b];
-        S.M[i * DMK_MSTRIDE + j] -= S.M[kk * DMK_MSTRIDE + j] * S.M[kk * DMK_MSTRIDE + i] * rk;
+      int i0 = T.d_anc[kk][ta0], j0 = T.d_anc[kk][tb0], i1 = T.d_anc[kk][ta1], j1 = T.d_anc[kk][tb1];
+      for (; kk >= 1; kk--) {
+        const int kn = (kk > 1) ? kk - 1 : 1;
+        const int nn = T.d_nanc[kn];
+        const int ni0 = T.d_anc[kn][ta0], nj0 = T.d_anc[kn][tb0], ni1 = T.d_anc[kn][ta1], nj1 = T.d_anc[kn][tb1];
+        const int npair = n * (n + 1) / 2;
+        const float rk = __builtin_amdgcn_rcpf(S.M[kk * (DMK_MSTRIDE + 1)]);
+        if (lane < npair)
+          S.M[i0 * DMK_MSTRIDE + j0] -= S.M[kk * DMK_MSTRIDE + j0] * S.M[kk * DMK_MSTRIDE + i0] * rk;
+        if (lane + 64 < npair)
+          S.M[i1 * DMK_MSTRIDE + j1] -= S.M[kk * DMK_MSTRIDE + j1] * S.M[kk * DMK_MSTRIDE + i1] * rk;
+        SYNC();
+        n = nn; i0 = ni0; j0 = nj0; i1 = ni1; j1 = nj1;
       }
-      SYNC();
     }
+    float dv = 0.f;  // 1 / D[lane]
     if (lane < DMK_NV) {
-      float dd = S.M[lk * DMK_MSTRIDE + lk];
-      float di = 1.0f / dd;
-      S.dinv[lk] = di;
+      const float dd = S.M[lk * (DMK_MSTRIDE + 1)];
+      dv = 1.0f / dd;
+      S.dinv[lk] = dv;
       S.dsqrtinv[lk] = 1.0f / sqrtf(dd);
-      for (int a = 0; a < dnanc; a++) S.M[lk * DMK_MSTRIDE + T.d_anc[lk][a]] *= di;
     }
     PROF(3);
     if (lane == 0) {
@@ -763,18 +770,18 @@ extern "C" __global__ void __launch_bounds__(256, 2) dm_step_kernel(DmLaunch P) 
       xs = -ddamp * S.qvel[lk] - bias + act;
     }
 #pragma unroll
-    for (int i = DMK_NV - 1; i >= 1; i--) {
-      float xi = rl(xs, i);
-      float l = S.M[i * DMK_MSTRIDE + lk];
+    for (int i = DMK_NV - 1; i >= 1; i--) {   // x <- L^-T x  (L[i][j] = M[i][j] * dinv[i])
+      const float xi = rl(xs * dv, i);
+      const float l = S.M[i * DMK_MSTRIDE + lk];
       if (lane < i) xs -= l * xi;
     }
-    xs *= S.dinv[lk];
 #pragma unroll
-    for (int j = 0; j < DMK_NV - 1; j++) {
-      float xj = rl(xs, j);
-      float l = S.M[lk * DMK_MSTRIDE + j];
+    for (int j = 0; j < DMK_NV - 1; j++) {    // z <- z - M[:, j] x_j with x = z * dinv  (D^-1 and L^-1 fused)
+      const float xj = rl(xs * dv, j);
+      const float l = S.M[lk * DMK_MSTRIDE + j];
       if (lane > j && lane < DMK_NV) xs -= l * xj;
     }
+    xs *= dv;
     if (lane < DMK_NV) S.qacc_smooth[lk] = xs;
     SYNC();
 
@@ -1089,7 +1096,7 @@ extern "C" __global__ void __launch_bounds__(256, 2) dm_step_kernel(DmLaunch P) 
         lds_cfloat_p Mp = (lds_cfloat_p)S.M;
 #pragma unroll
         for (int i = DMK_NV - 1; i >= 1; i--) {
-          const float xi = J[i];
+          const float xi = J[i] * S.dinv[i];
           asm volatile("" : "+v"(Mp), "+v"(J[0]));
 #pragma unroll
           for (int j = 0; j < i; j++) J[j] -= Mp[i * DMK_MSTRIDE + j] * xi;
@@ -1160,14 +1167,14 @@ extern "C" __global__ void __launch_bounds__(256, 2) dm_step_kernel(DmLaunch P) 
         float s = wave_sum(f * J[k]);
         if (lane == k) v = s;
       }
-      v *= S.dsqrtinv[lk];
+      v *= S.dsqrtinv[lk] * S.M[lk * (DMK_MSTRIDE + 1)];   // z = D (D^-1/2 v)
 #pragma unroll
-      for (int j = 0; j < DMK_NV - 1; j++) {
-        float xj = rl(v, j);
-        float l = S.M[lk * DMK_MSTRIDE + j];
+      for (int j = 0; j < DMK_NV - 1; j++) {                 // x = L^-1 (.) with x = z * dinv
+        const float xj = rl(v * dv, j);
+        const float l = S.M[lk * DMK_MSTRIDE + j];
         if (lane > j && lane < DMK_NV) v -= l * xj;
       }
-      qacc_out = xs + v;
+      qacc_out = xs + v * dv;
       if (P.debug && lane < DMK_MAXROW) P.debug[(size_t)env * DM_DEBUG_STRIDE + 352 + lane] = (lane < nefc) ? f : 0.f;
     }
     SYNC();

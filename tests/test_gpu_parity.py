@@ -162,3 +162,87 @@ def test_force_state_clip_playback(model, clips, oracle_clips, torch_mod, motion
     # un-normalised lerp while qpos[3:7] is normalised, so the pitch term leaves a small residue
     assert np.abs(gterms[:, 0] - 1.0).max() < 2e-3
     eng.close()
+
+
+@pytest.mark.parametrize("motion,scale,seed", [("run", 1.0, 11), ("spinkick", 0.5, 12), ("dance_b", 2.0, 13)])
+def test_teacher_forced_other_clips(model, clips, oracle_clips, torch_mod, motion, scale, seed):
+    res = _run_teacher_forced(model, clips, oracle_clips, torch_mod, scale, seed, nenv=8, nsteps=40, motion=motion)
+    ok = np.ones(len(res["qpos"]), bool)
+    for m in res["contact_mismatch"]:
+        assert m[3], m
+        ok[m[0]] = False
+    ok[res["stage_flips"]] = False
+    assert ok.mean() > 0.98
+    print(motion, "qpos", res["qpos"][ok].max(), "obs", res["obs"][ok].max())
+    assert res["qpos"][ok].max() < TOL_QPOS and res["obs"][ok].max() < TOL_OBS and res["rew"][ok].max() < TOL_REW
+
+
+def test_full_size_batch_properties(model, clips, torch_mod):
+    """BASELINE size (4096 envs): determinism and env-permutation invariance — shuffling the env order
+    must permute every output bit-exactly (no cross-env leakage), and a repeated run is bit-identical."""
+    torch = torch_mod
+    N = 4096
+    mc = clips["walk"]
+    L = len(mc.data_config)
+
+    def run(perm):
+        eng = _engine(model, clips, N, torch)
+        dev = eng.device
+        out = eng.alloc_outputs()
+        idx = (torch.arange(N, device=dev) * 7 % L).to(torch.int32)[perm]
+        eng.reset(out["obs"], idx_init=idx)
+        g = torch.Generator(device="cpu").manual_seed(3)
+        acts = [(torch.rand(N, 28, generator=g) * 3 - 1.5) for _ in range(6)]
+        res = []
+        for a in acts:
+            eng.step(a.to(dev)[perm].contiguous(), out)
+            res.append((out["obs"].clone(), out["rew"].clone(), out["done"].clone()))
+        q = eng.get_state()[0].clone()
+        eng.close()
+        return res, q
+
+    ident = torch.arange(N, device="cuda")
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(9)).cuda()
+    r0, q0 = run(ident)
+    r1, q1 = run(ident)
+    r2, q2 = run(perm)
+    assert torch.equal(q0, q1) and all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(r0, r1))
+    assert torch.equal(q0[perm], q2)
+    for a, b in zip(r0, r2):
+        assert torch.equal(a[0][perm], b[0]) and torch.equal(a[1][perm], b[1]) and torch.equal(a[2][perm], b[2])
+    assert torch.isfinite(q0).all() and float(r0[-1][1].mean()) > 0.0
+
+
+def test_caps_overflow_matches_oracle_rule(model, clips, oracle_clips, torch_mod):
+    """A pose lying in the floor plane produces more than 32 contacts: both sides must keep the first 32
+    contacts / 64 rows in canonical order and flag the overflow."""
+    from oracle.oracle import OracleSim
+    torch = torch_mod
+    q = model.qpos0.copy()
+    q[2] = 0.05                                  # root 5 cm above the floor ...
+    q[3:7] = [np.cos(np.pi / 4), 0, np.sin(np.pi / 4), 0]   # ... pitched 90 deg: the whole body lies on the plane
+    v = np.zeros(34)
+    s = OracleSim(model)
+    s.set_caps(32, 64)
+    s.set_state(q, v)
+    full = OracleSim(model)
+    full.set_state(q, v)
+    assert full.ncon >= 16 and full.nefc > 64     # 19 floor contacts x 4 pyramid rows
+    eng = _engine(model, clips, 1, torch)
+    dbg = eng.enable_debug()
+    eng.set_state(torch.tensor(q[None], dtype=torch.float32, device=eng.device),
+                  torch.tensor(v[None], dtype=torch.float32, device=eng.device), run_forward=True)
+    out = eng.alloc_outputs()
+    eng.step_forced(torch.tensor(q[None], dtype=torch.float32, device=eng.device),
+                    torch.tensor(v[None], dtype=torch.float32, device=eng.device), out)
+    torch.cuda.synchronize()
+    d = dbg.cpu().numpy()[0]
+    ncon, nefc = int(d[242]), int(d[243])
+    gpu = [(int(d[256 + 3 * c]), int(d[257 + 3 * c])) for c in range(ncon)]
+    ora = [(int(c[13]), int(c[14])) for c in s.get("contact")]
+    assert gpu == ora and nefc == s.nefc
+    if full.ncon > 32 or full.nefc > 64:
+        assert d[246] != 0 and (s.geti("overflow_con") > 0 or s.geti("overflow_row") > 0)
+    qa = d[174:208]
+    assert np.abs(qa - s.get("qacc")).max() < 2e-2 * max(1.0, np.abs(s.get("qacc")).max())
+    eng.close()
