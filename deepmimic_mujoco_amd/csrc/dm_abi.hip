@@ -92,6 +92,11 @@ static void build_tables(const DmModel &m, DmDev &T) {
     for (int a = b; a > 0; a = m.body_parent[a])
       for (int k = 0; k < m.body_dofnum[a]; k++) chain |= 1ull << (m.body_dofadr[a] + k);
     T.b_chain[b] = chain;
+    uint32_t cb = 0;
+    int ids[8], nc = 0;
+    for (int a = b; a > 0; a = m.body_parent[a]) ids[nc++] = a;
+    for (int c = 0; c < nc && c < 4; c++) cb |= (uint32_t)ids[nc - 1 - c] << (8 * c);   // root first
+    T.b_chainb[b] = cb;
   }
   for (int k = 0; k < DM_NV; k++) {
     int j = m.dof_jnt[k];
@@ -105,6 +110,12 @@ static void build_tables(const DmModel &m, DmDev &T) {
     int n = 0;
     for (int a = m.dof_parent[k]; a >= 0 && n < DMK_MAXANC; a = m.dof_parent[a]) T.d_anc[k][n++] = (uint8_t)a;
     T.d_nanc[k] = n;
+    for (int d = 0; d < n; d++) T.d_ancabs[k][d] = T.d_anc[k][n - 1 - d];   // absolute depth d
+    T.d_pbody[k] = m.body_parent[m.dof_body[k]];
+  }
+  for (int k = 0; k < DM_NV; k++) {
+    for (int a = 0; a < T.d_nanc[k]; a++) T.d_desc[T.d_anc[k][a]] |= 1ull << k;
+    T.nanc_pack[k >> 4] |= (uint64_t)T.d_nanc[k] << (4 * (k & 15));
   }
   for (int a = 0; a < DM_NU; a++) {
     int k = m.act_dof[a];

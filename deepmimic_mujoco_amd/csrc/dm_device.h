@@ -42,12 +42,17 @@ struct DmDev {
   float b_pos[16][3], b_ipos[16][3], b_inertia[16][6], b_mass[16], b_invw[16];
   uint32_t b_subtree[16];       // bit c: body c is in the subtree of b (incl. b)
   uint64_t b_chain[16];         // bit k: dof k moves body b
+  uint32_t b_chainb[16];        // ancestor bodies root..self, one byte each (0 = none)
   // dofs
   int32_t d_body[DM_NV], d_nanc[DM_NV], d_act[DM_NV], d_limited[DM_NV];
   float d_axis[DM_NV][3];       // joint axis in the body frame (hinges)
   float d_arm[DM_NV], d_damp[DM_NV], d_invw[DM_NV], d_lo[DM_NV], d_hi[DM_NV];
   float d_gear[DM_NV], d_clo[DM_NV], d_chi[DM_NV];
   uint8_t d_anc[DM_NV][DMK_MAXANC];
+  uint8_t d_ancabs[DM_NV][DMK_MAXANC + 4]; // ancestor dof at absolute depth d (0 if none)
+  uint64_t d_desc[DM_NV];       // bit k: dof k is a strict descendant
+  int32_t d_pbody[DM_NV];       // parent body of the dof's body
+  uint64_t nanc_pack[3];        // d_nanc of every dof, 4 bits each
   // geoms
   int32_t g_body[16], g_type[16], g_condim[16];
   float g_pos[16][3], g_mat[16][9], g_size[16][3], g_rbound[16], g_margin[16], g_mu[16];
@@ -73,11 +78,14 @@ struct EnvLds {
   // contacts of the current forward evaluation
   float c_dist[DMK_MAXCON], c_pos[DMK_MAXCON][3], c_frame[DMK_MAXCON][9];
   int32_t c_g1[DMK_MAXCON], c_g2[DMK_MAXCON];
+  unsigned long long prof_t; unsigned prof[16];  // -DDM_PROFILE diagnostic stamps only
+  int32_t info[8];                    // ncon, nefc, nlimit, solver_iter, overflow (last forward evaluation)
   int32_t rowinfo[DMK_MAXROW];        // contact rows: (contact << 3) | edge ; limit rows: -1
   // velocity-stage scratch (dead before the constraint stage) / box-box polygon scratch
   union {
     struct {
       float crb[DMK_NB][10];
+      float qloc[DMK_NB][8];          // body rotation relative to its parent (4) + offset in the parent frame (3)
       float cdofdot[DMK_NV][6];
       float cacc[DMK_NB][6], cfrc[DMK_NB][6], cfrcsub[DMK_NB][6];
     } v;

@@ -28,10 +28,16 @@
 // Diagnostic build only (-DDM_PROFILE): per-phase cycle stamps, written to the debug buffer
 // [352:368).  The shipped library never executes a stamp.
 #ifdef DM_PROFILE
-#define PROF_DECL unsigned prof_acc[16] = {0}; unsigned long long prof_t = __builtin_amdgcn_s_memtime();
-#define PROF(i) do { unsigned long long _t = __builtin_amdgcn_s_memtime(); prof_acc[i] += (unsigned)(_t - prof_t); prof_t = _t; } while (0)
+#define PROF_DECL do { if ((threadIdx.x & 63) == 0) { for (int _i = 0; _i < 16; _i++) g_S.prof[_i] = 0; g_S.prof_t = __builtin_amdgcn_s_memtime(); } } while (0)
+#define PROF(i) do { if ((threadIdx.x & 63) == 0) { unsigned long long _t = __builtin_amdgcn_s_memtime(); g_S.prof[i] += (unsigned)(_t - g_S.prof_t); g_S.prof_t = _t; } } while (0)
+#if DM_PROFILE == 2
+#define PROF2(i) PROF(i)
 #else
-#define PROF_DECL
+#define PROF2(i) do {} while (0)
+#endif
+#else
+#define PROF2(i) do {} while (0)
+#define PROF_DECL do {} while (0)
 #define PROF(i) do {} while (0)
 #endif
 typedef __attribute__((address_space(3))) const float *lds_cfloat_p;
@@ -400,30 +406,8 @@ __device__ __forceinline__ float impedance(const float *solimp, float pos, float
 
 }  // namespace
 
-// ======================================================================================
-extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, 2) dm_step_kernel(DmLaunch P) {
-  // Model tables are read from global memory at their use sites: 6 KB shared by every wave on the CU,
-  // so they sit in the vector L1 / scalar cache; keeping them out of LDS leaves room for more envs.
-  const DmDev &T = *P.T;
-  __shared__ EnvLds SS[DMK_ENVS_PER_BLOCK];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  EnvLds &S = SS[wave];
-  const int slot = blockIdx.x * DMK_ENVS_PER_BLOCK + wave;
-  if (slot >= P.nslots) return;
-  const int env = P.env_ids ? P.env_ids[slot] : slot;
-  if (env < 0 || env >= P.N) return;
-  const int mode = P.mode;
-  if (mode == DMK_MODE_RESET && P.mask && !P.mask[env]) return;
-  float *st = P.state + (size_t)env * DMK_STATE_STRIDE;
-  int *sti = reinterpret_cast<int *>(st);
+__shared__ EnvLds g_S;  // one environment per 64-thread block
 
-  // ---------------------------------------------------------------- lane roles (values are read
-  // from the LDS-resident table at their use sites so they do not pin registers)
-  const int lb = lane < DMK_NB ? lane : 0;       // lane as body
-  const int lk = lane < DMK_NV ? lane : 0;       // lane as dof
-  const int lg = lane < DMK_NG ? lane : 0;       // lane as geom
-  const int bdep = (lane < DMK_NB) ? T.b_depth[lb] : -1;
 #define bp (T.b_parent[lb])
 #define bdofadr (T.b_dofadr[lb])
 #define bdofnum (T.b_dofnum[lb])
@@ -446,346 +430,352 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, 2) dm_step
 #define gbody (T.g_body[lg])
 #define gposl (T.g_pos[lg])
 #define gmatl (T.g_mat[lg])
+
+// ---- forward evaluation, part 1: kinematics, inertia, factorisation, bias forces, qacc_smooth
+// Every pass is lane-parallel: bodies walk their (<= 4 deep) ancestor chain instead of waiting for a
+// level-by-level sweep, and the L^T D L factorisation keeps row i of M in the registers of lane i.
+__device__ __forceinline__ void fwd_smooth(const DmDev &T, const int lane) {
+  EnvLds &S = g_S;
+  const int lb = lane < DMK_NB ? lane : 0;       // lane as body
+  const int lk = lane < DMK_NV ? lane : 0;       // lane as dof
+  const int lg = lane < DMK_NG ? lane : 0;       // lane as geom
+  const bool isbody = lane >= 1 && lane < DMK_NB, isdof = lane < DMK_NV;
+  // role constants of this phase (function-local registers)
   const float bmass = (lane < DMK_NB) ? T.b_mass[lb] : 0.f;
-  const float h = T.timestep;
+  const int b_dofadr = T.b_dofadr[lb], b_dofnum = T.b_dofnum[lb];
+  const uint32_t b_chain4 = T.b_chainb[lb];      // ancestor bodies root..self, one byte each (0 = none)
+  const unsigned b_sub = T.b_subtree[lb];
+  const int d_body = T.d_body[lk], d_nanc = T.d_nanc[lk], d_pbody = T.d_pbody[lk];
   const float mtot_inv = T.total_mass_inv;
 
-  PROF_DECL
-  // ---------------------------------------------------------------- LDS init
-  for (int i = lane; i < DMK_NV * DMK_MSTRIDE; i += 64) S.M[i] = 0.f;
-  if (lane == 0) {
-    S.xpos[0][0] = S.xpos[0][1] = S.xpos[0][2] = 0;
-    S.xquat[0][0] = 1; S.xquat[0][1] = S.xquat[0][2] = S.xquat[0][3] = 0;
-    for (int i = 0; i < 9; i++) S.xmat[0][i] = (i % 4 == 0) ? 1.f : 0.f;
-    S.xipos[0][0] = S.xipos[0][1] = S.xipos[0][2] = 0;
-    for (int i = 0; i < 6; i++) S.cvel[0][i] = 0;
-    for (int i = 0; i < 10; i++) S.cinert[0][i] = 0;
-  }
-
-  // ---------------------------------------------------------------- load state
-  const int clip_id = sti[DMS_CLIP];
-  const DmClipDev clip = P.clips[(clip_id >= 0 && clip_id < 8) ? clip_id : 0];
-  if (clip.L < 1 || clip.rows == nullptr) return;  // no clip loaded for this env's clip id
-  int idx_curr = sti[DMS_IDX], ep_len = sti[DMS_EPLEN], rcnt = sti[DMS_RCNT];
-  idx_curr = idx_curr < 0 ? 0 : (idx_curr >= clip.L ? clip.L - 1 : idx_curr);
-  float ep_rew = st[DMS_EPREW];
-  if (lane < DMK_NQ) S.qpos[lane] = st[DMS_QPOS + lane];
-  if (lane < DMK_NV) { S.qvel[lane] = st[DMS_QVEL + lane]; S.warm[lane] = st[DMS_WARM + lane]; }
-  if (lane < DMK_NU) S.ctrl[lane] = st[DMS_CTRL + lane];
-  SYNC();
-  if (mode == DMK_MODE_STEP) {
-    if (lane < DMK_NU) S.ctrl[lane] = P.actions[(size_t)env * DMK_NU + lane];  // ctrl = action * 1.0 (:347)
-  } else if (mode == DMK_MODE_FORCED || mode == DMK_MODE_SETSTATE) {
-    if (lane < DMK_NQ) S.qpos[lane] = P.in_qpos[(size_t)slot * DMK_NQ + lane];
-    if (lane < DMK_NV) S.qvel[lane] = P.in_qvel[(size_t)slot * DMK_NV + lane];
-    if (mode == DMK_MODE_SETSTATE) {
-      if (P.in_warm && lane < DMK_NV) S.warm[lane] = P.in_warm[(size_t)slot * DMK_NV + lane];
-      if (P.in_ctrl && lane < DMK_NU) S.ctrl[lane] = P.in_ctrl[(size_t)slot * DMK_NU + lane];
+  // ---- P0: normalise the free-joint quaternion in place (mj_kinematics does); half-angle sin/cos
+  {
+    float q[4] = {S.qpos[3], S.qpos[4], S.qpos[5], S.qpos[6]};
+    quat_normalize(q);
+    SYNC();
+    if (lane < 4) S.qpos[3 + lane] = (lane == 0) ? q[0] : (lane == 1) ? q[1] : (lane == 2) ? q[2] : q[3];
+    if (lane >= 6 && lane < DMK_NV) {
+      float sn, cs;
+      sincosf(0.5f * S.qpos[lane + 1], &sn, &cs);
+      S.cs[lane][0] = cs; S.cs[lane][1] = sn;
     }
-  } else if (mode == DMK_MODE_RESET) {
-    int fi = P.idx_init ? P.idx_init[env] : (int)(dm_hash32(P.seed, env, rcnt, 0x5EED) % (uint32_t)clip.L);
-    fi = fi < 0 ? 0 : (fi >= clip.L ? clip.L - 1 : fi);
-    const float *rr = clip.reset + (size_t)fi * DMK_RESET_ROW;
-    if (lane < DMK_NQ) S.qpos[lane] = rr[lane];
-    if (lane < DMK_NV) S.qvel[lane] = rr[35 + lane];
-    idx_curr = fi; ep_len = 0; ep_rew = 0; rcnt++;
+    SYNC();
   }
-  SYNC();
-
-  // RK4 bookkeeping, lane = dof (k<3 root translation, 3..5 root rotation, >=6 hinges)
-  float x0q = 0, x0v = 0, accq = 0, accv = 0, curv = 0;
-  float q0[4] = {1, 0, 0, 0};
-  int it = (mode == DMK_MODE_STEP) ? 0 : 4;
-  bool after_reset = false, done = false, sim_err = false;
-  int reason = DM_REASON_NONE;
-  float reward = 0;
-  int ncon = 0, nefc = 0, nlimit = 0, solver_iter = 0, overflow = 0;
-  float com[3] = {0, 0, 0};
-  unsigned stage_ncon = 0, stage_nefc = 0;  // byte i = count at RK stage i (debug)
-
-  if (mode == DMK_MODE_SETSTATE && !P.run_forward) {  // store only
-    if (lane < DMK_NQ) st[DMS_QPOS + lane] = S.qpos[lane];
-    if (lane < DMK_NV) { st[DMS_QVEL + lane] = S.qvel[lane]; st[DMS_WARM + lane] = S.warm[lane]; }
-    if (lane < DMK_NU) st[DMS_CTRL + lane] = S.ctrl[lane];
-    return;
-  }
-  if (mode == DMK_MODE_STEP || mode == DMK_MODE_FORCED) {  // mj_checkPos / mj_checkVel
-    float a = (lane < DMK_NQ) ? S.qpos[lane] : 0.f, b = (lane < DMK_NV) ? S.qvel[lk] : 0.f;
-    sim_err = __any(!(fabsf(a) <= MAXVALF) || !(fabsf(b) <= MAXVALF));
-  }
-
-  PROF(0);
-  for (;;) {
-   float qacc_out = 0;
-   if (!sim_err) {
-    // ============================================================== forward evaluation
-    // stage state is in S.qpos / S.qvel / S.ctrl / S.warm
-    {  // normalise the free-joint quaternion in place (mj_kinematics does)
-      float q[4] = {S.qpos[3], S.qpos[4], S.qpos[5], S.qpos[6]};
-      quat_normalize(q);
-      SYNC();
-      if (lane < 4) S.qpos[3 + lane] = (lane == 0) ? q[0] : (lane == 1) ? q[1] : (lane == 2) ? q[2] : q[3];
-      if (lane >= 6 && lane < DMK_NV) {
-        float s, c;
-        sincosf(0.5f * S.qpos[lane + 1], &s, &c);
-        S.cs[lane][0] = c; S.cs[lane][1] = s;
-      }
-      SYNC();
-    }
-    if (it == 0) {  // capture X0 (after normalisation)
-      x0v = (lane < DMK_NV) ? S.qvel[lk] : 0.f;
-      x0q = (lane < 3) ? S.qpos[lane] : ((lane >= 6 && lane < DMK_NV) ? S.qpos[lane + 1] : 0.f);
-      for (int i = 0; i < 4; i++) q0[i] = S.qpos[3 + i];
-      curv = x0v;
-    }
-    // ---- kinematics, level by level (lane = body)
-    for (int lev = 1; lev <= 4; lev++) {
-      if (bdep == lev) {
-        float pos[3], q[4];
-        if (lev == 1) {
-          for (int i = 0; i < 3; i++) pos[i] = S.qpos[i];
-          for (int i = 0; i < 4; i++) q[i] = S.qpos[3 + i];
-        } else {
-          float pm[9], pp[3], tv[3];
-          for (int i = 0; i < 9; i++) pm[i] = S.xmat[bp][i];
-          for (int i = 0; i < 3; i++) pp[i] = S.xpos[bp][i];
-          for (int i = 0; i < 4; i++) q[i] = S.xquat[bp][i];
-          { const float bl[3] = {bpos[0], bpos[1], bpos[2]}; mat_vec(tv, pm, bl); }
-          for (int i = 0; i < 3; i++) pos[i] = pp[i] + tv[i];
+  PROF2(12);
+  // ---- P1 (lane = body): rotation of the body relative to its parent (product of its hinge
+  // quaternions) and each hinge axis expressed in the parent-body frame
+  if (isbody) {
+    float q[4] = {1.f, 0.f, 0.f, 0.f};
+    if (lb == 1) {
+      for (int i = 0; i < 4; i++) q[i] = S.qpos[3 + i];
+    } else {
 #pragma unroll
-          for (int j = 0; j < 3; j++) {
-            if (j < bdofnum) {
-              int k = bdofadr + j;
-              float ax[3], ql[4], qn[4];
-              { const float al[3] = {baxis(j)[0], baxis(j)[1], baxis(j)[2]}; quat_rot(ax, q, al); }
-              S.xaxis[k][0] = ax[0]; S.xaxis[k][1] = ax[1]; S.xaxis[k][2] = ax[2];
-              float c = S.cs[k][0], s = S.cs[k][1];
-              ql[0] = c; ql[1] = baxis(j)[0] * s; ql[2] = baxis(j)[1] * s; ql[3] = baxis(j)[2] * s;
-              quat_mul(qn, q, ql);
-              q[0] = qn[0]; q[1] = qn[1]; q[2] = qn[2]; q[3] = qn[3];
-            }
-          }
+      for (int j = 0; j < 3; j++) {
+        if (j < b_dofnum) {
+          const int k = b_dofadr + j;
+          const float al[3] = {T.d_axis[k][0], T.d_axis[k][1], T.d_axis[k][2]};
+          float ax[3], ql[4], qn[4];
+          quat_rot(ax, q, al);
+          S.xaxis[k][0] = ax[0]; S.xaxis[k][1] = ax[1]; S.xaxis[k][2] = ax[2];   // parent-frame axis for now
+          const float c = S.cs[k][0], sn = S.cs[k][1];
+          ql[0] = c; ql[1] = al[0] * sn; ql[2] = al[1] * sn; ql[3] = al[2] * sn;
+          quat_mul(qn, q, ql);
+          q[0] = qn[0]; q[1] = qn[1]; q[2] = qn[2]; q[3] = qn[3];
         }
-        quat_normalize(q);
-        float m9[9], tv[3];
-        quat2mat(m9, q);
-        for (int i = 0; i < 3; i++) S.xpos[lb][i] = pos[i];
-        for (int i = 0; i < 4; i++) S.xquat[lb][i] = q[i];
-        for (int i = 0; i < 9; i++) S.xmat[lb][i] = m9[i];
-        { const float bl[3] = {bipos[0], bipos[1], bipos[2]}; mat_vec(tv, m9, bl); }
-        for (int i = 0; i < 3; i++) S.xipos[lb][i] = pos[i] + tv[i];
-        if (lev == 1)
-          for (int j = 0; j < 3; j++) { S.xaxis[3 + j][0] = m9[j]; S.xaxis[3 + j][1] = m9[3 + j]; S.xaxis[3 + j][2] = m9[6 + j]; }
       }
-      SYNC();
     }
-    // ---- geoms (lane = geom), COM
+    for (int i = 0; i < 4; i++) S.u.v.qloc[lb][i] = q[i];
+    for (int i = 0; i < 3; i++) S.u.v.qloc[lb][4 + i] = (lb == 1) ? S.qpos[i] : T.b_pos[lb][i];
+  }
+  SYNC();
+  // ---- P2 (lane = body): compose along the ancestor chain root -> self
+  if (isbody) {
+    float q[4] = {1.f, 0.f, 0.f, 0.f}, pos[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int cb = (b_chain4 >> (8 * c)) & 0xFF;
+      if (cb != 0) {
+        float ql[4], pl[3], t[3], qn[4];
+        for (int i = 0; i < 4; i++) ql[i] = S.u.v.qloc[cb][i];
+        for (int i = 0; i < 3; i++) pl[i] = S.u.v.qloc[cb][4 + i];
+        quat_rot(t, q, pl);
+        pos[0] += t[0]; pos[1] += t[1]; pos[2] += t[2];
+        quat_mul(qn, q, ql);
+        q[0] = qn[0]; q[1] = qn[1]; q[2] = qn[2]; q[3] = qn[3];
+      }
+    }
+    quat_normalize(q);
+    float m9[9], tv[3];
+    quat2mat(m9, q);
+    const float ip[3] = {T.b_ipos[lb][0], T.b_ipos[lb][1], T.b_ipos[lb][2]};
+    mat_vec(tv, m9, ip);
+    for (int i = 0; i < 3; i++) { S.xpos[lb][i] = pos[i]; S.xipos[lb][i] = pos[i] + tv[i]; }
+    for (int i = 0; i < 4; i++) S.xquat[lb][i] = q[i];
+    for (int i = 0; i < 9; i++) S.xmat[lb][i] = m9[i];
+  }
+  SYNC();
+  PROF2(13);
+  // ---- P3: world joint axes (lane = dof), geom poses (lane = geom), whole-body COM
+  float com[3];
+  {
+    float ax[3] = {0.f, 0.f, 0.f};
+    if (lane >= 6 && isdof) {
+      const float pq[4] = {S.xquat[d_pbody][0], S.xquat[d_pbody][1], S.xquat[d_pbody][2], S.xquat[d_pbody][3]};
+      const float al[3] = {S.xaxis[lk][0], S.xaxis[lk][1], S.xaxis[lk][2]};
+      quat_rot(ax, pq, al);
+    } else if (lane >= 3 && lane < 6) {
+      ax[0] = S.xmat[1][lane - 3]; ax[1] = S.xmat[1][3 + lane - 3]; ax[2] = S.xmat[1][6 + lane - 3];
+    }
     if (lane < DMK_NG) {
-      float bm[9], tv[3];
-      for (int i = 0; i < 9; i++) bm[i] = S.xmat[gbody][i];
-      { const float gl[3] = {gposl[0], gposl[1], gposl[2]}; mat_vec(tv, bm, gl); }
-      for (int i = 0; i < 3; i++) S.gpos[lg][i] = S.xpos[gbody][i] + tv[i];
+      const int gb = T.g_body[lg];
+      float bm[9], tv[3], gl[3] = {T.g_pos[lg][0], T.g_pos[lg][1], T.g_pos[lg][2]}, gm[9];
+      for (int i = 0; i < 9; i++) { bm[i] = S.xmat[gb][i]; gm[i] = T.g_mat[lg][i]; }
+      mat_vec(tv, bm, gl);
+      for (int i = 0; i < 3; i++) S.gpos[lg][i] = S.xpos[gb][i] + tv[i];
       for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++)
-          S.gmat[lg][3 * i + j] = bm[3 * i] * gmatl[j] + bm[3 * i + 1] * gmatl[3 + j] + bm[3 * i + 2] * gmatl[6 + j];
+          S.gmat[lg][3 * i + j] = bm[3 * i] * gm[j] + bm[3 * i + 1] * gm[3 + j] + bm[3 * i + 2] * gm[6 + j];
     }
-    {
-      float xi[3] = {S.xipos[lb][0], S.xipos[lb][1], S.xipos[lb][2]};
-      for (int i = 0; i < 3; i++) com[i] = wave_sum(bmass * xi[i]) * mtot_inv;
-      if (lane == 0) { S.com[0] = com[0]; S.com[1] = com[1]; S.com[2] = com[2]; }
-    }
-    // ---- cinert (lane = body), cdof (lane = dof)
-    if (lane >= 1 && lane < DMK_NB) {
-      float R[9], Tm[9], W[6];
-      for (int i = 0; i < 9; i++) R[i] = S.xmat[lb][i];
-      const float Ib[9] = {binert[0], binert[3], binert[4], binert[3], binert[1], binert[5], binert[4], binert[5], binert[2]};
-      for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) Tm[3 * i + j] = R[3 * i] * Ib[j] + R[3 * i + 1] * Ib[3 + j] + R[3 * i + 2] * Ib[6 + j];
-      // W = Tm R^T, unique entries xx yy zz xy xz yz
-      W[0] = Tm[0] * R[0] + Tm[1] * R[1] + Tm[2] * R[2];
-      W[1] = Tm[3] * R[3] + Tm[4] * R[4] + Tm[5] * R[5];
-      W[2] = Tm[6] * R[6] + Tm[7] * R[7] + Tm[8] * R[8];
-      W[3] = Tm[0] * R[3] + Tm[1] * R[4] + Tm[2] * R[5];
-      W[4] = Tm[0] * R[6] + Tm[1] * R[7] + Tm[2] * R[8];
-      W[5] = Tm[3] * R[6] + Tm[4] * R[7] + Tm[5] * R[8];
-      float o[3] = {S.xipos[lb][0] - com[0], S.xipos[lb][1] - com[1], S.xipos[lb][2] - com[2]};
-      float oo = dot3(o, o);
-      float *ci = S.cinert[lb];
-      ci[0] = W[0] + bmass * (oo - o[0] * o[0]);
-      ci[1] = W[1] + bmass * (oo - o[1] * o[1]);
-      ci[2] = W[2] + bmass * (oo - o[2] * o[2]);
-      ci[3] = W[3] - bmass * o[0] * o[1];
-      ci[4] = W[4] - bmass * o[0] * o[2];
-      ci[5] = W[5] - bmass * o[1] * o[2];
-      ci[6] = bmass * o[0]; ci[7] = bmass * o[1]; ci[8] = bmass * o[2];
-      ci[9] = bmass;
-    }
-    if (lane < DMK_NV) {
+    const float xi[3] = {S.xipos[lb][0], S.xipos[lb][1], S.xipos[lb][2]};
+    for (int i = 0; i < 3; i++) com[i] = wave_sum(bmass * xi[i]) * mtot_inv;
+    if (lane == 0) { S.com[0] = com[0]; S.com[1] = com[1]; S.com[2] = com[2]; }
+    SYNC();  // every lane has read the parent-frame axes
+    // cdof (lane = dof), COM-based spatial frame
+    if (isdof) {
       float cd[6] = {0, 0, 0, 0, 0, 0};
       if (lane < 3) {
         cd[3 + lane] = 1.f;
       } else {
-        float ax[3] = {S.xaxis[lk][0], S.xaxis[lk][1], S.xaxis[lk][2]};
-        float off[3] = {com[0] - S.xpos[dbody][0], com[1] - S.xpos[dbody][1], com[2] - S.xpos[dbody][2]};
+        const float off[3] = {com[0] - S.xpos[d_body][0], com[1] - S.xpos[d_body][1], com[2] - S.xpos[d_body][2]};
         cd[0] = ax[0]; cd[1] = ax[1]; cd[2] = ax[2];
         cross3(cd + 3, ax, off);
+        S.xaxis[lk][0] = ax[0]; S.xaxis[lk][1] = ax[1]; S.xaxis[lk][2] = ax[2];
       }
       for (int i = 0; i < 6; i++) S.cdof[lk][i] = cd[i];
       S.cdof[lk][6] = 0; S.cdof[lk][7] = 0;
     }
-    SYNC();
-    PROF(1);
-    // ---- composite inertia per body via the subtree mask, then rows of M (lane = dof)
-    if (lane >= 1 && lane < DMK_NB) {
-      float acc[10];
-      for (int i = 0; i < 10; i++) acc[i] = 0;
-      for (int c = 1; c < DMK_NB; c++)
-        if ((bsub >> c) & 1u)
-          for (int i = 0; i < 10; i++) acc[i] += S.cinert[c][i];
-      for (int i = 0; i < 10; i++) S.u.v.crb[lb][i] = acc[i];
-    }
-    SYNC();
-    if (lane < DMK_NV) {
-      float buf[6], cd[6], I[10];
-      for (int i = 0; i < 10; i++) I[i] = S.u.v.crb[dbody][i];
-      for (int i = 0; i < 6; i++) cd[i] = S.cdof[lk][i];
-      mul_inert_vec(buf, I, cd);
-      int j = lk;
-      for (int a = 0; a <= dnanc; a++) {
-        if (a > 0) j = T.d_anc[lk][a - 1];
+  }
+  PROF2(14);
+  // ---- cinert (lane = body)
+  if (isbody) {
+    float R[9], Tm[9], W[6], bi[6];
+    for (int i = 0; i < 9; i++) R[i] = S.xmat[lb][i];
+    for (int i = 0; i < 6; i++) bi[i] = T.b_inertia[lb][i];
+    const float Ib[9] = {bi[0], bi[3], bi[4], bi[3], bi[1], bi[5], bi[4], bi[5], bi[2]};
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) Tm[3 * i + j] = R[3 * i] * Ib[j] + R[3 * i + 1] * Ib[3 + j] + R[3 * i + 2] * Ib[6 + j];
+    W[0] = Tm[0] * R[0] + Tm[1] * R[1] + Tm[2] * R[2];
+    W[1] = Tm[3] * R[3] + Tm[4] * R[4] + Tm[5] * R[5];
+    W[2] = Tm[6] * R[6] + Tm[7] * R[7] + Tm[8] * R[8];
+    W[3] = Tm[0] * R[3] + Tm[1] * R[4] + Tm[2] * R[5];
+    W[4] = Tm[0] * R[6] + Tm[1] * R[7] + Tm[2] * R[8];
+    W[5] = Tm[3] * R[6] + Tm[4] * R[7] + Tm[5] * R[8];
+    const float o[3] = {S.xipos[lb][0] - com[0], S.xipos[lb][1] - com[1], S.xipos[lb][2] - com[2]};
+    const float oo = dot3(o, o);
+    float *ci = S.cinert[lb];
+    ci[0] = W[0] + bmass * (oo - o[0] * o[0]);
+    ci[1] = W[1] + bmass * (oo - o[1] * o[1]);
+    ci[2] = W[2] + bmass * (oo - o[2] * o[2]);
+    ci[3] = W[3] - bmass * o[0] * o[1];
+    ci[4] = W[4] - bmass * o[0] * o[2];
+    ci[5] = W[5] - bmass * o[1] * o[2];
+    ci[6] = bmass * o[0]; ci[7] = bmass * o[1]; ci[8] = bmass * o[2];
+    ci[9] = bmass;
+  }
+  SYNC();
+  PROF(1);
+  // ---- composite inertia per body via the subtree mask (lane = body)
+  if (isbody) {
+    float acc[10];
+    for (int i = 0; i < 10; i++) acc[i] = 0;
+    for (int c = 1; c < DMK_NB; c++)
+      if ((b_sub >> c) & 1u)
+        for (int i = 0; i < 10; i++) acc[i] += S.cinert[c][i];
+    for (int i = 0; i < 10; i++) S.u.v.crb[lb][i] = acc[i];
+  }
+  SYNC();
+  // ---- row i of M in the registers of lane i, indexed by the ABSOLUTE depth of the ancestor:
+  // Mr[d] = M[i][ancestor of i at depth d] (d < depth_i), Md = M[i][i]
+  float Mr[DMK_MAXANC], Md = 1.f;
+  for (int d = 0; d < DMK_MAXANC; d++) Mr[d] = 0.f;
+  if (isdof) {
+    float buf[6], cd[6], I[10];
+    for (int i = 0; i < 10; i++) I[i] = S.u.v.crb[d_body][i];
+    for (int i = 0; i < 6; i++) cd[i] = S.cdof[lk][i];
+    mul_inert_vec(buf, I, cd);
+    Md = T.d_arm[lk];
+    for (int i = 0; i < 6; i++) Md += cd[i] * buf[i];
+#pragma unroll
+    for (int d = 0; d < DMK_MAXANC; d++) {
+      const int j = T.d_ancabs[lk][d];
+      if (d < d_nanc) {
         float v = 0;
         for (int i = 0; i < 6; i++) v += S.cdof[j][i] * buf[i];
-        if (a == 0) v += darm;
-        S.M[lk * DMK_MSTRIDE + j] = v;
+        Mr[d] = v;
       }
     }
-    SYNC();
-    PROF(2);
-    // ---- L^T D L factorisation in place, rows left UNSCALED (L[i][j] = M[i][j] * dinv[i] is applied by
-    // the users).  One dof per step; its ancestor pairs (a <= b) are spread over the lanes; the ancestor
-    // indices of the NEXT step are fetched while this step's update is in flight.
-    {
-      const int ta0 = T.tri_a[lane], tb0 = T.tri_b[lane];
-      const int ta1 = T.tri_a[(lane + 64 < 80) ? lane + 64 : 79], tb1 = T.tri_b[(lane + 64 < 80) ? lane + 64 : 79];
-      int kk = DMK_NV - 1;
-      int n = T.d_nanc[kk];
-      int i0 = T.d_anc[kk][ta0], j0 = T.d_anc[kk][tb0], i1 = T.d_anc[kk][ta1], j1 = T.d_anc[kk][tb1];
-      for (; kk >= 1; kk--) {
-        const int kn = (kk > 1) ? kk - 1 : 1;
-        const int nn = T.d_nanc[kn];
-        const int ni0 = T.d_anc[kn][ta0], nj0 = T.d_anc[kn][tb0], ni1 = T.d_anc[kn][ta1], nj1 = T.d_anc[kn][tb1];
-        const int npair = n * (n + 1) / 2;
-        const float rk = __builtin_amdgcn_rcpf(S.M[kk * (DMK_MSTRIDE + 1)]);
-        if (lane < npair)
-          S.M[i0 * DMK_MSTRIDE + j0] -= S.M[kk * DMK_MSTRIDE + j0] * S.M[kk * DMK_MSTRIDE + i0] * rk;
-        if (lane + 64 < npair)
-          S.M[i1 * DMK_MSTRIDE + j1] -= S.M[kk * DMK_MSTRIDE + j1] * S.M[kk * DMK_MSTRIDE + i1] * rk;
-        SYNC();
-        n = nn; i0 = ni0; j0 = nj0; i1 = ni1; j1 = nj1;
-      }
-    }
-    float dv = 0.f;  // 1 / D[lane]
-    if (lane < DMK_NV) {
-      const float dd = S.M[lk * (DMK_MSTRIDE + 1)];
-      dv = 1.0f / dd;
-      S.dinv[lk] = dv;
-      S.dsqrtinv[lk] = 1.0f / sqrtf(dd);
-    }
-    PROF(3);
-    if (lane == 0) {
-      for (int i = 0; i < 3; i++) { S.u.v.cacc[0][i] = 0; S.u.v.cacc[0][3 + i] = -T.gravity[i]; }
-    }
-    SYNC();
-    // ---- velocity stage: cvel, cdof_dot, cacc, cfrc (lane = body, level by level)
-    for (int lev = 1; lev <= 4; lev++) {
-      if (bdep == lev) {
-        float cv[6], ca[6];
-        for (int i = 0; i < 6; i++) { cv[i] = S.cvel[bp][i]; ca[i] = S.u.v.cacc[bp][i]; }
-        if (lev == 1) {
-          for (int k = 0; k < 3; k++) {
-            float qv = S.qvel[k];
-            for (int i = 0; i < 6; i++) { S.u.v.cdofdot[k][i] = 0; cv[i] += S.cdof[k][i] * qv; }
-          }
-          float dd[3][6];
-          for (int k = 3; k < 6; k++) {
-            float cd[6];
-            for (int i = 0; i < 6; i++) cd[i] = S.cdof[k][i];
-            cross_motion(dd[k - 3], cv, cd);
-          }
-          for (int k = 3; k < 6; k++) {
-            float qv = S.qvel[k];
-            for (int i = 0; i < 6; i++) {
-              S.u.v.cdofdot[k][i] = dd[k - 3][i];
-              ca[i] += dd[k - 3][i] * qv;
-            }
-          }
-          for (int k = 3; k < 6; k++) {
-            float qv = S.qvel[k];
-            for (int i = 0; i < 6; i++) cv[i] += S.cdof[k][i] * qv;
-          }
-        } else {
+  }
+  PROF(2);
+  // ---- L^T D L in registers: eliminate dof k = 33..1; its row is broadcast with v_readlane, every
+  // ancestor lane i applies M[i][j] -= M[k][j] M[k][i] / M[k][k].  Slots d >= depth_i of a lane hold
+  // values that are never read, so the update needs no per-slot predicate.
+  {
+    const uint64_t desc = T.d_desc[lk];   // bit k: dof k is a strict descendant of this lane's dof
+    const bool b0 = d_nanc & 1, b1 = d_nanc & 2, b2 = d_nanc & 4, b3 = d_nanc & 8;
+#pragma unroll 1
+    for (int kk = DMK_NV - 1; kk >= 1; kk--) {
+      const float rk = __builtin_amdgcn_rcpf(rl(Md, kk));
+      float val[DMK_MAXANC];   // row kk; slots beyond its depth hold finite never-read values, no predicate needed
 #pragma unroll
-          for (int j = 0; j < 3; j++) {
-            if (j < bdofnum) {
-              int k = bdofadr + j;
-              float cd[6], dd[6], qv = S.qvel[k];
-              for (int i = 0; i < 6; i++) cd[i] = S.cdof[k][i];
-              cross_motion(dd, cv, cd);
-              for (int i = 0; i < 6; i++) {
-                S.u.v.cdofdot[k][i] = dd[i];
-                ca[i] += dd[i] * qv;
-                cv[i] += cd[i] * qv;
-              }
-            }
-          }
+      for (int d = 0; d < DMK_MAXANC; d++) val[d] = rl(Mr[d], kk);
+      // M[kk][this lane's dof] = val[depth of this lane]: 4-level select tree on the bits of the depth
+      const float s01 = b0 ? val[1] : val[0], s23 = b0 ? val[3] : val[2], s45 = b0 ? val[5] : val[4];
+      const float s67 = b0 ? val[7] : val[6], s89 = b0 ? val[9] : val[8], sab = b0 ? val[11] : val[10];
+      const float t0 = b1 ? s23 : s01, t1 = b1 ? s67 : s45, t2 = b1 ? sab : s89;
+      const float mki = b3 ? t2 : (b2 ? t1 : t0);
+      const float t = (isdof && ((desc >> kk) & 1ull)) ? mki * rk : 0.f;
+#pragma unroll
+      for (int d = 0; d < DMK_MAXANC; d++) Mr[d] = fmaf(-val[d], t, Mr[d]);
+      Md = fmaf(-mki, t, Md);
+    }
+  }
+  // publish the factor (rows UNSCALED: L[i][j] = M[i][j] * dinv[i] is applied by the users)
+  float dv = 0.f;
+  if (isdof) {
+    dv = 1.0f / Md;
+    S.dinv[lk] = dv;
+    S.dsqrtinv[lk] = 1.0f / sqrtf(Md);
+    S.M[lk * (DMK_MSTRIDE + 1)] = Md;
+#pragma unroll
+    for (int d = 0; d < DMK_MAXANC; d++)
+      if (d < d_nanc) {
+        const int j = T.d_ancabs[lk][d];
+        S.M[lk * DMK_MSTRIDE + j] = Mr[d];
+      }
+  }
+  PROF(3);
+  // ---- velocity stage, lane-parallel.  Pass A (lane = body): w_b = sum over the body's dofs of cdof * qvel
+  if (isbody) {
+    float w[6] = {0, 0, 0, 0, 0, 0};
+    const int nd = (lb == 1) ? 6 : b_dofnum;
+    for (int j = 0; j < 6; j++)
+      if (j < nd) {
+        const int k = b_dofadr + j;
+        const float qv = S.qvel[k];
+        for (int i = 0; i < 6; i++) w[i] += S.cdof[k][i] * qv;
+      }
+    for (int i = 0; i < 6; i++) S.u.v.cacc[lb][i] = w[i];       // (scratch: w_b)
+  }
+  SYNC();
+  // Pass B (lane = body): velocity of the parent, then the body's dofs in order: cdof_dot, u_b = sum cdof_dot * qvel
+  if (isbody) {
+    float cv[6] = {0, 0, 0, 0, 0, 0}, u[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {       // ancestors only (the chain has at most 3 proper ancestors)
+      const int cb = (b_chain4 >> (8 * c)) & 0xFF;
+      if (cb != 0 && cb != lb)
+        for (int i = 0; i < 6; i++) cv[i] += S.u.v.cacc[cb][i];
+    }
+    if (lb == 1) {
+      for (int k = 0; k < 3; k++) {
+        const float qv = S.qvel[k];
+        for (int i = 0; i < 6; i++) { S.u.v.cdofdot[k][i] = 0; cv[i] += S.cdof[k][i] * qv; }
+      }
+      float dd[3][6];
+#pragma unroll
+      for (int k = 3; k < 6; k++) {
+        float cd[6];
+        for (int i = 0; i < 6; i++) cd[i] = S.cdof[k][i];
+        cross_motion(dd[k - 3], cv, cd);
+      }
+#pragma unroll
+      for (int k = 3; k < 6; k++) {
+        const float qv = S.qvel[k];
+        for (int i = 0; i < 6; i++) { S.u.v.cdofdot[k][i] = dd[k - 3][i]; u[i] += dd[k - 3][i] * qv; cv[i] += S.cdof[k][i] * qv; }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        if (j < b_dofnum) {
+          const int k = b_dofadr + j;
+          float cd[6], dd[6];
+          const float qv = S.qvel[k];
+          for (int i = 0; i < 6; i++) cd[i] = S.cdof[k][i];
+          cross_motion(dd, cv, cd);
+          for (int i = 0; i < 6; i++) { S.u.v.cdofdot[k][i] = dd[i]; u[i] += dd[i] * qv; cv[i] += cd[i] * qv; }
         }
-        float I[10], f0[6], t0[6], t1[6];
-        for (int i = 0; i < 10; i++) I[i] = S.cinert[lb][i];
-        mul_inert_vec(f0, I, ca);
-        mul_inert_vec(t0, I, cv);
-        cross_force(t1, cv, t0);
-        for (int i = 0; i < 6; i++) {
-          S.cvel[lb][i] = cv[i];
-          S.u.v.cacc[lb][i] = ca[i];
-          S.u.v.cfrc[lb][i] = f0[i] + t1[i];
-        }
       }
-      SYNC();
     }
-    if (lane >= 1 && lane < DMK_NB) {
-      float acc[6] = {0, 0, 0, 0, 0, 0};
-      for (int c = 1; c < DMK_NB; c++)
-        if ((bsub >> c) & 1u)
-          for (int i = 0; i < 6; i++) acc[i] += S.u.v.cfrc[c][i];
-      for (int i = 0; i < 6; i++) S.u.v.cfrcsub[lb][i] = acc[i];
-    }
-    SYNC();
-    // ---- smooth forces and qacc_smooth = M^-1 (passive - bias + actuation)   (lane = dof)
-    float xs = 0;
-    if (lane < DMK_NV) {
-      float bias = 0;
-      for (int i = 0; i < 6; i++) bias += S.cdof[lk][i] * S.u.v.cfrcsub[dbody][i];
-      float act = 0;
-      if (dact >= 0) act = dgear * clampf(S.ctrl[dact], dclo, dchi);
-      xs = -ddamp * S.qvel[lk] - bias + act;
-    }
+    for (int i = 0; i < 6; i++) { S.cvel[lb][i] = cv[i]; S.u.v.cfrcsub[lb][i] = u[i]; }   // (scratch: u_b)
+  }
+  SYNC();
+  PROF2(15);
+  // Pass C (lane = body): cacc = -gravity + sum over the chain of u, cfrc = I cacc + cvel x* (I cvel)
+  if (isbody) {
+    float ca[6] = {0, 0, 0, -T.gravity[0], -T.gravity[1], -T.gravity[2]}, cv[6], I[10], f0[6], t0[6], t1[6];
 #pragma unroll
-    for (int i = DMK_NV - 1; i >= 1; i--) {   // x <- L^-T x  (L[i][j] = M[i][j] * dinv[i])
-      const float xi = rl(xs * dv, i);
-      const float l = S.M[i * DMK_MSTRIDE + lk];
-      if (lane < i) xs -= l * xi;
+    for (int c = 0; c < 4; c++) {
+      const int cb = (b_chain4 >> (8 * c)) & 0xFF;
+      if (cb != 0)
+        for (int i = 0; i < 6; i++) ca[i] += S.u.v.cfrcsub[cb][i];
     }
+    for (int i = 0; i < 6; i++) cv[i] = S.cvel[lb][i];
+    for (int i = 0; i < 10; i++) I[i] = S.cinert[lb][i];
+    mul_inert_vec(f0, I, ca);
+    mul_inert_vec(t0, I, cv);
+    cross_force(t1, cv, t0);
+    for (int i = 0; i < 6; i++) S.u.v.cfrc[lb][i] = f0[i] + t1[i];
+  }
+  SYNC();
+  // Pass D (lane = body): subtree sums of cfrc
+  if (isbody) {
+    float acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int c = 1; c < DMK_NB; c++)
+      if ((b_sub >> c) & 1u)
+        for (int i = 0; i < 6; i++) acc[i] += S.u.v.cfrc[c][i];
+    for (int i = 0; i < 6; i++) S.u.v.cacc[lb][i] = acc[i];      // (scratch reuse: subtree force)
+  }
+  SYNC();
+  PROF2(10);
+  // ---- smooth forces and qacc_smooth = M^-1 (passive - bias + actuation)   (lane = dof)
+  float xs = 0;
+  if (isdof) {
+    float bias = 0;
+    for (int i = 0; i < 6; i++) bias += S.cdof[lk][i] * S.u.v.cacc[d_body][i];
+    float act = 0;
+    const int da = T.d_act[lk];
+    if (da >= 0) act = T.d_gear[lk] * clampf(S.ctrl[da], T.d_clo[lk], T.d_chi[lk]);
+    xs = -T.d_damp[lk] * S.qvel[lk] - bias + act;
+  }
 #pragma unroll
-    for (int j = 0; j < DMK_NV - 1; j++) {    // z <- z - M[:, j] x_j with x = z * dinv  (D^-1 and L^-1 fused)
-      const float xj = rl(xs * dv, j);
-      const float l = S.M[lk * DMK_MSTRIDE + j];
-      if (lane > j && lane < DMK_NV) xs -= l * xj;
-    }
-    xs *= dv;
-    if (lane < DMK_NV) S.qacc_smooth[lk] = xs;
-    SYNC();
+  for (int i = DMK_NV - 1; i >= 1; i--) {   // x <- L^-T x  (L[i][j] = M[i][j] * dinv[i])
+    const float xi = rl(xs * dv, i);
+    const float l = S.M[i * DMK_MSTRIDE + lk];
+    if (lane < i) xs -= l * xi;
+  }
+#pragma unroll
+  for (int j = 0; j < DMK_NV - 1; j++) {    // z <- z - M[:, j] x_j with x = z * dinv  (D^-1 and L^-1 fused)
+    const float xj = rl(xs * dv, j);
+    const float l = S.M[lk * DMK_MSTRIDE + j];
+    if (lane > j && lane < DMK_NV) xs -= l * xj;
+  }
+  xs *= dv;
+  if (isdof) S.qacc_smooth[lk] = xs;
+  SYNC();
+  PROF(4);
+}
 
-    PROF(4);
+// ---- forward evaluation, part 2: collision detection -> contact list in LDS; returns ncon | overflow << 8
+__device__ __forceinline__ int fwd_collide(const DmDev &T, const int lane) {
+  EnvLds &S = g_S;
+  int ncon = 0, overflow = 0;
+  const int lb = lane < DMK_NB ? lane : 0;       // lane as body
+  const int lk = lane < DMK_NV ? lane : 0;       // lane as dof
+  const int lg = lane < DMK_NG ? lane : 0;       // lane as geom
+  const int bdep = (lane < DMK_NB) ? T.b_depth[lb] : -1;
+  const float bmass = (lane < DMK_NB) ? T.b_mass[lb] : 0.f;
+  const float mtot_inv = T.total_mass_inv;
+  (void)lg; (void)bdep; (void)bmass; (void)mtot_inv; (void)lb; (void)lk;
     // ---- collision: lane = candidate pair, two rounds in canonical order
     int base = 0;
     overflow = 0;
@@ -980,6 +970,24 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, 2) dm_step
     SYNC();
 
     PROF(5);
+  return ncon | (overflow << 8);
+}
+
+// ---- forward evaluation, part 3: constraint rows, A = J M^-1 J^T + R, PGS, qacc; returns qacc[lane]
+__device__ __forceinline__ float fwd_constraint(const DmDev &T, const int lane, const int ncon, int overflow, float *dbg_force) {
+  EnvLds &S = g_S;
+  int nefc = 0, nlimit = 0, solver_iter = 0;
+  const int lb = lane < DMK_NB ? lane : 0;       // lane as body
+  const int lk = lane < DMK_NV ? lane : 0;       // lane as dof
+  const int lg = lane < DMK_NG ? lane : 0;       // lane as geom
+  const int bdep = (lane < DMK_NB) ? T.b_depth[lb] : -1;
+  const float bmass = (lane < DMK_NB) ? T.b_mass[lb] : 0.f;
+  const float mtot_inv = T.total_mass_inv;
+  (void)lg; (void)bdep; (void)bmass; (void)mtot_inv; (void)lb; (void)lk;
+  const float xs = (lane < DMK_NV) ? S.qacc_smooth[lk] : 0.f;
+  const float dv = (lane < DMK_NV) ? S.dinv[lk] : 0.f;
+  const float com[3] = {S.com[0], S.com[1], S.com[2]};
+  float qacc_out;
     // ---- constraint rows: limits in joint order, then contacts in contact order
     {
       bool lim = false;
@@ -1175,13 +1183,132 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, 2) dm_step
         if (lane > j && lane < DMK_NV) v -= l * xj;
       }
       qacc_out = xs + v * dv;
-      if (P.debug && lane < DMK_MAXROW) P.debug[(size_t)env * DM_DEBUG_STRIDE + 352 + lane] = (lane < nefc) ? f : 0.f;
+#ifndef DM_PROFILE
+      if (dbg_force && lane < DMK_MAXROW) dbg_force[lane] = (lane < nefc) ? f : 0.f;
+#endif
     }
     SYNC();
     if (lane < DMK_NV) { S.qacc[lk] = qacc_out; S.warm[lk] = qacc_out; }
     SYNC();
-    if (it < 4) { stage_ncon |= (unsigned)(ncon & 0xFF) << (8 * it); stage_nefc |= (unsigned)(nefc & 0xFF) << (8 * it); }
     PROF(9);
+  if (lane == 0) { S.info[0] = ncon; S.info[1] = nefc; S.info[2] = nlimit; S.info[3] = solver_iter; S.info[4] = overflow; }
+  return qacc_out;
+}
+
+// ======================================================================================
+extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, 2) dm_step_kernel(DmLaunch P) {
+  // Model tables are read from global memory at their use sites: 6 KB shared by every wave on the CU,
+  // so they sit in the vector L1 / scalar cache; keeping them out of LDS leaves room for more envs.
+  const DmDev &T = *P.T;
+  const int lane = threadIdx.x & 63;
+  EnvLds &S = g_S;
+  const int slot = blockIdx.x;
+  if (slot >= P.nslots) return;
+  const int env = P.env_ids ? P.env_ids[slot] : slot;
+  if (env < 0 || env >= P.N) return;
+  const int mode = P.mode;
+  if (mode == DMK_MODE_RESET && P.mask && !P.mask[env]) return;
+  float *st = P.state + (size_t)env * DMK_STATE_STRIDE;
+  int *sti = reinterpret_cast<int *>(st);
+
+  // ---------------------------------------------------------------- lane roles (values are read
+  // from the LDS-resident table at their use sites so they do not pin registers)
+  const int lb = lane < DMK_NB ? lane : 0;       // lane as body
+  const int lk = lane < DMK_NV ? lane : 0;       // lane as dof
+  const int lg = lane < DMK_NG ? lane : 0;       // lane as geom
+  const int bdep = (lane < DMK_NB) ? T.b_depth[lb] : -1;
+  const float bmass = (lane < DMK_NB) ? T.b_mass[lb] : 0.f;
+  const float h = T.timestep;
+  const float mtot_inv = T.total_mass_inv;
+
+  PROF_DECL;
+  // ---------------------------------------------------------------- LDS init
+  for (int i = lane; i < DMK_NV * DMK_MSTRIDE; i += 64) S.M[i] = 0.f;
+  if (lane == 0) {
+    S.xpos[0][0] = S.xpos[0][1] = S.xpos[0][2] = 0;
+    S.xquat[0][0] = 1; S.xquat[0][1] = S.xquat[0][2] = S.xquat[0][3] = 0;
+    for (int i = 0; i < 9; i++) S.xmat[0][i] = (i % 4 == 0) ? 1.f : 0.f;
+    S.xipos[0][0] = S.xipos[0][1] = S.xipos[0][2] = 0;
+    for (int i = 0; i < 6; i++) S.cvel[0][i] = 0;
+    for (int i = 0; i < 10; i++) S.cinert[0][i] = 0;
+  }
+
+  // ---------------------------------------------------------------- load state
+  const int clip_id = sti[DMS_CLIP];
+  const DmClipDev clip = P.clips[(clip_id >= 0 && clip_id < 8) ? clip_id : 0];
+  if (clip.L < 1 || clip.rows == nullptr) return;  // no clip loaded for this env's clip id
+  int idx_curr = sti[DMS_IDX], ep_len = sti[DMS_EPLEN], rcnt = sti[DMS_RCNT];
+  idx_curr = idx_curr < 0 ? 0 : (idx_curr >= clip.L ? clip.L - 1 : idx_curr);
+  float ep_rew = st[DMS_EPREW];
+  if (lane < DMK_NQ) S.qpos[lane] = st[DMS_QPOS + lane];
+  if (lane < DMK_NV) { S.qvel[lane] = st[DMS_QVEL + lane]; S.warm[lane] = st[DMS_WARM + lane]; }
+  if (lane < DMK_NU) S.ctrl[lane] = st[DMS_CTRL + lane];
+  SYNC();
+  if (mode == DMK_MODE_STEP) {
+    if (lane < DMK_NU) S.ctrl[lane] = P.actions[(size_t)env * DMK_NU + lane];  // ctrl = action * 1.0 (:347)
+  } else if (mode == DMK_MODE_FORCED || mode == DMK_MODE_SETSTATE) {
+    if (lane < DMK_NQ) S.qpos[lane] = P.in_qpos[(size_t)slot * DMK_NQ + lane];
+    if (lane < DMK_NV) S.qvel[lane] = P.in_qvel[(size_t)slot * DMK_NV + lane];
+    if (mode == DMK_MODE_SETSTATE) {
+      if (P.in_warm && lane < DMK_NV) S.warm[lane] = P.in_warm[(size_t)slot * DMK_NV + lane];
+      if (P.in_ctrl && lane < DMK_NU) S.ctrl[lane] = P.in_ctrl[(size_t)slot * DMK_NU + lane];
+    }
+  } else if (mode == DMK_MODE_RESET) {
+    int fi = P.idx_init ? P.idx_init[env] : (int)(dm_hash32(P.seed, env, rcnt, 0x5EED) % (uint32_t)clip.L);
+    fi = fi < 0 ? 0 : (fi >= clip.L ? clip.L - 1 : fi);
+    const float *rr = clip.reset + (size_t)fi * DMK_RESET_ROW;
+    if (lane < DMK_NQ) S.qpos[lane] = rr[lane];
+    if (lane < DMK_NV) S.qvel[lane] = rr[35 + lane];
+    idx_curr = fi; ep_len = 0; ep_rew = 0; rcnt++;
+  }
+  SYNC();
+
+  // RK4 bookkeeping, lane = dof (k<3 root translation, 3..5 root rotation, >=6 hinges)
+  float x0q = 0, x0v = 0, accq = 0, accv = 0, curv = 0;
+  float q0[4] = {1, 0, 0, 0};
+  int it = (mode == DMK_MODE_STEP) ? 0 : 4;
+  bool after_reset = false, done = false, sim_err = false;
+  int reason = DM_REASON_NONE;
+  float reward = 0;
+  int ncon = 0, nefc = 0, nlimit = 0, solver_iter = 0, overflow = 0;
+  float com[3] = {0, 0, 0};
+  unsigned stage_ncon = 0, stage_nefc = 0;  // byte i = count at RK stage i (debug)
+
+  if (mode == DMK_MODE_SETSTATE && !P.run_forward) {  // store only
+    if (lane < DMK_NQ) st[DMS_QPOS + lane] = S.qpos[lane];
+    if (lane < DMK_NV) { st[DMS_QVEL + lane] = S.qvel[lane]; st[DMS_WARM + lane] = S.warm[lane]; }
+    if (lane < DMK_NU) st[DMS_CTRL + lane] = S.ctrl[lane];
+    return;
+  }
+  if (mode == DMK_MODE_STEP || mode == DMK_MODE_FORCED) {  // mj_checkPos / mj_checkVel
+    float a = (lane < DMK_NQ) ? S.qpos[lane] : 0.f, b = (lane < DMK_NV) ? S.qvel[lk] : 0.f;
+    sim_err = __any(!(fabsf(a) <= MAXVALF) || !(fabsf(b) <= MAXVALF));
+  }
+
+  PROF(0);
+  for (;;) {
+   float qacc_out = 0;
+   if (!sim_err) {
+    // ============================================================== forward evaluation
+    // launder the table pointer once per stage: keeps hipcc from hoisting table loads out of the
+    // stage loop into registers that would then live (and spill) across the whole kernel
+    const DmDev *Tp = P.T;
+    asm volatile("" : "+s"(Tp));
+    const DmDev &Ts = *Tp;
+    fwd_smooth(Ts, lane);
+    if (it == 0) {  // capture X0 (after normalisation)
+      x0v = (lane < DMK_NV) ? S.qvel[lk] : 0.f;
+      x0q = (lane < 3) ? S.qpos[lane] : ((lane >= 6 && lane < DMK_NV) ? S.qpos[lane + 1] : 0.f);
+      for (int i = 0; i < 4; i++) q0[i] = S.qpos[3 + i];
+      curv = x0v;
+    }
+    {
+      const int cr = fwd_collide(Ts, lane);
+      ncon = cr & 0xFF;
+      qacc_out = fwd_constraint(Ts, lane, ncon, cr >> 8, P.debug ? P.debug + (size_t)env * DM_DEBUG_STRIDE + 352 : nullptr);
+      nefc = S.info[1]; nlimit = S.info[2]; solver_iter = S.info[3]; overflow = S.info[4];
+      if (it < 4) { stage_ncon |= (unsigned)(ncon & 0xFF) << (8 * it); stage_nefc |= (unsigned)(nefc & 0xFF) << (8 * it); }
+    }
     // ============================================================== end of forward evaluation
     if (it == 0 || (it == 4 && mode == DMK_MODE_FORCED && !after_reset)) {  // mj_checkAcc
       bool badv = (lane < DMK_NV) && !(fabsf(qacc_out) <= MAXVALF);
@@ -1381,9 +1508,9 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, 2) dm_step
 
   PROF(11);
 #ifdef DM_PROFILE
-  if (P.debug && lane < 12) { unsigned v = 0;
+  if (P.debug && lane < 16) { unsigned v = 0;
 #pragma unroll
-    for (int i = 0; i < 12; i++) if (lane == i) v = prof_acc[i];
+    for (int i = 0; i < 16; i++) if (lane == i) v = g_S.prof[i];
     P.debug[(size_t)env * DM_DEBUG_STRIDE + 352 + lane] = (float)v; }
 #endif
   // ---------------------------------------------------------------- state write-back
