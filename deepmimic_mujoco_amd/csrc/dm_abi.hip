@@ -3,6 +3,7 @@
 // the clip tables, and launches the fused step kernel (dm_kernels.hip).
 #include "../../include/deepmimic_hip.h"
 #include "dm_device.h"
+#include "dm_topology.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -116,6 +117,8 @@ static void build_tables(const DmModel &m, DmDev &T) {
   for (int k = 0; k < DM_NV; k++) {
     for (int a = 0; a < T.d_nanc[k]; a++) T.d_desc[T.d_anc[k][a]] |= 1ull << k;
     T.nanc_pack[k >> 4] |= (uint64_t)T.d_nanc[k] << (4 * (k & 15));
+    for (int a = 0; a < T.d_nanc[k]; a++) T.d_ancm[k] |= 1ull << T.d_anc[k][a];
+    T.d_madr[k] = m.dof_Madr[k];
   }
   for (int a = 0; a < DM_NU; a++) {
     int k = m.act_dof[a];
@@ -135,6 +138,15 @@ static void build_tables(const DmModel &m, DmDev &T) {
     T.g_mu[g] = (float)m.geom_friction[g][0];
   }
   for (int p = 0; p < DM_MAXPAIR; p++) { T.p_g1[p] = (int16_t)m.pair_geom1[p]; T.p_g2[p] = (int16_t)m.pair_geom2[p]; }
+  for (int p = 0; p < m.npair; p++) {
+    int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
+    DmPairDev &pr = T.pairs[p];
+    pr.g1 = (int16_t)g1; pr.g2 = (int16_t)g2;
+    pr.t1 = (int8_t)m.geom_type[g1]; pr.t2 = (int8_t)m.geom_type[g2];
+    pr.margin = (float)fmax(m.geom_margin[g1], m.geom_margin[g2]);
+    pr.rbsum = (float)((m.geom_type[g1] == DM_GEOM_PLANE ? 0.0 : m.geom_rbound[g1]) + m.geom_rbound[g2]);
+    for (int i = 0; i < 3; i++) { pr.z1[i] = (float)m.geom_size[g1][i]; pr.z2[i] = (float)m.geom_size[g2][i]; }
+  }
   int p = 0;
   for (int b = 0; b < DMK_MAXANC; b++)
     for (int a = 0; a <= b; a++) { T.tri_a[p] = (uint8_t)a; T.tri_b[p] = (uint8_t)b; p++; }
@@ -155,6 +167,9 @@ static int check_model(DmEngine *e, const DmModel &m) {
     for (int i = 0; i < 3; i++)
       if (m.jnt_pos[j][i] != 0.0) return fail(e, DM_EINVAL, "kernels assume joint anchors at the body origin");
   if (m.jnt_type[0] != DM_JNT_FREE || m.jnt_body[0] != 1) return fail(e, DM_EINVAL, "joint 0 must be the free root");
+  for (int k = 0; k < DM_NV; k++)
+    if (m.dof_parent[k] != topo::PARENT[k] || m.dof_Madr[k] != topo::MADR[k])
+      return fail(e, DM_EINVAL, "dof tree differs from the compiled-in topology (regenerate csrc/dm_topology.h)");
   return DM_OK;
 }
 

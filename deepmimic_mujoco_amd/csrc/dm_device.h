@@ -26,6 +26,14 @@
 #define DMK_STATE_STRIDE 144   // floats per env in the HBM state row (see DmState)
 #define DMK_CLIP_ROW 80        // floats per clip frame row (73 used)
 
+// One collision candidate: everything the prefilter and the narrowphase need except the poses.
+struct DmPairDev {
+  int16_t g1, g2;
+  int8_t t1, t2, pad0, pad1;
+  float margin, rbsum;   // max of the two margins; sum of the bounding radii (plane: radius of geom 2)
+  float z1[3], z2[3];    // geom sizes
+};
+
 // Global-memory (read-only) model tables, fp32.  Built on the host from DmModel.
 struct DmDev {
   // scalars
@@ -53,11 +61,14 @@ struct DmDev {
   uint64_t d_desc[DM_NV];       // bit k: dof k is a strict descendant
   int32_t d_pbody[DM_NV];       // parent body of the dof's body
   uint64_t nanc_pack[3];        // d_nanc of every dof, 4 bits each
+  uint64_t d_ancm[DM_NV];       // bit j: dof j is a strict ancestor
+  int32_t d_madr[DM_NV];        // start of row i in the sparse factor
   // geoms
   int32_t g_body[16], g_type[16], g_condim[16];
   float g_pos[16][3], g_mat[16][9], g_size[16][3], g_rbound[16], g_margin[16], g_mu[16];
   // candidate pairs (canonical order)
   int16_t p_g1[DM_MAXPAIR], p_g2[DM_MAXPAIR];
+  DmPairDev pairs[DM_MAXPAIR];
   uint8_t tri_a[80], tri_b[80]; // lower-triangle pair decode for the factorisation
 };
 
@@ -73,7 +84,7 @@ struct EnvLds {
   float cinert[DMK_NB][10];
   float cdof[DMK_NV][8];              // ang3, lin3, pad2 (16-byte rows)
   float cvel[DMK_NB][6];
-  float M[DMK_NV * DMK_MSTRIDE];
+  float M[DM_NM + 2];                 // sparse L^T D L factor, MuJoCo row layout (dm_topology.h)
   float dinv[36], dsqrtinv[36];
   // contacts of the current forward evaluation
   float c_dist[DMK_MAXCON], c_pos[DMK_MAXCON][3], c_frame[DMK_MAXCON][9];

@@ -13,6 +13,7 @@
 // (oracle/dm_oracle.c) is an independent scalar implementation of the same spec.
 #include "../../include/deepmimic_hip.h"
 #include "dm_device.h"
+#include "dm_topology.h"
 
 #include <math.h>
 
@@ -256,25 +257,31 @@ __device__ __noinline__ void np_box_box(EnvLds &S, float margin, const float *p1
   S.u.bb.ncand = 0;
   float R[9], AR[9], t[3], tw[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
   mat_t_vec(t, R1, tw);
+#pragma unroll
   for (int i = 0; i < 3; i++)
+#pragma unroll
     for (int j = 0; j < 3; j++) {
       R[3 * i + j] = R1[i] * R2[j] + R1[3 + i] * R2[3 + j] + R1[6 + i] * R2[6 + j];
       AR[3 * i + j] = fabsf(R[3 * i + j]) + 1e-9f;
     }
   float best = -1e30f, bn[3] = {0, 0, 0};
   int code = -1;
+#pragma unroll
   for (int i = 0; i < 3; i++) {
     float s = fabsf(t[i]) - (s1[i] + s2[0] * AR[3 * i] + s2[1] * AR[3 * i + 1] + s2[2] * AR[3 * i + 2]);
     if (s > margin) return;
     if (s > best) { best = s; code = i; }
   }
+#pragma unroll
   for (int j = 0; j < 3; j++) {
     float tj = t[0] * R[j] + t[1] * R[3 + j] + t[2] * R[6 + j];
     float s = fabsf(tj) - (s2[j] + s1[0] * AR[j] + s1[1] * AR[3 + j] + s1[2] * AR[6 + j]);
     if (s > margin) return;
     if (s > best) { best = s; code = 3 + j; }
   }
+#pragma unroll
   for (int i = 0; i < 3; i++)
+#pragma unroll
     for (int j = 0; j < 3; j++) {
       float ei[3] = {0, 0, 0}, ej[3] = {R[j], R[3 + j], R[6 + j]}, ax[3];
       ei[i] = 1;
@@ -283,6 +290,7 @@ __device__ __noinline__ void np_box_box(EnvLds &S, float margin, const float *p1
       if (l < 1e-6f) continue;
       ax[0] /= l; ax[1] /= l; ax[2] /= l;
       float ra = s1[0] * fabsf(ax[0]) + s1[1] * fabsf(ax[1]) + s1[2] * fabsf(ax[2]), rb = 0;
+#pragma unroll
       for (int k = 0; k < 3; k++) {
         float ek[3] = {R[k], R[3 + k], R[6 + k]};
         rb += s2[k] * fabsf(dot3(ax, ek));
@@ -399,6 +407,7 @@ __device__ __forceinline__ float impedance(const float *solimp, float pos, float
   if (x <= 0) return dmin;
   float y;
   if (power == 1) y = x;
+  else if (power == 2) y = (x <= mid) ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);   // MuJoCo default
   else if (x <= mid) y = powf(x, power) / powf(mid, power - 1);
   else y = 1 - powf(1 - x, power) / powf(1 - mid, power - 1);
   return dmin + y * (dmax - dmin);
@@ -639,20 +648,21 @@ __device__ __forceinline__ void fwd_smooth(const DmDev &T, const int lane) {
       Md = fmaf(-mki, t, Md);
     }
   }
-  // publish the factor (rows UNSCALED: L[i][j] = M[i][j] * dinv[i] is applied by the users)
+  // publish the factor in the sparse MuJoCo layout (row i: M(i,i), M(i,parent), ...), rows UNSCALED:
+  // L[i][j] = M[i][j] * dinv[i] is applied by the users
   float dv = 0.f;
+  const int mrow = T.d_madr[lk] + d_nanc;          // S.M[mrow - depth(j)] = M[lane][j]
+  const uint64_t ancm = T.d_ancm[lk];              // bit j: dof j is a strict ancestor of this lane's dof
   if (isdof) {
     dv = 1.0f / Md;
     S.dinv[lk] = dv;
     S.dsqrtinv[lk] = 1.0f / sqrtf(Md);
-    S.M[lk * (DMK_MSTRIDE + 1)] = Md;
+    S.M[mrow - d_nanc] = Md;
 #pragma unroll
     for (int d = 0; d < DMK_MAXANC; d++)
-      if (d < d_nanc) {
-        const int j = T.d_ancabs[lk][d];
-        S.M[lk * DMK_MSTRIDE + j] = Mr[d];
-      }
+      if (d < d_nanc) S.M[mrow - d] = Mr[d];
   }
+  SYNC();
   PROF(3);
   // ---- velocity stage, lane-parallel.  Pass A (lane = body): w_b = sum over the body's dofs of cdof * qvel
   if (isbody) {
@@ -747,17 +757,22 @@ __device__ __forceinline__ void fwd_smooth(const DmDev &T, const int lane) {
     if (da >= 0) act = T.d_gear[lk] * clampf(S.ctrl[da], T.d_clo[lk], T.d_chi[lk]);
     xs = -T.d_damp[lk] * S.qvel[lk] - bias + act;
   }
+  {
+    const uint64_t descm = T.d_desc[lk];
 #pragma unroll
-  for (int i = DMK_NV - 1; i >= 1; i--) {   // x <- L^-T x  (L[i][j] = M[i][j] * dinv[i])
-    const float xi = rl(xs * dv, i);
-    const float l = S.M[i * DMK_MSTRIDE + lk];
-    if (lane < i) xs -= l * xi;
-  }
+    for (int i = DMK_NV - 1; i >= 1; i--) {   // x <- L^-T x  (L[i][j] = M[i][j] * dinv[i])
+      const float xi = rl(xs * dv, i);
+      const bool isa = (descm >> i) & 1ull;    // this lane's dof is an ancestor of i
+      const float l = S.M[isa ? topo::MADR[i] + topo::NANC[i] - d_nanc : 0];
+      if (isa) xs -= l * xi;
+    }
 #pragma unroll
-  for (int j = 0; j < DMK_NV - 1; j++) {    // z <- z - M[:, j] x_j with x = z * dinv  (D^-1 and L^-1 fused)
-    const float xj = rl(xs * dv, j);
-    const float l = S.M[lk * DMK_MSTRIDE + j];
-    if (lane > j && lane < DMK_NV) xs -= l * xj;
+    for (int j = 0; j < DMK_NV - 1; j++) {    // z <- z - M[:, j] x_j with x = z * dinv  (D^-1 and L^-1 fused)
+      const float xj = rl(xs * dv, j);
+      const bool isd = (ancm >> j) & 1ull;     // j is an ancestor of this lane's dof
+      const float l = S.M[isd ? mrow - topo::NANC[j] : 0];
+      if (isd) xs -= l * xj;
+    }
   }
   xs *= dv;
   if (isdof) S.qacc_smooth[lk] = xs;
@@ -788,21 +803,27 @@ __device__ __forceinline__ int fwd_collide(const DmDev &T, const int lane) {
       int g1 = 0, g2 = 0;
       bool isbb = false;
       float margin = 0;
+      // per-pair constants come as one contiguous 12-word record (host-precomputed)
+      bool act = false;
+      int t1 = 0, t2 = 0;
+      float x1[3], x2[3], z1[3], z2[3];
       if (p < T.npair) {
-        g1 = T.p_g1[p]; g2 = T.p_g2[p];
-        const int t1 = T.g_type[g1], t2 = T.g_type[g2];
-        margin = fmaxf(T.g_margin[g1], T.g_margin[g2]);
-        float x1[3], x2[3], M1[9], M2[9], z1[3], z2[3];
-        for (int i = 0; i < 3; i++) { x1[i] = S.gpos[g1][i]; x2[i] = S.gpos[g2][i]; z1[i] = T.g_size[g1][i]; z2[i] = T.g_size[g2][i]; }
-        for (int i = 0; i < 9; i++) { M1[i] = S.gmat[g1][i]; M2[i] = S.gmat[g2][i]; }
-        bool act;
+        const DmPairDev pr = T.pairs[p];
+        g1 = pr.g1; g2 = pr.g2; t1 = pr.t1; t2 = pr.t2;
+        margin = pr.margin;
+        for (int i = 0; i < 3; i++) { x1[i] = S.gpos[g1][i]; x2[i] = S.gpos[g2][i]; z1[i] = pr.z1[i]; z2[i] = pr.z2[i]; }
+        const float df[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
         if (t1 == DM_GEOM_PLANE) {
-          float pn[3] = {M1[2], M1[5], M1[8]}, df[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
-          act = dot3(df, pn) - T.g_rbound[g2] <= margin;
+          const float pn[3] = {S.gmat[g1][2], S.gmat[g1][5], S.gmat[g1][8]};
+          act = dot3(df, pn) - pr.rbsum <= margin;
         } else {
-          float df[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
-          act = !(sqrtf(dot3(df, df)) > T.g_rbound[g1] + T.g_rbound[g2] + margin);
+          act = !(dot3(df, df) > (pr.rbsum + margin) * (pr.rbsum + margin));
         }
+      }
+      if (!__any(act)) continue;   // nothing near in this round (wave-uniform): no narrowphase, no compaction
+      if (act) {
+        float M1[9], M2[9];
+        for (int i = 0; i < 9; i++) { M1[i] = S.gmat[g1][i]; M2[i] = S.gmat[g2][i]; }
         if (act) {
           if (t1 == DM_GEOM_PLANE) {
             float pn[3] = {M1[2], M1[5], M1[8]};
@@ -948,6 +969,7 @@ __device__ __forceinline__ int fwd_collide(const DmDev &T, const int lane) {
       unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
       int off = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
       int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+      if (total == 0) continue;
       int w = base + off;
 #pragma unroll
       for (int s = 0; s < 4; s++) {
@@ -1098,16 +1120,17 @@ __device__ __forceinline__ float fwd_constraint(const DmDev &T, const int lane, 
       PROF(6);
       // ---- B row = D^-1/2 L^-T J^T, in place (lane = row)
       {
-        // The factor entries are wave-uniform LDS broadcasts.  Tie the row pointer of step i to the
-        // result of step i+1 so hipcc cannot hoist all 561 loads ahead of the FMAs (that costs >200
-        // VGPRs and spills to scratch).
+        // x <- L^-T x on the row held by this lane: only the 276 ancestor pairs of the dof tree, all
+        // register and LDS indices static (dm_topology.h); factor entries are wave-uniform broadcasts.
+        // Step i's loads are tied to step i+1's result so they are not all hoisted ahead of the FMAs.
         lds_cfloat_p Mp = (lds_cfloat_p)S.M;
 #pragma unroll
         for (int i = DMK_NV - 1; i >= 1; i--) {
           const float xi = J[i] * S.dinv[i];
           asm volatile("" : "+v"(Mp), "+v"(J[0]));
 #pragma unroll
-          for (int j = 0; j < i; j++) J[j] -= Mp[i * DMK_MSTRIDE + j] * xi;
+          for (int j = 0; j < i; j++)
+            if (topo::is_anc(j, i)) J[j] -= Mp[topo::midx(i, j)] * xi;
         }
       }
 #pragma unroll
@@ -1175,12 +1198,15 @@ __device__ __forceinline__ float fwd_constraint(const DmDev &T, const int lane, 
         float s = wave_sum(f * J[k]);
         if (lane == k) v = s;
       }
-      v *= S.dsqrtinv[lk] * S.M[lk * (DMK_MSTRIDE + 1)];   // z = D (D^-1/2 v)
+      const int mrow = T.d_madr[lk] + T.d_nanc[lk];
+      const uint64_t ancm = T.d_ancm[lk];
+      v *= S.dsqrtinv[lk] * S.M[T.d_madr[lk]];               // z = D (D^-1/2 v)
 #pragma unroll
       for (int j = 0; j < DMK_NV - 1; j++) {                 // x = L^-1 (.) with x = z * dinv
         const float xj = rl(v * dv, j);
-        const float l = S.M[lk * DMK_MSTRIDE + j];
-        if (lane > j && lane < DMK_NV) v -= l * xj;
+        const bool isd = (ancm >> j) & 1ull;
+        const float l = S.M[isd ? mrow - topo::NANC[j] : 0];
+        if (isd) v -= l * xj;
       }
       qacc_out = xs + v * dv;
 #ifndef DM_PROFILE
@@ -1223,7 +1249,6 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, 2) dm_step
 
   PROF_DECL;
   // ---------------------------------------------------------------- LDS init
-  for (int i = lane; i < DMK_NV * DMK_MSTRIDE; i += 64) S.M[i] = 0.f;
   if (lane == 0) {
     S.xpos[0][0] = S.xpos[0][1] = S.xpos[0][2] = 0;
     S.xquat[0][0] = 1; S.xquat[0][1] = S.xquat[0][2] = S.xquat[0][3] = 0;
