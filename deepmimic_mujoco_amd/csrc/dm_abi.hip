@@ -20,6 +20,7 @@ struct DmEngine {
   int N = 0;
   DmDev *dT = nullptr;
   float *dState = nullptr;
+  float *dArScratch = nullptr;
   float *dClipRows[DM_MAX_CLIPS] = {nullptr};
   float *dClipReset[DM_MAX_CLIPS] = {nullptr};
   int clipL[DM_MAX_CLIPS] = {0};
@@ -194,6 +195,9 @@ extern "C" int dm_create(const DmModel *model, const DmConfig *cfg, DmHandle *ou
   for (int i = 0; i < e->N; i++)
     for (int k = 0; k < DM_NQ; k++) init[(size_t)i * DMK_STATE_STRIDE + DMS_QPOS + k] = (float)model->qpos0[k];
   hipMemcpy(e->dState, init.data(), sb, hipMemcpyHostToDevice);
+  if (hipMalloc(&e->dArScratch, (size_t)e->N * (DMK_MAXROW - DMK_REGROW) * 64 * sizeof(float)) != hipSuccess) {
+    hipFree(e->dState); hipFree(e->dT); delete e; return DM_ENOMEM;
+  }
   hipEventCreate(&e->ev0);
   hipEventCreate(&e->ev1);
   *out = e;
@@ -206,6 +210,7 @@ extern "C" int dm_destroy(DmHandle e) {
   hipDeviceSynchronize();
   for (int i = 0; i < DM_MAX_CLIPS; i++) { if (e->dClipRows[i]) hipFree(e->dClipRows[i]); if (e->dClipReset[i]) hipFree(e->dClipReset[i]); }
   if (e->dState) hipFree(e->dState);
+  if (e->dArScratch) hipFree(e->dArScratch);
   if (e->dT) hipFree(e->dT);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
@@ -291,6 +296,7 @@ static void fill_launch(DmEngine *e, DmLaunch &P, int mode) {
   memset(&P, 0, sizeof(P));
   P.T = e->dT;
   P.state = e->dState;
+  P.ar_scratch = e->dArScratch;
   for (int i = 0; i < DM_MAX_CLIPS; i++) { P.clips[i].rows = e->dClipRows[i]; P.clips[i].reset = e->dClipReset[i]; P.clips[i].L = e->clipL[i]; }
   P.N = e->N; P.mode = mode; P.auto_reset = e->cfg.auto_reset; P.max_ep_length = e->cfg.max_ep_length;
   P.vel_obs_scale = e->cfg.vel_obs_scale; P.low_z = e->cfg.low_z; P.high_z = e->cfg.high_z; P.obs_bound = e->cfg.obs_bound;

@@ -17,6 +17,8 @@
 
 #include <math.h>
 
+#include <type_traits>
+
 // One wavefront owns one environment, so LDS hand-offs between phases only need ordering inside the
 // wave: DS operations of a wave execute in order; the fences stop the compiler moving LDS accesses.
 #define SYNC()                                              \
@@ -26,6 +28,9 @@
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
   } while (0)
 #define DMK_ENVS_PER_BLOCK 1
+#ifndef DMK_WAVES_PER_SIMD
+#define DMK_WAVES_PER_SIMD 2
+#endif
 // Diagnostic build only (-DDM_PROFILE): per-phase cycle stamps, written to the debug buffer
 // [352:368).  The shipped library never executes a stamp.
 #ifdef DM_PROFILE
@@ -46,6 +51,18 @@ typedef __attribute__((address_space(3))) const float *lds_cfloat_p;
 #define MAXVALF 1e10f
 
 namespace {
+
+// Compile-time loop with early exit: f(integral_constant<int, I>) returns false to stop.  Guarantees
+// static register indices for the per-lane A-matrix row (a rolled loop would put it in scratch).
+template <int I, int N>
+struct StaticFor {
+  template <class F>
+  static __device__ __forceinline__ void run(F &&f) {
+    if constexpr (I < N) {
+      if (f(std::integral_constant<int, I>{})) StaticFor<I + 1, N>::run(f);
+    }
+  }
+};
 
 __device__ __forceinline__ float rl(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
@@ -996,7 +1013,8 @@ __device__ __forceinline__ int fwd_collide(const DmDev &T, const int lane) {
 }
 
 // ---- forward evaluation, part 3: constraint rows, A = J M^-1 J^T + R, PGS, qacc; returns qacc[lane]
-__device__ __forceinline__ float fwd_constraint(const DmDev &T, const int lane, const int ncon, int overflow, float *dbg_force) {
+__device__ __forceinline__ float fwd_constraint(const DmDev &T, const int lane, const int ncon, int overflow, float *dbg_force,
+                                                float *ar_scratch) {
   EnvLds &S = g_S;
   int nefc = 0, nlimit = 0, solver_iter = 0;
   const int lb = lane < DMK_NB ? lane : 0;       // lane as body
@@ -1135,14 +1153,17 @@ __device__ __forceinline__ float fwd_constraint(const DmDev &T, const int lane, 
       }
 #pragma unroll
       for (int k = 0; k < DMK_NV; k++) J[k] *= S.dsqrtinv[k];
-      // ---- A row: AR[i] = B_lane . B_i (+ R on the diagonal)
-      float AR[DMK_MAXROW];
+      // ---- A row: AR[i] = B_lane . B_i (+ R on the diagonal).  Columns 0..31 live in registers; the
+      // rare columns 32..63 (nefc > 32: p99 of the benchmark workload is 16) go to a per-env global
+      // scratch, written and later re-read by the same lane.
+      float AR[DMK_REGROW];
+      float *arx = ar_scratch + lane;                      // column i >= 32 at arx[(i - 32) * 64]
       float ARd = R;
 #pragma unroll
       for (int k = 0; k < DMK_NV; k++) ARd += J[k] * J[k];
-#pragma unroll
-      for (int i = 0; i < DMK_MAXROW; i++) {
-        if (i >= nefc) break;  // rows beyond nefc are never read
+      StaticFor<0, DMK_REGROW>::run([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (i >= nefc) return false;  // rows beyond nefc are never read
         float acc0 = 0, acc1 = 0;
 #pragma unroll
         for (int k = 0; k < DMK_NV; k += 2) {
@@ -1152,6 +1173,19 @@ __device__ __forceinline__ float fwd_constraint(const DmDev &T, const int lane, 
         float acc = acc0 + acc1;
         if (lane == i) acc += R;
         AR[i] = acc;
+        return true;
+      });
+#pragma unroll 1
+      for (int i = DMK_REGROW; i < nefc; i++) {
+        float acc0 = 0, acc1 = 0;
+#pragma unroll
+        for (int k = 0; k < DMK_NV; k += 2) {
+          acc0 = fmaf(J[k], rl(J[k], i), acc0);
+          acc1 = fmaf(J[k + 1], rl(J[k + 1], i), acc1);
+        }
+        float acc = acc0 + acc1;
+        if (lane == i) acc += R;
+        arx[(i - DMK_REGROW) * 64] = acc;
       }
       const float ARinv = (lane < nefc) ? 1.0f / ARd : 0.f;
       PROF(7);
@@ -1161,11 +1195,14 @@ __device__ __forceinline__ float fwd_constraint(const DmDev &T, const int lane, 
         float jar = jw - aref;
         float fw = (lane < nefc && jar < 0) ? -Dd * jar : 0.f;
         float rw = bb;
-#pragma unroll
-        for (int i = 0; i < DMK_MAXROW; i++) {
-          if (i >= nefc) break;
+        StaticFor<0, DMK_REGROW>::run([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          if (i >= nefc) return false;
           rw += AR[i] * rl(fw, i);
-        }
+          return true;
+        });
+#pragma unroll 1
+        for (int i = DMK_REGROW; i < nefc; i++) rw += arx[(i - DMK_REGROW) * 64] * rl(fw, i);
         float cost = wave_sum(fw * (0.5f * (rw - bb) + bb));
         if (!(cost > 0)) { f = fw; r = rw; }
       }
@@ -1174,9 +1211,9 @@ __device__ __forceinline__ float fwd_constraint(const DmDev &T, const int lane, 
       int iter = 0;
       while (iter < T.iterations) {
         float impv = 0;
-#pragma unroll
-        for (int i = 0; i < DMK_MAXROW; i++) {
-          if (i >= nefc) break;
+        StaticFor<0, DMK_REGROW>::run([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          if (i >= nefc) return false;
           // every lane evaluates its own row; only row i's update is committed and broadcast
           const float fn = fmaxf(0.f, fmaf(-r, ARinv, f));
           const float dl = fn - f;
@@ -1185,6 +1222,22 @@ __device__ __forceinline__ float fwd_constraint(const DmDev &T, const int lane, 
           impv -= rl(t, i);
           r = fmaf(AR[i], dli, r);
           f = (lane == i) ? fn : f;
+          return true;
+        });
+        if (nefc > DMK_REGROW) {                            // overflow columns, streamed one row ahead
+          float anext = arx[0];
+#pragma unroll 1
+          for (int i = DMK_REGROW; i < nefc; i++) {
+            const float acur = anext;
+            if (i + 1 < nefc) anext = arx[(i + 1 - DMK_REGROW) * 64];
+            const float fn = fmaxf(0.f, fmaf(-r, ARinv, f));
+            const float dl = fn - f;
+            const float t = dl * fmaf(0.5f * dl, ARd, r);
+            const float dli = rl(dl, i);
+            impv -= rl(t, i);
+            r = fmaf(acur, dli, r);
+            f = (lane == i) ? fn : f;
+          }
         }
         iter++;
         if (impv * scale < tol) break;
@@ -1222,7 +1275,7 @@ __device__ __forceinline__ float fwd_constraint(const DmDev &T, const int lane, 
 }
 
 // ======================================================================================
-extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, 2) dm_step_kernel(DmLaunch P) {
+extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_PER_SIMD) dm_step_kernel(DmLaunch P) {
   // Model tables are read from global memory at their use sites: 6 KB shared by every wave on the CU,
   // so they sit in the vector L1 / scalar cache; keeping them out of LDS leaves room for more envs.
   const DmDev &T = *P.T;
@@ -1330,7 +1383,8 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, 2) dm_step
     {
       const int cr = fwd_collide(Ts, lane);
       ncon = cr & 0xFF;
-      qacc_out = fwd_constraint(Ts, lane, ncon, cr >> 8, P.debug ? P.debug + (size_t)env * DM_DEBUG_STRIDE + 352 : nullptr);
+      qacc_out = fwd_constraint(Ts, lane, ncon, cr >> 8, P.debug ? P.debug + (size_t)env * DM_DEBUG_STRIDE + 352 : nullptr,
+                                P.ar_scratch + (size_t)env * (DMK_MAXROW - DMK_REGROW) * 64);
       nefc = S.info[1]; nlimit = S.info[2]; solver_iter = S.info[3]; overflow = S.info[4];
       if (it < 4) { stage_ncon |= (unsigned)(ncon & 0xFF) << (8 * it); stage_nefc |= (unsigned)(nefc & 0xFF) << (8 * it); }
     }
