@@ -143,7 +143,8 @@ class FlatGradAllReduce:
 class PPO:
     def __init__(self, env, net_arch=(256, 128), n_steps=4096, batch_size=4096, n_epochs=20, learning_rate=4e-4,
                  gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5,
-                 normalize_advantage=True, seed=0, device=None, buffer_dtype=torch.float32, policy=None):
+                 normalize_advantage=True, seed=0, device=None, buffer_dtype=torch.float32, policy=None,
+                 use_hip_graph=None):
         self.env = env
         self.device = device if device is not None else getattr(env, "device", torch.device("cpu"))
         self.n_envs = env.num_envs if env is not None else 0
@@ -154,7 +155,13 @@ class PPO:
         self.buffer_dtype = buffer_dtype
         torch.manual_seed(seed)  # identical initial weights on every rank; no parameter broadcast needed
         self.policy = (policy if policy is not None else MlpPolicy(net_arch=tuple(net_arch))).to(self.device)
-        self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5)
+        on_gpu = self.device.type == "cuda"
+        # The optimizer step of one minibatch is ~60 small kernels: launch-bound.  On one GPU it is captured
+        # once into a hipGraph and replayed (640 replays per PPO iteration with the reference's settings).
+        self.use_hip_graph = (on_gpu and not dist.is_initialized()) if use_hip_graph is None else bool(use_hip_graph)
+        self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5, fused=on_gpu,
+                                          capturable=on_gpu and self.use_hip_graph)
+        self._graph = None
         self.grad_sync = FlatGradAllReduce(self.policy.parameters())
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         if dist.is_initialized():  # decorrelate action noise across ranks after the common init
@@ -201,28 +208,73 @@ class PPO:
         """``n_epochs`` passes over the flattened rollout in minibatches of ``batch_size`` (SB3 PPO.train)."""
         flat = {k: v.reshape(-1, *v.shape[2:]) for k, v in buf.items()}
         n = flat["obs"].shape[0]
-        losses = []
+        loss_sum = torch.zeros((), device=self.device)
+        nsteps = 0
         for _ in range(self.n_epochs):
             perm = torch.randperm(n, device=self.device, generator=generator)
             for s in range(0, n, self.batch_size):
                 idx = perm[s:s + self.batch_size]
-                obs, act = flat["obs"][idx].float(), flat["act"][idx].float()
-                adv, ret, old_logp = flat["adv"][idx], flat["ret"][idx], flat["logp"][idx]
-                if self.normalize_advantage and len(idx) > 1:
-                    adv = (adv - adv.mean()) / (adv.std() + 1e-8)
-                value, logp, entropy = self.policy.evaluate_actions(obs, act)
-                ratio = torch.exp(logp - old_logp)
-                pg = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - self.clip_range, 1 + self.clip_range)).mean()
-                vl = torch.nn.functional.mse_loss(ret, value)
-                loss = pg + self.vf_coef * vl - self.ent_coef * entropy.mean()
-                self.optimizer.zero_grad(set_to_none=False)
-                loss.backward()
-                self.grad_sync()                         # the ONE collective of the data-parallel learner
-                nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
-                self.optimizer.step()
-                losses.append(float(loss.detach()))
-        self.stats["loss"] = float(np.mean(losses)) if losses else 0.0
+                if self.use_hip_graph and len(idx) == self.batch_size:
+                    loss = self._graph_step(flat, idx)
+                else:
+                    loss = self._minibatch_step(flat["obs"][idx].float(), flat["act"][idx].float(), flat["adv"][idx],
+                                                flat["ret"][idx], flat["logp"][idx])
+                loss_sum += loss
+                nsteps += 1
+        self.stats["loss"] = float(loss_sum / max(nsteps, 1))   # one host sync per train() call
         return self.stats["loss"]
+
+    def _minibatch_step(self, obs, act, adv, ret, old_logp):
+        if self.normalize_advantage and obs.shape[0] > 1:
+            adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+        value, logp, entropy = self.policy.evaluate_actions(obs, act)
+        ratio = torch.exp(logp - old_logp)
+        pg = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - self.clip_range, 1 + self.clip_range)).mean()
+        vl = torch.nn.functional.mse_loss(ret, value)
+        loss = pg + self.vf_coef * vl - self.ent_coef * entropy.mean()
+        self.optimizer.zero_grad(set_to_none=False)
+        loss.backward()
+        self.grad_sync()                         # the ONE collective of the data-parallel learner
+        nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
+        self.optimizer.step()
+        return loss.detach()
+
+    def _graph_step(self, flat, idx):
+        """Replay the captured optimizer step on static input buffers (capture on first use)."""
+        if self._graph is None:
+            B, dev = self.batch_size, self.device
+            self._gin = dict(obs=torch.zeros(B, 67, device=dev), act=torch.zeros(B, 28, device=dev),
+                             adv=torch.zeros(B, device=dev), ret=torch.zeros(B, device=dev),
+                             logp=torch.zeros(B, device=dev))
+            # warm-up iterations must not change the model: snapshot parameters and optimizer state
+            snap_p = [p.detach().clone() for p in self.policy.parameters()]
+            snap_o = {k: {kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in st.items()}
+                      for k, st in self.optimizer.state.items()}
+            had_state = len(self.optimizer.state) > 0
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    self._minibatch_step(**{("old_logp" if k == "logp" else k): v for k, v in self._gin.items()})
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._gloss = self._minibatch_step(**{("old_logp" if k == "logp" else k): v for k, v in self._gin.items()})
+            with torch.no_grad():
+                for p, q in zip(self.policy.parameters(), snap_p):
+                    p.copy_(q)
+                for k, st in self.optimizer.state.items():
+                    for kk, vv in st.items():
+                        if torch.is_tensor(vv):
+                            vv.copy_(snap_o[k][kk]) if had_state and k in snap_o else vv.zero_()
+        g = self._gin
+        torch.index_select(flat["obs"], 0, idx, out=g["obs"]) if flat["obs"].dtype == torch.float32 else g["obs"].copy_(flat["obs"][idx])
+        torch.index_select(flat["act"], 0, idx, out=g["act"]) if flat["act"].dtype == torch.float32 else g["act"].copy_(flat["act"][idx])
+        torch.index_select(flat["adv"], 0, idx, out=g["adv"])
+        torch.index_select(flat["ret"], 0, idx, out=g["ret"])
+        torch.index_select(flat["logp"], 0, idx, out=g["logp"])
+        self._graph.replay()
+        return self._gloss
 
     def learn(self, total_timesteps, log_interval=1, callback=None):
         it = 0

@@ -1,0 +1,76 @@
+"""Training driver — the build's counterpart of src/sb3_ppo.py:244-314 / src/ppo.py:16-40.
+
+    python -m deepmimic_mujoco_amd.train --motion walk --envs 4096 --horizon 32 --total 2000000
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m deepmimic_mujoco_amd.train ...
+
+One process per GPU; every rank owns `--envs` environments (sharded, no collective on the env path)
+and a policy replica; gradients are all-reduced once per optimizer step (RCCL over xGMI).
+"""
+import argparse
+import json
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--motion", default="walk", help="clip name or comma list (multi-clip: env i -> clip i mod k)")
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--horizon", type=int, default=32)          # 32 x 4096 = the reference's 4096 x 32 batch
+    ap.add_argument("--epochs", type=int, default=20)           # src/sb3_ppo.py:259
+    ap.add_argument("--minibatch", type=int, default=4096)      # :271
+    ap.add_argument("--lr", type=float, default=4e-4)           # :260
+    ap.add_argument("--arch", default="256,128")                # :265 ([1024,512] is BASELINE config 3)
+    ap.add_argument("--total", type=int, default=1_000_000)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--bf16-buffer", action="store_true", help="store rollout obs/actions in bf16 (config 5)")
+    ap.add_argument("--save", default="")
+    ap.add_argument("--json", action="store_true", help="print a JSON throughput summary on rank 0")
+    args = ap.parse_args(argv)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    rank = dist.get_rank() if world > 1 else 0
+
+    from .deepmimic_env import HipDeepMimicVecEnv
+    from .ppo import PPO
+
+    motions = args.motion.split(",")
+    env = HipDeepMimicVecEnv(args.envs, motion=motions if len(motions) > 1 else motions[0], device=local_rank,
+                             seed=1234 + 7919 * rank)
+    ppo = PPO(env, net_arch=tuple(int(x) for x in args.arch.split(",")), n_steps=args.horizon,
+              batch_size=args.minibatch, n_epochs=args.epochs, learning_rate=args.lr, seed=args.seed,
+              buffer_dtype=torch.bfloat16 if args.bf16_buffer else torch.float32)
+    hist = []
+    t0 = time.perf_counter()
+    ppo.learn(args.total, log_interval=0 if args.json else 1, callback=lambda p: hist.append(dict(p.stats)))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        if args.save:
+            ppo.save(os.path.expanduser(args.save))
+        if args.json:
+            steady = hist[1:] if len(hist) > 1 else hist
+            roll = sum(h["rollout_s"] for h in steady) / len(steady)
+            trn = sum(h["train_s"] for h in steady) / len(steady)
+            per_it = args.envs * args.horizon * world
+            print(json.dumps({"workload": "ppo", "n_gpus": world, "envs_per_gpu": args.envs, "horizon": args.horizon,
+                              "arch": args.arch, "epochs": args.epochs, "minibatch": args.minibatch,
+                              "iterations": len(hist), "rollout_env_steps_per_s": per_it / roll,
+                              "train_s_per_iter": trn, "overall_env_steps_per_s": per_it / (roll + trn),
+                              "mean_reward_last": hist[-1]["mean_reward"], "wall_s": dt,
+                              "grad_allreduce_calls": ppo.grad_sync.calls}))
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -176,3 +176,26 @@ def test_short_ppo_run_on_device():
     a = ppo.predict(venv.reset_tensor())
     assert a.shape == (128, 28) and a.abs().max() <= 2.0
     venv.close()
+
+
+def test_hip_graph_update_matches_eager():
+    """The captured (hipGraph) optimizer step must produce the same parameters as the eager step."""
+    import torch
+    from deepmimic_mujoco_amd.ppo import PPO
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    T, N = 8, 64
+    buf = dict(obs=torch.randn(T, N, 67, generator=g), act=torch.randn(T, N, 28, generator=g),
+               adv=torch.randn(T, N, generator=g), ret=torch.randn(T, N, generator=g),
+               logp=-40 + torch.randn(T, N, generator=g), rew=torch.zeros(T, N), done=torch.zeros(T, N),
+               val=torch.zeros(T, N))
+    buf = {k: v.to(dev) for k, v in buf.items()}
+    outs = []
+    for use_graph in (False, True):
+        ppo = PPO(None, net_arch=(64, 32), n_epochs=2, batch_size=128, device=dev, use_hip_graph=use_graph, seed=3)
+        gen = torch.Generator(device=dev).manual_seed(5)
+        ppo.train(buf, generator=gen)
+        ppo.train(buf, generator=gen)
+        outs.append(torch.cat([p.detach().reshape(-1) for p in ppo.policy.parameters()]).cpu())
+    assert torch.isfinite(outs[0]).all()
+    assert torch.allclose(outs[0], outs[1], rtol=1e-4, atol=1e-6), (outs[0] - outs[1]).abs().max()
