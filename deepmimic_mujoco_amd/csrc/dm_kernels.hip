@@ -47,6 +47,8 @@
 #define PROF(i) do {} while (0)
 #endif
 typedef __attribute__((address_space(3))) const float *lds_cfloat_p;
+typedef const __attribute__((address_space(1))) DmDev GDev;          // model tables: global address space
+typedef const __attribute__((address_space(1))) DmPairDev GPair;
 #define MINVALF 1e-15f
 #define MAXVALF 1e10f
 
@@ -269,8 +271,12 @@ __device__ __forceinline__ void make_frame(float *f) {  // [EXT] mju_makeFrame
 
 // Box-box for the single foot-foot pair: SAT over 15 axes, then reference-face clipping
 // (polygon scratch in LDS) or closest points of two edges.  Same construction as the oracle.
-__device__ __noinline__ void np_box_box(EnvLds &S, float margin, const float *p1, const float *R1, const float *s1,
-                                        const float *p2, const float *R2, const float *s2) {
+__device__ __noinline__ void np_box_box(EnvLds &S, GPair *pr) {
+  // operands are fetched here (LDS poses, pair record) so the caller needs no stack arrays for them
+  const float margin = pr->margin;
+  float p1[3], p2[3], R1[9], R2[9], s1[3], s2[3];
+  for (int i = 0; i < 3; i++) { p1[i] = S.gpos[pr->g1][i]; p2[i] = S.gpos[pr->g2][i]; s1[i] = pr->z1[i]; s2[i] = pr->z2[i]; }
+  for (int i = 0; i < 9; i++) { R1[i] = S.gmat[pr->g1][i]; R2[i] = S.gmat[pr->g2][i]; }
   S.u.bb.ncand = 0;
   float R[9], AR[9], t[3], tw[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
   mat_t_vec(t, R1, tw);
@@ -460,7 +466,7 @@ __shared__ EnvLds g_S;  // one environment per 64-thread block
 // ---- forward evaluation, part 1: kinematics, inertia, factorisation, bias forces, qacc_smooth
 // Every pass is lane-parallel: bodies walk their (<= 4 deep) ancestor chain instead of waiting for a
 // level-by-level sweep, and the L^T D L factorisation keeps row i of M in the registers of lane i.
-__device__ __forceinline__ void fwd_smooth(const DmDev &T, const int lane) {
+__device__ __forceinline__ void fwd_smooth(GDev &T, const int lane) {
   EnvLds &S = g_S;
   const int lb = lane < DMK_NB ? lane : 0;       // lane as body
   const int lk = lane < DMK_NV ? lane : 0;       // lane as dof
@@ -798,7 +804,7 @@ __device__ __forceinline__ void fwd_smooth(const DmDev &T, const int lane) {
 }
 
 // ---- forward evaluation, part 2: collision detection -> contact list in LDS; returns ncon | overflow << 8
-__device__ __forceinline__ int fwd_collide(const DmDev &T, const int lane) {
+__device__ __forceinline__ int fwd_collide(GDev &T, const int lane) {
   EnvLds &S = g_S;
   int ncon = 0, overflow = 0;
   const int lb = lane < DMK_NB ? lane : 0;       // lane as body
@@ -816,7 +822,12 @@ __device__ __forceinline__ int fwd_collide(const DmDev &T, const int lane) {
       Cand c;
       c.valid = 0;
       c.t[0] = c.t[1] = c.t[2] = 0;
-      for (int s = 0; s < 4; s++) { c.d[s] = 0; for (int i = 0; i < 3; i++) { c.p[s][i] = 0; c.n[s][i] = 0; } }
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        c.d[s] = 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { c.p[s][i] = 0; c.n[s][i] = 0; }
+      }
       int g1 = 0, g2 = 0;
       bool isbb = false;
       float margin = 0;
@@ -825,7 +836,7 @@ __device__ __forceinline__ int fwd_collide(const DmDev &T, const int lane) {
       int t1 = 0, t2 = 0;
       float x1[3], x2[3], z1[3], z2[3];
       if (p < T.npair) {
-        const DmPairDev pr = T.pairs[p];
+        GPair &pr = T.pairs[p];
         g1 = pr.g1; g2 = pr.g2; t1 = pr.t1; t2 = pr.t2;
         margin = pr.margin;
         for (int i = 0; i < 3; i++) { x1[i] = S.gpos[g1][i]; x2[i] = S.gpos[g2][i]; z1[i] = pr.z1[i]; z2[i] = pr.z2[i]; }
@@ -969,7 +980,7 @@ __device__ __forceinline__ int fwd_collide(const DmDev &T, const int lane) {
           }
         }
         if (isbb) {
-          np_box_box(S, margin, x1, M1, z1, x2, M2, z2);
+          np_box_box(S, &T.pairs[p]);
           int nc = S.u.bb.ncand;
 #pragma unroll
           for (int s = 0; s < 4; s++)
@@ -1013,7 +1024,7 @@ __device__ __forceinline__ int fwd_collide(const DmDev &T, const int lane) {
 }
 
 // ---- forward evaluation, part 3: constraint rows, A = J M^-1 J^T + R, PGS, qacc; returns qacc[lane]
-__device__ __forceinline__ float fwd_constraint(const DmDev &T, const int lane, const int ncon, int overflow, float *dbg_force,
+__device__ __forceinline__ float fwd_constraint(GDev &T, const int lane, const int ncon, int overflow, float *dbg_force,
                                                 float *ar_scratch) {
   EnvLds &S = g_S;
   int nefc = 0, nlimit = 0, solver_iter = 0;
@@ -1098,9 +1109,10 @@ __device__ __forceinline__ float fwd_constraint(const DmDev &T, const int lane, 
             rdiag = tran;
           } else {
             rtype = 2;
-            int tsel = 3 + 3 * (e >> 1);
+            const bool second = (e >> 1) != 0;   // tangent 2 for edges 2,3
+            const float tx = second ? fr[6] : fr[3], ty = second ? fr[7] : fr[4], tz = second ? fr[8] : fr[5];
             float sg = (e & 1) ? -mu : mu;
-            wl[0] = fr[0] + sg * fr[tsel]; wl[1] = fr[1] + sg * fr[tsel + 1]; wl[2] = fr[2] + sg * fr[tsel + 2];
+            wl[0] = fr[0] + sg * tx; wl[1] = fr[1] + sg * ty; wl[2] = fr[2] + sg * tz;
             rdiag = tran + mu * mu * tran;
           }
           float off[3] = {S.c_pos[ci][0] - com[0], S.c_pos[ci][1] - com[1], S.c_pos[ci][2] - com[2]};
@@ -1278,7 +1290,7 @@ __device__ __forceinline__ float fwd_constraint(const DmDev &T, const int lane, 
 extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_PER_SIMD) dm_step_kernel(DmLaunch P) {
   // Model tables are read from global memory at their use sites: 6 KB shared by every wave on the CU,
   // so they sit in the vector L1 / scalar cache; keeping them out of LDS leaves room for more envs.
-  const DmDev &T = *P.T;
+  GDev &T = *(GDev *)P.T;
   const int lane = threadIdx.x & 63;
   EnvLds &S = g_S;
   const int slot = blockIdx.x;
@@ -1370,9 +1382,9 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_
     // ============================================================== forward evaluation
     // launder the table pointer once per stage: keeps hipcc from hoisting table loads out of the
     // stage loop into registers that would then live (and spill) across the whole kernel
-    const DmDev *Tp = P.T;
+    GDev *Tp = (GDev *)P.T;
     asm volatile("" : "+s"(Tp));
-    const DmDev &Ts = *Tp;
+    GDev &Ts = *Tp;
     fwd_smooth(Ts, lane);
     if (it == 0) {  // capture X0 (after normalisation)
       x0v = (lane < DMK_NV) ? S.qvel[lk] : 0.f;
