@@ -28,6 +28,17 @@ ALGO_BYTES_PER_ENV_STEP = 1260      # 315 fp32 words of state in/
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def measured_traffic_bytes():
+    """HBM bytes per launch of dm_step_kernel from the committed PMC profile (same command, 4096 envs)."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01_v5_pmc_dm_step_kernel.csv")
+    try:
+        vals = {r["counter"]: float(r["mean_per_dispatch_over_last_10_dispatches"]) for r in csv.DictReader(open(path))}
+        return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
+
+
 def cpu_baseline(model, mocap, budget_s=12.0):
     """Oracle DPEnv.step() on host cores: 1 thread, bounded sample of the same workload."""
     from oracle.oracle import OracleClip, bench_steps
@@ -55,6 +66,7 @@ def main():
     ap.add_argument("--motion", default="walk")
     ap.add_argument("--actions", default="random", choices=["random", "zero"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     args = ap.parse_args()
 
     import torch
@@ -63,13 +75,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; --dist-backend gloo + several ranks on one GPU is only for rehearsing the N>1 path
+    local_dev = local_rank % torch.cuda.device_count()
+    launched = "RANK" in os.environ
+    if launched:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group(args.dist_backend)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    local_rank = local_dev
+
+    def barrier():
+        if launched:
+            dist.barrier()
 
     from deepmimic_mujoco_amd.model import load_model
     from deepmimic_mujoco_amd.mocap import MocapDM
@@ -97,19 +120,17 @@ def main():
     eng.enable_timing(True)
     kernel_ms = []
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(args.warmup + i)
         if i % 8 == 7 or i == args.steps - 1:   # sample the kernel duration (event sync drains the stream)
             kernel_ms.append(eng.last_step_ms())
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if launched:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     done_frac = float(out["done"].float().mean().item())
@@ -119,6 +140,7 @@ def main():
         value = total_steps / dt
         kms = float(np.mean(kernel_ms))
         achieved = N * ALGO_BYTES_PER_ENV_STEP / (kms * 1e-3) / 1e9
+        traffic = measured_traffic_bytes() if (N == 4096 and args.actions == "random") else None
         line = {
             "metric": "env-steps/sec (whole node), 34-DoF humanoid, 4096 envs, at 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -130,7 +152,9 @@ def main():
                        "envs_per_gpu": N, "parallelism": "env-sharded x%d, no data-path collective" % world,
                        "done_fraction_last_step": done_frac},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_note": "bytes/launch = (FETCH_SIZE + WRITE_SIZE) * 1024 from the separate rocprofv3 --pmc passes "
+                                         "committed under profiles/ (4-byte-per-lane accesses: FETCH_SIZE uncalibrated on gfx950)",
                          "kernel": "dm_step_kernel", "kernel_ms": kms,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP},
         }
@@ -138,7 +162,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(model, mocap)
         print(json.dumps(line))
     eng.close()
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 

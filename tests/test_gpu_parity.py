@@ -246,3 +246,18 @@ def test_caps_overflow_matches_oracle_rule(model, clips, oracle_clips, torch_mod
     qa = d[174:208]
     assert np.abs(qa - s.get("qacc")).max() < 2e-2 * max(1.0, np.abs(s.get("qacc")).max())
     eng.close()
+
+
+def test_thousand_step_teacher_forced_trajectory(model, clips, oracle_clips, torch_mod):
+    """BASELINE target: per-step qpos L-inf error < 1e-4 vs the CPU path over 1000 steps on identical
+    (state, action) sequences.  The oracle runs 1000 consecutive steps (small random torques, resets on
+    done); the HIP path is reset to the oracle's (qpos, qvel, qacc_warmstart, ctrl) before every step."""
+    res = _run_teacher_forced(model, clips, oracle_clips, torch_mod, 0.25, 77, nenv=1, nsteps=1000)
+    ok = np.ones(len(res["qpos"]), bool)
+    for m in res["contact_mismatch"]:
+        assert m[3], m
+        ok[m[0]] = False
+    ok[res["stage_flips"]] = False
+    print("1000 steps: qpos max %.3g (flips excluded: %d), qvel max %.3g" % (res["qpos"][ok].max(), (~ok).sum(), res["qvel"][ok].max()))
+    assert len(res["qpos"]) == 1000 and ok.sum() >= 990
+    assert res["qpos"][ok].max() < TOL_QPOS
