@@ -23,7 +23,7 @@ REASONS = {0: None, 1: "low_z", 2: "high_z", 3: "max_ep_len", 4: "acyclical_end"
 EXPORTS = ["dm_default_config", "dm_create", "dm_destroy", "dm_last_error", "dm_num_envs",
            "dm_load_clip", "dm_set_env_clips", "dm_reset", "dm_step", "dm_step_forced",
            "dm_set_state", "dm_get_state", "dm_get_counters", "dm_set_counters", "dm_set_debug",
-           "dm_fill_random_actions", "dm_last_step_ms", "dm_enable_timing"]
+           "dm_fill_random_actions", "dm_last_step_ms", "dm_enable_timing", "dm_get_work"]
 
 
 class DmConfig(C.Structure):
@@ -31,7 +31,8 @@ class DmConfig(C.Structure):
                 ("vel_obs_scale", C.c_float), ("low_z", C.c_float), ("high_z", C.c_float),
                 ("w_pose", C.c_float), ("w_vel", C.c_float), ("w_end_eff", C.c_float),
                 ("w_com", C.c_float), ("w_joint_limit", C.c_float), ("obs_bound", C.c_float),
-                ("seed", C.c_uint64), ("auto_reset", C.c_int32), ("device", C.c_int32)]
+                ("seed", C.c_uint64), ("auto_reset", C.c_int32), ("device", C.c_int32),
+                ("lpt_schedule", C.c_int32), ("pad", C.c_int32)]
 
 
 _LIB = None
@@ -68,6 +69,7 @@ def load_library():
     L.dm_get_counters.argtypes = [vp, vp, vp, vp, vp]
     L.dm_set_counters.argtypes = [vp, vp, vp, vp]
     L.dm_set_debug.argtypes = [vp, vp]
+    L.dm_get_work.argtypes = [vp, vp, vp]
     L.dm_fill_random_actions.argtypes = [vp, vp, C.c_uint32, vp]
     L.dm_last_step_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.dm_enable_timing.argtypes = [vp, i32]
@@ -203,6 +205,11 @@ class HipEngine:
     def fill_random_actions(self, actions, step_index):
         self._chk(self.L.dm_fill_random_actions(self.h, _ptr(actions), int(step_index), self._stream()),
                   "dm_fill_random_actions")
+
+    def get_work(self):
+        w = self.torch.zeros(self.N, dtype=self.torch.int32, device=self.device)
+        self._chk(self.L.dm_get_work(self.h, _ptr(w), self._stream()), "dm_get_work")
+        return w
 
     def enable_timing(self, on=True):
         self._chk(self.L.dm_enable_timing(self.h, 1 if on else 0), "dm_enable_timing")

@@ -25,6 +25,8 @@ struct DmEngine {
   float *dClipReset[DM_MAX_CLIPS] = {nullptr};
   int clipL[DM_MAX_CLIPS] = {0};
   float *debug = nullptr;
+  int32_t *dOrder = nullptr;   // slot -> env permutation for dm_step (longest-first)
+  int32_t *dCost = nullptr;    // per-env work estimate written by dm_step
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timing = false;
   float last_ms = 0;
@@ -56,6 +58,7 @@ extern "C" void dm_default_config(DmConfig *c) {
   c->seed = 1234;
   c->auto_reset = 1;
   c->device = 0;
+  c->lpt_schedule = 1;
 }
 
 static void build_tables(const DmModel &m, DmDev &T) {
@@ -198,6 +201,10 @@ extern "C" int dm_create(const DmModel *model, const DmConfig *cfg, DmHandle *ou
   if (hipMalloc(&e->dArScratch, (size_t)e->N * (DMK_MAXROW - DMK_REGROW) * 64 * sizeof(float)) != hipSuccess) {
     hipFree(e->dState); hipFree(e->dT); delete e; return DM_ENOMEM;
   }
+  if (hipMalloc(&e->dOrder, e->N * sizeof(int32_t)) != hipSuccess || hipMalloc(&e->dCost, e->N * sizeof(int32_t)) != hipSuccess) {
+    hipFree(e->dArScratch); hipFree(e->dState); hipFree(e->dT); delete e; return DM_ENOMEM;
+  }
+  hipMemset(e->dCost, 0, e->N * sizeof(int32_t));
   hipEventCreate(&e->ev0);
   hipEventCreate(&e->ev1);
   *out = e;
@@ -211,6 +218,8 @@ extern "C" int dm_destroy(DmHandle e) {
   for (int i = 0; i < DM_MAX_CLIPS; i++) { if (e->dClipRows[i]) hipFree(e->dClipRows[i]); if (e->dClipReset[i]) hipFree(e->dClipReset[i]); }
   if (e->dState) hipFree(e->dState);
   if (e->dArScratch) hipFree(e->dArScratch);
+  if (e->dOrder) hipFree(e->dOrder);
+  if (e->dCost) hipFree(e->dCost);
   if (e->dT) hipFree(e->dT);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
@@ -255,6 +264,8 @@ extern "C" int dm_load_clip(DmHandle e, int clip_id, int L, const double *qpos, 
   e->clipL[clip_id] = L;
   return DM_OK;
 }
+
+__global__ void dm_schedule_kernel(const int32_t *cost, int32_t *order, int n);
 
 __global__ void dm_set_clip_kernel(float *state, const int32_t *ids, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -331,6 +342,12 @@ extern "C" int dm_step(DmHandle e, const float *actions, float *obs, float *rew,
   DmLaunch P;
   fill_launch(e, P, DMK_MODE_STEP);
   P.actions = actions; P.obs = obs; P.rew = rew; P.done = done; P.terms = terms; P.reason = reason; P.terminal_obs = terminal_obs;
+  P.cost = e->dCost;
+  if (e->cfg.lpt_schedule) {
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    hipLaunchKernelGGL(dm_schedule_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->dCost, e->dOrder, e->N);
+    P.env_ids = e->dOrder;
+  }
   return launch(e, P, e->N, stream);
 }
 
@@ -376,6 +393,38 @@ extern "C" int dm_set_counters(DmHandle e, const int32_t *idx, const int32_t *le
   hipLaunchKernelGGL(dm_counters_kernel, dim3((e->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->dState, e->N,
                      (int32_t *)nullptr, (int32_t *)nullptr, (float *)nullptr, idx, len);
   HIPCHK(e, hipGetLastError());
+  return DM_OK;
+}
+
+// Bucket sort of the per-env work estimates, heaviest first (one 1024-thread block; N <= 65536 in practice).
+__global__ void dm_schedule_kernel(const int32_t *cost, int32_t *order, int n) {
+  __shared__ int hist[256];
+  __shared__ int base[256];
+  const int tid = threadIdx.x;
+  if (tid < 256) hist[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) {
+    int b = cost[i] >> 5;
+    b = 255 - (b > 255 ? 255 : (b < 0 ? 0 : b));
+    atomicAdd(&hist[b], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int b = 0; b < 256; b++) { base[b] = acc; acc += hist[b]; }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) {
+    int b = cost[i] >> 5;
+    b = 255 - (b > 255 ? 255 : (b < 0 ? 0 : b));
+    order[atomicAdd(&base[b], 1)] = i;
+  }
+}
+
+extern "C" int dm_get_work(DmHandle e, int32_t *work_out, void *stream) {
+  if (!e || !work_out) return DM_EINVAL;
+  HIPCHK(e, hipSetDevice(e->cfg.device));
+  HIPCHK(e, hipMemcpyAsync(work_out, e->dCost, e->N * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return DM_OK;
 }
 

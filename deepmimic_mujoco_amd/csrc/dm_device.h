@@ -152,6 +152,7 @@ struct DmLaunch {
   const float *in_warm;         // N x 34 or null    (SETSTATE)
   const float *in_ctrl;         // N x 28 or null    (SETSTATE)
   const int32_t *env_ids;       // slot -> env or null
+  int32_t *cost;                // per-env work estimate of this step (constraint-row updates + forwards), or null
   const uint8_t *mask;          // RESET: per-env mask or null
   const int32_t *idx_init;      // RESET: per-env frame or null (random)
   int32_t run_forward;          // SETSTATE

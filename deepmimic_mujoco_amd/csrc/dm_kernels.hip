@@ -1363,6 +1363,7 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_
   int ncon = 0, nefc = 0, nlimit = 0, solver_iter = 0, overflow = 0;
   float com[3] = {0, 0, 0};
   unsigned stage_ncon = 0, stage_nefc = 0;  // byte i = count at RK stage i (debug)
+  int work = 0;                              // work estimate of this step (for longest-first scheduling)
 
   if (mode == DMK_MODE_SETSTATE && !P.run_forward) {  // store only
     if (lane < DMK_NQ) st[DMS_QPOS + lane] = S.qpos[lane];
@@ -1399,6 +1400,7 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_
                                 P.ar_scratch + (size_t)env * (DMK_MAXROW - DMK_REGROW) * 64);
       nefc = S.info[1]; nlimit = S.info[2]; solver_iter = S.info[3]; overflow = S.info[4];
       if (it < 4) { stage_ncon |= (unsigned)(ncon & 0xFF) << (8 * it); stage_nefc |= (unsigned)(nefc & 0xFF) << (8 * it); }
+      work += 64 + (nefc > 0 ? 48 + 4 * nefc : 0) + nefc * solver_iter;
     }
     // ============================================================== end of forward evaluation
     if (it == 0 || (it == 4 && mode == DMK_MODE_FORCED && !after_reset)) {  // mj_checkAcc
@@ -1609,6 +1611,7 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_
   if (lane < DMK_NV) { st[DMS_QVEL + lane] = S.qvel[lane]; st[DMS_WARM + lane] = S.warm[lane]; }
   if (lane < DMK_NU) st[DMS_CTRL + lane] = S.ctrl[lane];
   if (lane == 0) { sti[DMS_IDX] = idx_curr; sti[DMS_EPLEN] = ep_len; st[DMS_EPREW] = ep_rew; sti[DMS_RCNT] = rcnt; }
+  if (P.cost && lane == 0) P.cost[env] = work;
 }
 
 // Uniform random actions in [-2, 2) for bench.py config 2 (same generator as the oracle driver).

@@ -57,6 +57,8 @@ typedef struct DmConfig {
   uint64_t seed;           /* counter-based RNG seed for reference-state-init resets */
   int32_t auto_reset;      /* 1: SubprocVecEnv worker semantics (reset inside step when done) */
   int32_t device;          /* HIP device ordinal */
+  int32_t lpt_schedule;    /* 1 (default): dm_step launches envs longest-first by last step's work estimate */
+  int32_t pad;
 } DmConfig;
 
 void dm_default_config(DmConfig *cfg);
@@ -115,6 +117,14 @@ int dm_set_counters(DmHandle h, const int32_t *idx_curr, const int32_t *episode_
  * => DM_DEBUG_STRIDE floats per env. Enabled by dm_set_debug(h, buf) with buf float[N*stride] or NULL. */
 #define DM_DEBUG_STRIDE 416
 int dm_set_debug(DmHandle h, float *debug_buf);
+
+/* Longest-first scheduling (DmConfig.lpt_schedule): 4096 envs are only ~2 rounds of resident wavefronts, so the
+ * step time is set by stragglers (envs with many active constraints / an auto-reset).  Every dm_step records a
+ * work estimate per env; the next dm_step bucket-sorts it on device (one tiny kernel) and hands the heavy envs to
+ * the first workgroups.  This only changes which env a workgroup picks up, never any result (tests: permutation
+ * invariance).  No reference counterpart: SubprocVecEnv workers are scheduled by the OS.
+ * dm_get_work copies the last estimates (device int32[N]) for inspection. */
+int dm_get_work(DmHandle h, int32_t *work_out, void *stream);
 
 /* Device-side uniform random actions in [-2,2) from the counter-based generator shared with the
  * oracle's baseline driver (oracle/dm_oracle.c: hash32), for bench.py config 2. */
