@@ -102,6 +102,9 @@ struct EnvLds {
       float cacc[DMK_NB][6], cfrc[DMK_NB][6], cfrcsub[DMK_NB][6];
     } v;
     struct {
+      float tr[20][DM_NV + 1];        // force-weighted constraint rows, transposed through LDS (finish)
+    } fin;
+    struct {
       float poly[2][16][3];
       float cand[8][8];               // dist, pos3, normal3, pad
       int32_t ncand;

@@ -1257,11 +1257,30 @@ __device__ __forceinline__ float fwd_constraint(GDev &T, const int lane, const i
       solver_iter = iter;
       PROF(8);
       // ---- qacc = qacc_smooth + L^-1 D^-1/2 sum_r f_r B_r
+      // v[k] = sum_r f_r B_r[k]: rows live in the lanes of their constraints, the result is wanted in the
+      // lanes of the dofs.  Few rows carry force, so transpose only those through LDS (34 writes per
+      // active row-lane, one read per active row per dof-lane); fall back to 34 wave reductions otherwise.
       float v = 0;
+      {
+        const bool actv = (lane < nefc) && (f != 0.f);
+        int nact;
+        const int slot = prefix_count(actv, lane, &nact);
+        if (nact <= 20) {
+          if (actv) {
 #pragma unroll
-      for (int k = 0; k < DMK_NV; k++) {
-        float s = wave_sum(f * J[k]);
-        if (lane == k) v = s;
+            for (int k = 0; k < DMK_NV; k++) S.u.fin.tr[slot][k] = f * J[k];
+          }
+          SYNC();
+          if (lane < DMK_NV)
+            for (int a = 0; a < nact; a++) v += S.u.fin.tr[a][lk];
+          SYNC();
+        } else {
+#pragma unroll
+          for (int k = 0; k < DMK_NV; k++) {
+            float s = wave_sum(f * J[k]);
+            if (lane == k) v = s;
+          }
+        }
       }
       const int mrow = T.d_madr[lk] + T.d_nanc[lk];
       const uint64_t ancm = T.d_ancm[lk];
