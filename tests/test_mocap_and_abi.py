@@ -94,3 +94,11 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "dm_oracle.h" not in src, f
+
+
+def test_generated_topology_header_matches_the_xml(model):
+    """csrc/dm_topology.h (constexpr dof tree the kernels are specialised to) must be in sync with the asset."""
+    from deepmimic_mujoco_amd import gen_topology
+    assert open(gen_topology.OUT).read() == gen_topology.render(model)
+    parent = list(model.dof_parent)
+    assert parent[:7] == [-1, 0, 1, 2, 3, 4, 5] and parent[20] == 5 and parent[27] == 5 and parent[12] == 8
