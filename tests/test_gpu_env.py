@@ -199,3 +199,24 @@ def test_hip_graph_update_matches_eager():
         outs.append(torch.cat([p.detach().reshape(-1) for p in ppo.policy.parameters()]).cpu())
     assert torch.isfinite(outs[0]).all()
     assert torch.allclose(outs[0], outs[1], rtol=1e-4, atol=1e-6), (outs[0] - outs[1]).abs().max()
+
+
+def test_max_size_batch_and_tiny_batch(model, clips):
+    """BASELINE config 5 size (65 536 envs on one GPU's share = 8 192; here the full 65 536 on one GPU) and N = 1."""
+    import torch
+    from deepmimic_mujoco_amd._lib import HipEngine
+    for n in (1, 3, 65536):
+        eng = HipEngine(model, n)
+        eng.load_clip(0, clips["walk"])
+        out = eng.alloc_outputs()
+        eng.reset(out["obs"])
+        act = torch.zeros(n, 28, device=eng.device)
+        for i in range(3):
+            eng.fill_random_actions(act, i)
+            eng.step(act, out)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out["obs"]).all() and torch.isfinite(out["rew"]).all()
+        assert out["obs"].abs().max() <= 100.0
+        w = eng.get_work()
+        assert w.shape == (n,) and int(w.min()) > 0
+        eng.close()
