@@ -261,3 +261,71 @@ def test_thousand_step_teacher_forced_trajectory(model, clips, oracle_clips, tor
     print("1000 steps: qpos max %.3g (flips excluded: %d), qvel max %.3g" % (res["qpos"][ok].max(), (~ok).sum(), res["qvel"][ok].max()))
     assert len(res["qpos"]) == 1000 and ok.sum() >= 990
     assert res["qpos"][ok].max() < TOL_QPOS
+
+
+def test_narrowphase_coverage_all_pair_types(model, clips, oracle_clips, torch_mod):
+    """Random self-colliding poses (joint angles over their full ranges, root in the air or near the floor)
+    so that every pair-type routine fires, including capsule-box and box-box; contact lists (geom ids in
+    canonical order), distances and the resulting qacc must agree with the oracle."""
+    from oracle.oracle import OracleSim
+    torch = torch_mod
+    rng = np.random.default_rng(2024)
+    lo, hi = model.jnt_range[1:, 0], model.jnt_range[1:, 1]
+    s = OracleSim(model)
+    s.set_caps(32, 64)
+    want = {(0, 2): 8, (0, 3): 8, (0, 6): 8, (2, 2): 8, (2, 3): 12, (2, 6): 12, (3, 3): 12, (3, 6): 16, (6, 6): 16}
+    got = {k: 0 for k in want}
+    samples = []
+    tries = 0
+    while any(got[k] < want[k] for k in want) and tries < 60000:
+        tries += 1
+        q = model.qpos0.copy()
+        q[7:] = rng.uniform(lo, hi)
+        if rng.random() < 0.5:                       # bias towards feet/legs meeting
+            q[7 + 13:7 + 28] = rng.uniform(lo[13:], hi[13:]) * rng.uniform(0.2, 1.0)
+        quat = rng.normal(size=4)
+        q[3:7] = quat / np.linalg.norm(quat)
+        q[2] = rng.choice([2.0, 2.0, rng.uniform(0.2, 1.0)])
+        v = rng.normal(size=34) * 0.5
+        if s.set_state(q, v) != 0:
+            continue
+        con = s.get("contact")
+        if len(con) == 0 or len(con) > 30 or s.nefc > 60:
+            continue
+        if np.any(np.abs(con[:, 0] - 0.001) < 2e-5):   # keep away from the activation threshold
+            continue
+        types = {(int(model.geom_type[int(c[13])]), int(model.geom_type[int(c[14])])) for c in con}
+        need = [t for t in types if t in want and got[t] < want[t]]
+        if not need:
+            continue
+        for t in types:
+            if t in got:
+                got[t] += 1
+        samples.append((q, v, con.copy(), s.get("qacc").copy(), s.nefc))
+    print("narrowphase samples", len(samples), "tries", tries, got)
+    assert all(got[k] >= want[k] for k in want), got
+    n = len(samples)
+    eng = _engine(model, clips, n, torch)
+    dbg = eng.enable_debug()
+    dev = eng.device
+    Q = torch.tensor(np.array([x[0] for x in samples]), dtype=torch.float32, device=dev)
+    V = torch.tensor(np.array([x[1] for x in samples]), dtype=torch.float32, device=dev)
+    out = eng.alloc_outputs()
+    eng.step_forced(Q, V, out)        # set_state + forward from a zero warm start, as the oracle did
+    torch.cuda.synchronize()
+    d = dbg.cpu().numpy()
+    worst_dist, worst_acc = 0.0, 0.0
+    for i, (q, v, con, qacc, nefc) in enumerate(samples):
+        ncon = int(d[i, 242])
+        gpu = [(int(d[i, 256 + 3 * c]), int(d[i, 257 + 3 * c])) for c in range(ncon)]
+        ora = [(int(c[13]), int(c[14])) for c in con]
+        assert gpu == ora, (i, gpu, ora)
+        assert int(d[i, 243]) == nefc
+        gd = np.array([d[i, 258 + 3 * c] for c in range(ncon)])
+        worst_dist = max(worst_dist, np.abs(gd - con[:, 0]).max())
+        scale = max(1.0, np.abs(qacc).max())
+        worst_acc = max(worst_acc, np.abs(d[i, 174:208] - qacc).max() / scale)
+    print("contact dist max err %.3g, qacc max rel err %.3g" % (worst_dist, worst_acc))
+    assert worst_dist < 2e-6
+    assert worst_acc < 2e-3
+    eng.close()
