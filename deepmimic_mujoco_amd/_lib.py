@@ -23,7 +23,8 @@ REASONS = {0: None, 1: "low_z", 2: "high_z", 3: "max_ep_len", 4: "acyclical_end"
 EXPORTS = ["dm_default_config", "dm_create", "dm_destroy", "dm_last_error", "dm_num_envs",
            "dm_load_clip", "dm_set_env_clips", "dm_reset", "dm_step", "dm_step_forced",
            "dm_set_state", "dm_get_state", "dm_get_counters", "dm_set_counters", "dm_set_debug",
-           "dm_fill_random_actions", "dm_last_step_ms", "dm_enable_timing", "dm_get_work"]
+           "dm_fill_random_actions", "dm_last_step_ms", "dm_enable_timing", "dm_get_work",
+           "dm_set_clip_flags"]
 
 
 class DmConfig(C.Structure):
@@ -70,6 +71,7 @@ def load_library():
     L.dm_set_counters.argtypes = [vp, vp, vp, vp]
     L.dm_set_debug.argtypes = [vp, vp]
     L.dm_get_work.argtypes = [vp, vp, vp]
+    L.dm_set_clip_flags.argtypes = [vp, i32, i32]
     L.dm_fill_random_actions.argtypes = [vp, vp, C.c_uint32, vp]
     L.dm_last_step_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.dm_enable_timing.argtypes = [vp, i32]
@@ -134,12 +136,13 @@ class HipEngine:
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
 
     # ---- clips
-    def load_clip(self, clip_id, mocap):
+    def load_clip(self, clip_id, mocap, floor=False, acyclic=False):
         q, v, b, g = [np.ascontiguousarray(a, np.float64) for a in mocap.tables()]
         self._chk(self.L.dm_load_clip(self.h, clip_id, len(q), q.ctypes.data_as(C.c_void_p),
                                       v.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
                                       g.ctypes.data_as(C.c_void_p)), "dm_load_clip")
         self.clip_len[clip_id] = len(q)
+        self._chk(self.L.dm_set_clip_flags(self.h, clip_id, (1 if floor else 0) | (2 if acyclic else 0)), "dm_set_clip_flags")
 
     def set_env_clips(self, clip_ids):
         t = None if clip_ids is None else clip_ids.to(self.device, self.torch.int32).contiguous()

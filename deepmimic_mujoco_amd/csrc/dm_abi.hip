@@ -24,6 +24,7 @@ struct DmEngine {
   float *dClipRows[DM_MAX_CLIPS] = {nullptr};
   float *dClipReset[DM_MAX_CLIPS] = {nullptr};
   int clipL[DM_MAX_CLIPS] = {0};
+  int clipFlags[DM_MAX_CLIPS] = {0};
   float *debug = nullptr;
   int32_t *dOrder = nullptr;   // slot -> env permutation for dm_step (longest-first)
   int32_t *dCost = nullptr;    // per-env work estimate written by dm_step
@@ -295,6 +296,12 @@ __global__ void dm_get_state_kernel(const float *state, const int32_t *ids, int 
   if (ctrl && lane < DM_NU) ctrl[(size_t)slot * DM_NU + lane] = st[DMS_CTRL + lane];
 }
 
+extern "C" int dm_set_clip_flags(DmHandle e, int clip_id, int flags) {
+  if (!e || clip_id < 0 || clip_id >= DM_MAX_CLIPS) return DM_EINVAL;
+  e->clipFlags[clip_id] = flags;
+  return DM_OK;
+}
+
 extern "C" int dm_set_env_clips(DmHandle e, const int32_t *clip_ids, void *stream) {
   if (!e) return DM_EINVAL;
   HIPCHK(e, hipSetDevice(e->cfg.device));
@@ -308,7 +315,7 @@ static void fill_launch(DmEngine *e, DmLaunch &P, int mode) {
   P.T = e->dT;
   P.state = e->dState;
   P.ar_scratch = e->dArScratch;
-  for (int i = 0; i < DM_MAX_CLIPS; i++) { P.clips[i].rows = e->dClipRows[i]; P.clips[i].reset = e->dClipReset[i]; P.clips[i].L = e->clipL[i]; }
+  for (int i = 0; i < DM_MAX_CLIPS; i++) { P.clips[i].rows = e->dClipRows[i]; P.clips[i].reset = e->dClipReset[i]; P.clips[i].L = e->clipL[i]; P.clips[i].flags = e->clipFlags[i]; }
   P.N = e->N; P.mode = mode; P.auto_reset = e->cfg.auto_reset; P.max_ep_length = e->cfg.max_ep_length;
   P.vel_obs_scale = e->cfg.vel_obs_scale; P.low_z = e->cfg.low_z; P.high_z = e->cfg.high_z; P.obs_bound = e->cfg.obs_bound;
   P.w_pose = e->cfg.w_pose; P.w_vel = e->cfg.w_vel; P.w_ee = e->cfg.w_end_eff; P.w_com = e->cfg.w_com; P.w_jl = e->cfg.w_joint_limit;

@@ -134,7 +134,7 @@ struct EnvLds {
 struct DmClipDev {
   const float *rows;    // L x DMK_CLIP_ROW
   const float *reset;   // L x DMK_RESET_ROW : qpos 35 | qvel 34
-  int32_t L, pad;
+  int32_t L, flags;     // flags: DM_CLIP_FLOOR | DM_CLIP_ACYCLIC
 };
 
 enum { DMK_MODE_STEP = 0, DMK_MODE_FORCED = 1, DMK_MODE_RESET = 2, DMK_MODE_SETSTATE = 3 };

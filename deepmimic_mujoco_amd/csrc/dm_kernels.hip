@@ -1556,9 +1556,14 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_
         reward = P.w_pose * r_cfg + P.w_vel * r_vel + P.w_ee * r_ee + P.w_com * r_com + P.w_jl * qlim;
         // ---- termination (:418-442)
         const float zc = S.com[2];
-        done = (zc < P.low_z) || (zc > P.high_z);
-        reason = (zc < P.low_z) ? DM_REASON_LOW_Z : DM_REASON_HIGH_Z;
+        done = false;
+        reason = DM_REASON_NONE;
+        if (!(clip.flags & DM_CLIP_FLOOR)) {                      // :420-424 (written every step, even when not done)
+          done = (zc < P.low_z) || (zc > P.high_z);
+          reason = (zc < P.low_z) ? DM_REASON_LOW_Z : DM_REASON_HIGH_Z;
+        }
         if (P.max_ep_length != 0 && ep_len >= P.max_ep_length) { done = true; reason = DM_REASON_MAX_EP_LEN; }
+        if ((clip.flags & DM_CLIP_ACYCLIC) && idx_curr + 1 == clip.L) { done = true; reason = DM_REASON_ACYCLIC_END; }  // :440-442
         // ---- post-step counters (:452-455)
         idx_curr = (idx_curr + 1) % clip.L;
         ep_rew += reward;

@@ -165,7 +165,9 @@ class DPEnv:
         self.mocap.load_mocap(filepath)
         self.mocap_dt = self.mocap.dt
         self.mocap_data_len = len(self.mocap.data_config)
-        self._eng.load_clip(0, self.mocap)
+        mcfg = self.motion_config
+        self._eng.load_clip(0, self.mocap, floor=mcfg.motion in mcfg.floor_motions,
+                            acyclic=mcfg.motion in mcfg.acyclical_motions)
 
     def reference_state_init(self, idx_init=None):     # deepmimic_env.py:312-316
         self.idx_init = random.randint(0, self.mocap_data_len - 1)
@@ -293,7 +295,8 @@ class HipDeepMimicVecEnv(_SB3VecEnv):
         for cid, m in enumerate(self.motions):
             mc = MocapDM(robot=robot, model=self.model)
             mc.load_mocap(MotionConfig(m, robot).mocap_path)
-            self.engine.load_clip(cid, mc)
+            mcfg = MotionConfig(m, robot)
+            self.engine.load_clip(cid, mc, floor=m in mcfg.floor_motions, acyclic=m in mcfg.acyclical_motions)
             self.mocaps.append(mc)
         if len(self.motions) > 1:
             ids = torch.arange(self.num_envs, device=self.engine.device) % len(self.motions)

@@ -179,13 +179,21 @@ class MocapDM:
             raise NotImplementedError("only the default 'continuity' mode is restated")
         with open(filepath, "r") as fin:
             data = json.load(fin)
-        if "Format" in data:
-            raise NotImplementedError("direct_qpos clips are a 'next' row (SURVEY §8f-3)")
         motions = np.array(data["Frames"], dtype=np.float64)
         self.loop = data.get("Loop")
         self.dt = float(motions[0][0])
         self.motion_name = os.path.splitext(os.path.basename(filepath))[0]
         vmx = 5.0 if "getup" in filepath else 10.0
+        if "Format" in data:
+            # "direct_qpos" clips (mocap_v2.py:271-272, written by src/retarget.py:176-190): frames are
+            # [dt, qpos...] already in MuJoCo order; velocities / FK tables / interpolation follow as usual.
+            if data["Format"] != "direct_qpos" or motions.shape[1] != 1 + _model.NQ:
+                raise NotImplementedError("unsupported mocap Format %r / width %d" % (data["Format"], motions.shape[1]))
+            self.all_states = []
+            self.singularity_fired = 0
+            self.data_config = [row[1:].copy() for row in motions]
+            self._finish_tables(self.data_config)
+            return
 
         # per-frame aligned states (mocap_v2.py:56-77)
         all_states = []
@@ -223,7 +231,9 @@ class MocapDM:
                 row += list(eul)
             configs.append(np.array(row))
         self.data_config = configs
+        self._finish_tables(configs)
 
+    def _finish_tables(self, configs):
         # velocities (mocap_v2.py:274-289)
         vels = []
         for k in range(len(configs)):

@@ -74,6 +74,12 @@ int dm_num_envs(DmHandle h);
  * HOST float64 tables: qpos[L*35], qvel[L*34], body_xpos[L*14*3], geom_xpos[L*16*3]. */
 int dm_load_clip(DmHandle h, int clip_id, int L, const double *host_qpos, const double *host_qvel,
                  const double *host_body_xpos, const double *host_geom_xpos);
+/* Clip flags: MotionConfig.floor_motions / acyclical_motions membership (src/config.py:36-37):
+ * DM_CLIP_FLOOR skips the low/high COM termination (deepmimic_env.py:420), DM_CLIP_ACYCLIC ends the episode
+ * when the last frame is reached (:440-442). */
+#define DM_CLIP_FLOOR 1
+#define DM_CLIP_ACYCLIC 2
+int dm_set_clip_flags(DmHandle h, int clip_id, int flags);
 /* Per-env clip assignment (device int32[N]; NULL = all envs use clip 0). */
 int dm_set_env_clips(DmHandle h, const int32_t *clip_ids, void *stream);
 

@@ -1117,9 +1117,12 @@ int dmo_env_step(const DmModel *m, DmoData *d, DmoEnv *e, const DmoClip *clip, c
   double mt = 0, zc = 0;                                          /* :420-424 */
   for (int b = 0; b < NB; b++) { mt += m->body_mass[b]; zc += m->body_mass[b] * d->xipos[b][2]; }
   zc /= mt;
-  done = (zc < 0.7) || (zc > 2.0);
-  *reason = (zc < 0.7) ? DMO_REASON_LOW_Z : DMO_REASON_HIGH_Z;    /* written every step (:424) */
+  if (!(clip->flags & 1)) {                                       /* :420 not a floor motion */
+    done = (zc < 0.7) || (zc > 2.0);
+    *reason = (zc < 0.7) ? DMO_REASON_LOW_Z : DMO_REASON_HIGH_Z;  /* written every step (:424) */
+  }
   if (e->episode_length >= 1000) { done = 1; *reason = DMO_REASON_MAX_EP_LEN; } /* :435-438 */
+  if ((clip->flags & 2) && e->idx_curr + 1 == clip->L) { done = 1; *reason = DMO_REASON_ACYCLIC_END; } /* :440-442 */
   e->idx_curr = (e->idx_curr + 1) % clip->L;                      /* :452 */
   e->episode_reward += *reward;
   e->episode_length += 1;

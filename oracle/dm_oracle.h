@@ -78,6 +78,8 @@ typedef struct DmoClip {
   const double *qvel;      /* L x 34 */
   const double *body_xpos; /* L x 14 x 3 */
   const double *geom_xpos; /* L x 16 x 3 */
+  int32_t flags;           /* 1 floor motion, 2 acyclical motion (src/config.py:36-37) */
+  int32_t pad;
 } DmoClip;
 
 /* per-env task state (DPEnv attributes idx_curr, episode_length, ...) */

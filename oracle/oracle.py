@@ -19,7 +19,7 @@ _LIB = None
 
 class _Clip(C.Structure):
     _fields_ = [("L", C.c_int32), ("qpos", C.c_void_p), ("qvel", C.c_void_p),
-                ("body_xpos", C.c_void_p), ("geom_xpos", C.c_void_p)]
+                ("body_xpos", C.c_void_p), ("geom_xpos", C.c_void_p), ("flags", C.c_int32), ("pad", C.c_int32)]
 
 
 class _Env(C.Structure):
@@ -67,14 +67,15 @@ def _p(a):
 
 
 class OracleClip:
-    def __init__(self, qpos, qvel, body_xpos, geom_xpos):
+    def __init__(self, qpos, qvel, body_xpos, geom_xpos, floor=False, acyclic=False):
         self.qpos = np.ascontiguousarray(qpos, np.float64).reshape(-1, NQ)
         self.qvel = np.ascontiguousarray(qvel, np.float64).reshape(-1, NV)
         self.body_xpos = np.ascontiguousarray(body_xpos, np.float64).reshape(-1, NBODY, 3)
         self.geom_xpos = np.ascontiguousarray(geom_xpos, np.float64).reshape(-1, NGEOM, 3)
         self.L = len(self.qpos)
         self.c = _Clip(self.L, _p(self.qpos).value, _p(self.qvel).value,
-                       _p(self.body_xpos).value, _p(self.geom_xpos).value)
+                       _p(self.body_xpos).value, _p(self.geom_xpos).value,
+                       (1 if floor else 0) | (2 if acyclic else 0), 0)
 
 
 class OracleSim:

@@ -220,3 +220,32 @@ def test_max_size_batch_and_tiny_batch(model, clips):
         w = eng.get_work()
         assert w.shape == (n,) and int(w.min()) > 0
         eng.close()
+
+
+def test_floor_and_acyclic_motion_semantics(model):
+    """getup_facedown is a floor + acyclical motion (src/config.py:36-37): no low/high COM termination
+    (deepmimic_env.py:420), episode ends with 'acyclical_end' on the last frame (:440-442)."""
+    from deepmimic_mujoco_amd.config import MotionConfig
+    from deepmimic_mujoco_amd.deepmimic_env import DPEnv
+    from deepmimic_mujoco_amd.mocap import MocapDM
+    from oracle.oracle import OracleClip, OracleSim
+    env = DPEnv(motion="getup_facedown")
+    mc = MocapDM(model=model)
+    mc.load_mocap(MotionConfig("getup_facedown").mocap_path)
+    oc = OracleClip(*mc.tables(), floor=True, acyclic=True)
+    s = OracleSim(model)
+    s.set_caps(32, 64)
+    L = env.mocap_data_len
+    env.reset_model(idx_init=L - 6)
+    s.env_reset(oc, L - 6)
+    for t in range(6):
+        i = env.idx_curr
+        fs = (mc.data_config[i], mc.data_vel[i])
+        o, r, d, info = env.step(np.zeros(28), force_state=fs)
+        eo, er, ed, et, ereason = s.env_step(oc, np.zeros(28), force_state=fs)
+        assert d == ed and abs(r - er) < 1e-4 and np.abs(o - eo).max() < 2e-3
+        if t < 5:
+            assert not d and "done_reason" not in info        # lying on the floor (COM z < 0.7) does not terminate
+        else:
+            assert d and info["done_reason"] == "acyclical_end" and ereason == 4
+    env.close()

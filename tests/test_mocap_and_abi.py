@@ -102,3 +102,42 @@ def test_generated_topology_header_matches_the_xml(model):
     assert open(gen_topology.OUT).read() == gen_topology.render(model)
     parent = list(model.dof_parent)
     assert parent[:7] == [-1, 0, 1, 2, 3, 4, 5] and parent[20] == 5 and parent[27] == 5 and parent[12] == 8
+
+
+def test_all_humanoid3d_clips_of_the_reference(model):
+    """Every humanoid3d clip the reference ships either loads or raises exactly as mocap_v2.py:313-316 does
+    (backflip dt 0.0625 and spin dt 0.041667 are not integer multiples of the simulator step)."""
+    from deepmimic_mujoco_amd.config import MotionConfig
+    from deepmimic_mujoco_amd.mocap import MocapDM
+    expect = {"cartwheel": 164, "crawl": 177, "dance_a": 98, "getup_facedown": 183, "getup_faceup": 227, "jump": 107,
+              "kick": 92, "punch": 128, "roll": 121}          # kick/punch: dt 0.0333 -> (n-1)*2 frames
+    for name, L in expect.items():
+        mc = MocapDM(model=model)
+        mc.load_mocap(MotionConfig(name).mocap_path)
+        assert len(mc.data_config) == L, (name, len(mc.data_config))
+        q, v, b, g = mc.tables()
+        assert np.isfinite(q).all() and np.isfinite(v).all() and np.isfinite(g).all()
+    for name in ("backflip", "spin"):
+        with pytest.raises(Exception, match="Invalid dt ratio"):
+            MocapDM(model=model).load_mocap(MotionConfig(name).mocap_path)
+    cfg = MotionConfig("getup_facedown")
+    assert cfg.motion in cfg.floor_motions and cfg.motion in cfg.acyclical_motions
+
+
+def test_direct_qpos_format_round_trip(tmp_path, model, clips):
+    """mocap_v2.py:271-272: a "Format": "direct_qpos" file carries qpos rows verbatim."""
+    import json
+    from deepmimic_mujoco_amd.mocap import MocapDM
+    src = clips["spinkick"]                       # dt 0.016666: no interpolation, so tables must match exactly
+    frames = [[src.dt] + list(map(float, q)) for q in src.data_config]
+    p = tmp_path / "humanoid3d_direct.txt"
+    p.write_text(json.dumps({"Loop": "wrap", "Format": "direct_qpos", "Frames": frames}))
+    mc = MocapDM(model=model)
+    mc.load_mocap(str(p))
+    q0, v0, b0, g0 = src.tables()
+    q1, v1, b1, g1 = mc.tables()
+    assert np.array_equal(q0, q1) and np.allclose(v0, v1) and np.allclose(g0, g1) and np.allclose(b0, b1)
+    bad = tmp_path / "bad.txt"
+    bad.write_text(json.dumps({"Format": "direct_qpos", "Frames": [[0.0166] + [0.0] * 44]}))
+    with pytest.raises(NotImplementedError):
+        MocapDM(model=model).load_mocap(str(bad))       # 44-wide rows are the Unitree G1's qpos (out of scope)
