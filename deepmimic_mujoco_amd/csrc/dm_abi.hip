@@ -199,7 +199,7 @@ extern "C" int dm_create(const DmModel *model, const DmConfig *cfg, DmHandle *ou
   for (int i = 0; i < e->N; i++)
     for (int k = 0; k < DM_NQ; k++) init[(size_t)i * DMK_STATE_STRIDE + DMS_QPOS + k] = (float)model->qpos0[k];
   hipMemcpy(e->dState, init.data(), sb, hipMemcpyHostToDevice);
-  if (hipMalloc(&e->dArScratch, (size_t)e->N * (DMK_MAXROW - DMK_REGROW) * 64 * sizeof(float)) != hipSuccess) {
+  if (hipMalloc(&e->dArScratch, (size_t)e->N * DMK_MAXROW * DMK_MAXROW * sizeof(float)) != hipSuccess) {
     hipFree(e->dState); hipFree(e->dT); delete e; return DM_ENOMEM;
   }
   if (hipMalloc(&e->dOrder, e->N * sizeof(int32_t)) != hipSuccess || hipMalloc(&e->dCost, e->N * sizeof(int32_t)) != hipSuccess) {

@@ -20,7 +20,8 @@
 #define DMK_NB DM_NBODY
 #define DMK_NG DM_NGEOM
 #define DMK_MAXCON DM_MAXCON   // contact slots per forward evaluation
-#define DMK_MAXROW DM_MAXROW   // constraint rows per forward evaluation (= wave width)
+#define DMK_MAXROW DM_MAXROW   // constraint rows per forward evaluation
+#define DMK_LANEROW 64         // one row per lane up to here; 65..128 rows take the two-rows-per-lane path
 #define DMK_REGROW 32          // A-matrix columns kept in registers; columns 32..63 spill to ar_scratch
 #define DMK_MSTRIDE 35         // dense tree-sparse M, odd stride: conflict-free rows and columns
 #define DMK_MAXANC 12          // deepest dof has 12 ancestors (root 6 + hip 3 + knee 1 + ankle x,y)
@@ -142,7 +143,7 @@ enum { DMK_MODE_STEP = 0, DMK_MODE_FORCED = 1, DMK_MODE_RESET = 2, DMK_MODE_SETS
 struct DmLaunch {
   const DmDev *T;
   float *state;                 // N x DMK_STATE_STRIDE
-  float *ar_scratch;            // N x 32 x 64: A-matrix columns 32..63 (only touched when nefc > 32)
+  float *ar_scratch;            // N x 128 x 128: A-matrix columns beyond the register-resident 32 (touched only when nefc > 32)
   DmClipDev clips[8];
   int32_t N, nslots, mode, auto_reset, max_ep_length;
   float vel_obs_scale, low_z, high_z, obs_bound;

@@ -1023,6 +1023,204 @@ __device__ __forceinline__ int fwd_collide(GDev &T, const int lane) {
   return ncon | (overflow << 8);
 }
 
+// ---- one constraint row (limit or pyramid edge / frictionless contact) for the calling lane:
+// Jacobian row -> reference acceleration, regulariser -> B row = D^-1/2 L^-T J^T (returned in J)
+__device__ __forceinline__ void build_row(GDev &T, EnvLds &S, const int r, const int nefc, const float (&com)[3],
+                                          float (&J)[DMK_NV], float &R, float &Dd, float &aref, float &bb, float &jw) {
+      float rpos = 0, rmargin = 0, rdiag = 1, mu = 0;
+      int rtype = -1, full = 0;
+      float wl[3] = {0, 0, 0}, wa[3] = {0, 0, 0};
+      unsigned long long cm1 = 0, cm2 = 0;
+      int ldof = -1;
+      float lsign = 0;
+      if (r < nefc) {
+        int info = S.rowinfo[r];
+        if (info < 0) {
+          int v = -info - 1;
+          ldof = v >> 1;
+          lsign = (v & 1) ? -1.f : 1.f;
+          rtype = 0;
+          float q = S.qpos[ldof + 1];
+          rpos = (v & 1) ? (T.d_hi[ldof] - q) : (q - T.d_lo[ldof]);
+          rmargin = 0;
+          rdiag = T.d_invw[ldof];
+        } else {
+          int ci = (info >> 3) & 0x3F, e = info & 7;
+          full = (info & 0x4000) ? 1 : 0;
+          int g1 = S.c_g1[ci], g2 = S.c_g2[ci];
+          int b1 = T.g_body[g1], b2 = T.g_body[g2];
+          int cd1 = T.g_condim[g1], cd2 = T.g_condim[g2];
+          int dim = cd1 > cd2 ? cd1 : cd2;
+          mu = fmaxf(T.g_mu[g1], T.g_mu[g2]);
+          float fr[9];
+          for (int i = 0; i < 9; i++) fr[i] = S.c_frame[ci][i];
+          float tran = T.b_invw[b1] + T.b_invw[b2];
+          if (dim < 3) {
+            rtype = 1;
+            wl[0] = fr[0]; wl[1] = fr[1]; wl[2] = fr[2];
+            rdiag = tran;
+          } else {
+            rtype = 2;
+            const bool second = (e >> 1) != 0;   // tangent 2 for edges 2,3
+            const float tx = second ? fr[6] : fr[3], ty = second ? fr[7] : fr[4], tz = second ? fr[8] : fr[5];
+            float sg = (e & 1) ? -mu : mu;
+            wl[0] = fr[0] + sg * tx; wl[1] = fr[1] + sg * ty; wl[2] = fr[2] + sg * tz;
+            rdiag = tran + mu * mu * tran;
+          }
+          float off[3] = {S.c_pos[ci][0] - com[0], S.c_pos[ci][1] - com[1], S.c_pos[ci][2] - com[2]};
+          cross3(wa, off, wl);
+          cm1 = T.b_chain[b1]; cm2 = T.b_chain[b2];
+          rpos = S.c_dist[ci];
+          rmargin = fmaxf(T.g_margin[g1], T.g_margin[g2]);
+        }
+      }
+      float vel = 0, jqs = 0;
+      jw = 0;
+#pragma unroll
+      for (int k = 0; k < DMK_NV; k++) {
+        const float4 ca = *reinterpret_cast<const float4 *>(&S.cdof[k][0]);
+        const float2 cb = *reinterpret_cast<const float2 *>(&S.cdof[k][4]);
+        float val = ca.x * wa[0] + ca.y * wa[1] + ca.z * wa[2] + ca.w * wl[0] + cb.x * wl[1] + cb.y * wl[2];
+        float sg = (float)((int)((cm2 >> k) & 1ull) - (int)((cm1 >> k) & 1ull));
+        float j = sg * val;
+        if (rtype == 0) j = (k == ldof) ? lsign : 0.f;
+        if (rtype < 0) j = 0.f;
+        J[k] = j;
+        vel += j * S.qvel[k];
+        jqs += j * S.qacc_smooth[k];
+        jw += j * S.warm[k];
+      }
+      R = 1; Dd = 0; aref = 0; bb = 0;
+      if (r < nefc) {
+        float sol[5] = {T.solimp[0], T.solimp[1], T.solimp[2], T.solimp[3], T.solimp[4]};
+        float imp = impedance(sol, rpos, rmargin);
+        R = fmaxf(MINVALF, (1 - imp) * rdiag / imp);
+        if (rtype == 2 && full) R = 2 * mu * mu * R;
+        aref = -T.B * vel - T.K * imp * (rpos - rmargin);
+        bb = jqs - aref;
+        Dd = 1.0f / R;
+      }
+      // ---- B row = D^-1/2 L^-T J^T, in place (lane = row)
+      {
+        // x <- L^-T x on the row held by this lane: only the 276 ancestor pairs of the dof tree, all
+        // register and LDS indices static (dm_topology.h); factor entries are wave-uniform broadcasts.
+        // Step i's loads are tied to step i+1's result so they are not all hoisted ahead of the FMAs.
+        lds_cfloat_p Mp = (lds_cfloat_p)S.M;
+#pragma unroll
+        for (int i = DMK_NV - 1; i >= 1; i--) {
+          const float xi = J[i] * S.dinv[i];
+          asm volatile("" : "+v"(Mp), "+v"(J[0]));
+#pragma unroll
+          for (int j = 0; j < i; j++)
+            if (topo::is_anc(j, i)) J[j] -= Mp[topo::midx(i, j)] * xi;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < DMK_NV; k++) J[k] *= S.dsqrtinv[k];
+}
+
+// ---- wide constraint path, 64 < nefc <= 128 (lying / getting-up poses: ~20 floor contacts x 4 pyramid rows).
+// Every lane carries two rows (lane and lane + 64); the whole A matrix streams through a per-env global
+// scratch (column i at ar[i * 128 + row]), one column prefetched ahead of the Gauss-Seidel update.  Rare and
+// out of line so that it costs the common path neither registers nor instruction cache.
+__device__ __noinline__ float fwd_constraint_wide(GDev &T, const int lane, const int nefc, const float xs, const float dv,
+                                                  float *ar) {
+  EnvLds &S = g_S;
+  const int lk = lane < DMK_NV ? lane : 0;
+  const float com[3] = {S.com[0], S.com[1], S.com[2]};
+  float Ja[DMK_NV], Jb[DMK_NV];
+  float Ra, Da, arefa, bba, jwa, Rb, Db, arefb, bbb, jwb;
+  build_row(T, S, lane, nefc, com, Ja, Ra, Da, arefa, bba, jwa);
+  build_row(T, S, lane + 64, nefc, com, Jb, Rb, Db, arefb, bbb, jwb);
+  float ARda = Ra, ARdb = Rb;
+#pragma unroll
+  for (int k = 0; k < DMK_NV; k++) { ARda += Ja[k] * Ja[k]; ARdb += Jb[k] * Jb[k]; }
+  const bool va = lane < nefc, vb = lane + 64 < nefc;
+#pragma unroll 1
+  for (int i = 0; i < nefc; i++) {
+    const int src = i & 63;
+    float acca = 0, accb = 0;
+    if (i < 64) {
+#pragma unroll
+      for (int k = 0; k < DMK_NV; k++) { const float bi = rl(Ja[k], src); acca = fmaf(Ja[k], bi, acca); accb = fmaf(Jb[k], bi, accb); }
+      if (lane == src) acca += Ra;
+    } else {
+#pragma unroll
+      for (int k = 0; k < DMK_NV; k++) { const float bi = rl(Jb[k], src); acca = fmaf(Ja[k], bi, acca); accb = fmaf(Jb[k], bi, accb); }
+      if (lane == src) accb += Rb;
+    }
+    ar[i * 128 + lane] = acca;
+    ar[i * 128 + 64 + lane] = accb;
+  }
+  const float ARinva = va ? 1.0f / ARda : 0.f, ARinvb = vb ? 1.0f / ARdb : 0.f;
+  // warm start
+  float fa = 0, fb = 0, ra = bba, rb = bbb;
+  {
+    const float jara = jwa - arefa, jarb = jwb - arefb;
+    const float fwa = (va && jara < 0) ? -Da * jara : 0.f, fwb = (vb && jarb < 0) ? -Db * jarb : 0.f;
+    float rwa = bba, rwb = bbb;
+#pragma unroll 1
+    for (int i = 0; i < nefc; i++) {
+      const float fi = (i < 64) ? rl(fwa, i & 63) : rl(fwb, i & 63);
+      rwa = fmaf(ar[i * 128 + lane], fi, rwa);
+      rwb = fmaf(ar[i * 128 + 64 + lane], fi, rwb);
+    }
+    const float cost = wave_sum(fwa * (0.5f * (rwa - bba) + bba) + fwb * (0.5f * (rwb - bbb) + bbb));
+    if (!(cost > 0)) { fa = fwa; fb = fwb; ra = rwa; rb = rwb; }
+  }
+  const float scale = T.pgs_scale, tol = T.tolerance;
+  int iter = 0;
+  while (iter < T.iterations) {
+    float impv = 0;
+    float na = ar[lane], nb = ar[64 + lane];
+#pragma unroll 1
+    for (int i = 0; i < nefc; i++) {
+      const float ca = na, cb = nb;
+      if (i + 1 < nefc) { na = ar[(i + 1) * 128 + lane]; nb = ar[(i + 1) * 128 + 64 + lane]; }
+      const int src = i & 63;
+      float dli;
+      if (i < 64) {
+        const float fn = fmaxf(0.f, fmaf(-ra, ARinva, fa));
+        const float dl = fn - fa;
+        const float t = dl * fmaf(0.5f * dl, ARda, ra);
+        dli = rl(dl, src);
+        impv -= rl(t, src);
+        fa = (lane == src) ? fn : fa;
+      } else {
+        const float fn = fmaxf(0.f, fmaf(-rb, ARinvb, fb));
+        const float dl = fn - fb;
+        const float t = dl * fmaf(0.5f * dl, ARdb, rb);
+        dli = rl(dl, src);
+        impv -= rl(t, src);
+        fb = (lane == src) ? fn : fb;
+      }
+      ra = fmaf(ca, dli, ra);
+      rb = fmaf(cb, dli, rb);
+    }
+    iter++;
+    if (impv * scale < tol) break;
+  }
+  if (lane == 0) S.info[3] = iter;
+  // qacc = qacc_smooth + L^-1 D^-1/2 sum_r f_r B_r
+  float v = 0;
+#pragma unroll
+  for (int k = 0; k < DMK_NV; k++) {
+    const float sm = wave_sum(fa * Ja[k] + fb * Jb[k]);
+    if (lane == k) v = sm;
+  }
+  const int mrow = T.d_madr[lk] + T.d_nanc[lk];
+  const uint64_t ancm = T.d_ancm[lk];
+  v *= S.dsqrtinv[lk] * S.M[T.d_madr[lk]];               // z = D (D^-1/2 v)
+#pragma unroll
+  for (int j = 0; j < DMK_NV - 1; j++) {                 // x = L^-1 (.) with x = z * dinv
+    const float xj = rl(v * dv, j);
+    const bool isd = (ancm >> j) & 1ull;
+    const float l = S.M[isd ? mrow - topo::NANC[j] : 0];
+    if (isd) v -= l * xj;
+  }
+  return xs + v * dv;
+}
+
 // ---- forward evaluation, part 3: constraint rows, A = J M^-1 J^T + R, PGS, qacc; returns qacc[lane]
 __device__ __forceinline__ float fwd_constraint(GDev &T, const int lane, const int ncon, int overflow, float *dbg_force,
                                                 float *ar_scratch) {
@@ -1072,99 +1270,15 @@ __device__ __forceinline__ float fwd_constraint(GDev &T, const int lane, const i
 
     qacc_out = xs;  // qacc = qacc_smooth when there is no constraint
     solver_iter = 0;
-    if (nefc > 0) {
-      // ---- Jacobian row, reference acceleration, regulariser (lane = row)
+    if (nefc > DMK_LANEROW) {
+      qacc_out = fwd_constraint_wide(T, lane, nefc, xs, dv, ar_scratch);
+      solver_iter = S.info[3];
+    } else if (nefc > 0) {
+      // ---- Jacobian row, reference acceleration, regulariser, B row (lane = row)
       float J[DMK_NV];
-      float rpos = 0, rmargin = 0, rdiag = 1, mu = 0;
-      int rtype = -1, full = 0;
-      float wl[3] = {0, 0, 0}, wa[3] = {0, 0, 0};
-      unsigned long long cm1 = 0, cm2 = 0;
-      int ldof = -1;
-      float lsign = 0;
-      if (lane < nefc) {
-        int info = S.rowinfo[lane];
-        if (info < 0) {
-          int v = -info - 1;
-          ldof = v >> 1;
-          lsign = (v & 1) ? -1.f : 1.f;
-          rtype = 0;
-          float q = S.qpos[ldof + 1];
-          rpos = (v & 1) ? (T.d_hi[ldof] - q) : (q - T.d_lo[ldof]);
-          rmargin = 0;
-          rdiag = T.d_invw[ldof];
-        } else {
-          int ci = (info >> 3) & 0x3F, e = info & 7;
-          full = (info & 0x4000) ? 1 : 0;
-          int g1 = S.c_g1[ci], g2 = S.c_g2[ci];
-          int b1 = T.g_body[g1], b2 = T.g_body[g2];
-          int cd1 = T.g_condim[g1], cd2 = T.g_condim[g2];
-          int dim = cd1 > cd2 ? cd1 : cd2;
-          mu = fmaxf(T.g_mu[g1], T.g_mu[g2]);
-          float fr[9];
-          for (int i = 0; i < 9; i++) fr[i] = S.c_frame[ci][i];
-          float tran = T.b_invw[b1] + T.b_invw[b2];
-          if (dim < 3) {
-            rtype = 1;
-            wl[0] = fr[0]; wl[1] = fr[1]; wl[2] = fr[2];
-            rdiag = tran;
-          } else {
-            rtype = 2;
-            const bool second = (e >> 1) != 0;   // tangent 2 for edges 2,3
-            const float tx = second ? fr[6] : fr[3], ty = second ? fr[7] : fr[4], tz = second ? fr[8] : fr[5];
-            float sg = (e & 1) ? -mu : mu;
-            wl[0] = fr[0] + sg * tx; wl[1] = fr[1] + sg * ty; wl[2] = fr[2] + sg * tz;
-            rdiag = tran + mu * mu * tran;
-          }
-          float off[3] = {S.c_pos[ci][0] - com[0], S.c_pos[ci][1] - com[1], S.c_pos[ci][2] - com[2]};
-          cross3(wa, off, wl);
-          cm1 = T.b_chain[b1]; cm2 = T.b_chain[b2];
-          rpos = S.c_dist[ci];
-          rmargin = fmaxf(T.g_margin[g1], T.g_margin[g2]);
-        }
-      }
-      float vel = 0, jqs = 0, jw = 0;
-#pragma unroll
-      for (int k = 0; k < DMK_NV; k++) {
-        const float4 ca = *reinterpret_cast<const float4 *>(&S.cdof[k][0]);
-        const float2 cb = *reinterpret_cast<const float2 *>(&S.cdof[k][4]);
-        float val = ca.x * wa[0] + ca.y * wa[1] + ca.z * wa[2] + ca.w * wl[0] + cb.x * wl[1] + cb.y * wl[2];
-        float sg = (float)((int)((cm2 >> k) & 1ull) - (int)((cm1 >> k) & 1ull));
-        float j = sg * val;
-        if (rtype == 0) j = (k == ldof) ? lsign : 0.f;
-        if (rtype < 0) j = 0.f;
-        J[k] = j;
-        vel += j * S.qvel[k];
-        jqs += j * S.qacc_smooth[k];
-        jw += j * S.warm[k];
-      }
-      float R = 1, Dd = 0, aref = 0, bb = 0;
-      if (lane < nefc) {
-        float sol[5] = {T.solimp[0], T.solimp[1], T.solimp[2], T.solimp[3], T.solimp[4]};
-        float imp = impedance(sol, rpos, rmargin);
-        R = fmaxf(MINVALF, (1 - imp) * rdiag / imp);
-        if (rtype == 2 && full) R = 2 * mu * mu * R;
-        aref = -T.B * vel - T.K * imp * (rpos - rmargin);
-        bb = jqs - aref;
-        Dd = 1.0f / R;
-      }
+      float R, Dd, aref, bb, jw;
+      build_row(T, S, lane, nefc, com, J, R, Dd, aref, bb, jw);
       PROF(6);
-      // ---- B row = D^-1/2 L^-T J^T, in place (lane = row)
-      {
-        // x <- L^-T x on the row held by this lane: only the 276 ancestor pairs of the dof tree, all
-        // register and LDS indices static (dm_topology.h); factor entries are wave-uniform broadcasts.
-        // Step i's loads are tied to step i+1's result so they are not all hoisted ahead of the FMAs.
-        lds_cfloat_p Mp = (lds_cfloat_p)S.M;
-#pragma unroll
-        for (int i = DMK_NV - 1; i >= 1; i--) {
-          const float xi = J[i] * S.dinv[i];
-          asm volatile("" : "+v"(Mp), "+v"(J[0]));
-#pragma unroll
-          for (int j = 0; j < i; j++)
-            if (topo::is_anc(j, i)) J[j] -= Mp[topo::midx(i, j)] * xi;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < DMK_NV; k++) J[k] *= S.dsqrtinv[k];
       // ---- A row: AR[i] = B_lane . B_i (+ R on the diagonal).  Columns 0..31 live in registers; the
       // rare columns 32..63 (nefc > 32: p99 of the benchmark workload is 16) go to a per-env global
       // scratch, written and later re-read by the same lane.
@@ -1294,7 +1408,7 @@ __device__ __forceinline__ float fwd_constraint(GDev &T, const int lane, const i
       }
       qacc_out = xs + v * dv;
 #ifndef DM_PROFILE
-      if (dbg_force && lane < DMK_MAXROW) dbg_force[lane] = (lane < nefc) ? f : 0.f;
+      if (dbg_force && lane < DMK_LANEROW) dbg_force[lane] = (lane < nefc) ? f : 0.f;
 #endif
     }
     SYNC();
@@ -1416,7 +1530,7 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_
       const int cr = fwd_collide(Ts, lane);
       ncon = cr & 0xFF;
       qacc_out = fwd_constraint(Ts, lane, ncon, cr >> 8, P.debug ? P.debug + (size_t)env * DM_DEBUG_STRIDE + 352 : nullptr,
-                                P.ar_scratch + (size_t)env * (DMK_MAXROW - DMK_REGROW) * 64);
+                                P.ar_scratch + (size_t)env * DMK_MAXROW * DMK_MAXROW);
       nefc = S.info[1]; nlimit = S.info[2]; solver_iter = S.info[3]; overflow = S.info[4];
       if (it < 4) { stage_ncon |= (unsigned)(ncon & 0xFF) << (8 * it); stage_nefc |= (unsigned)(nefc & 0xFF) << (8 * it); }
       work += 64 + (nefc > 0 ? 48 + 4 * nefc : 0) + nefc * solver_iter;

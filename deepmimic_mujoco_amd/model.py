@@ -24,7 +24,7 @@ import numpy as np
 
 NQ, NV, NU, NBODY, NGEOM, NJNT, NM = 35, 34, 28, 14, 16, 29, 310
 MAXPAIR, NOBS, NEE = 128, 67, 4
-MAXCON, MAXROW = 32, 64
+MAXCON, MAXROW = 32, 128
 
 GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX = 0, 2, 3, 6
 JNT_FREE, JNT_HINGE = 0, 3

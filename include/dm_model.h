@@ -33,7 +33,7 @@ extern "C" {
 #define DM_NOBS 67      /* DPEnv observation (src/deepmimic_env.py:33-45) */
 #define DM_NEE 4        /* end-effector geoms (src/config.py:12) */
 #define DM_MAXCON 32    /* contact slots kept per env per forward evaluation (HIP build) */
-#define DM_MAXROW 64    /* constraint rows kept per env per forward evaluation (HIP build: one row per lane) */
+#define DM_MAXROW 128   /* constraint rows kept per env per forward evaluation (HIP build: up to two rows per lane) */
 
 /* geom types follow MuJoCo's mjtGeom numbering [EXT] so that the
  * "lower type first" pair ordering is reproduced. */

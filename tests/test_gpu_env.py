@@ -24,7 +24,7 @@ def test_dpenv_surface_matches_oracle(model, clips, oracle_clips):
     assert env.observation_space.shape == (67,) and env.mocap_data_len == 76 and env.version == "v1.0"
     oc = oracle_clips["walk"]
     s = OracleSim(model)
-    s.set_caps(32, 64)
+    s.set_caps(32, 128)
     obs = env.reset_model(idx_init=5)
     eobs = s.env_reset(oc, 5)
     assert obs.dtype == np.float64 and np.abs(obs - eobs).max() < 1e-5
@@ -67,7 +67,7 @@ def test_vecenv_autoreset_semantics(model, clips, oracle_clips):
     L = oc.L
     # reset #0 of env i picks frame hash(seed, i, 0) % L
     s = OracleSim(model)
-    s.set_caps(32, 64)
+    s.set_caps(32, 128)
     for i in (0, 17, 63):
         fi = _hash32(seed, i, 0, 0x5EED) % L
         assert np.abs(obs[i] - s.env_reset(oc, fi)).max() < 1e-5
@@ -126,7 +126,7 @@ def test_free_running_rollout_stays_close_to_oracle(model, clips, oracle_clips):
     sims = []
     for i in range(N):
         s = OracleSim(model)
-        s.set_caps(32, 64)
+        s.set_caps(32, 128)
         s.env_reset(oc, int(idx[i]))
         sims.append(s)
     rng = np.random.default_rng(5)
@@ -234,7 +234,7 @@ def test_floor_and_acyclic_motion_semantics(model):
     mc.load_mocap(MotionConfig("getup_facedown").mocap_path)
     oc = OracleClip(*mc.tables(), floor=True, acyclic=True)
     s = OracleSim(model)
-    s.set_caps(32, 64)
+    s.set_caps(32, 128)
     L = env.mocap_data_len
     env.reset_model(idx_init=L - 6)
     s.env_reset(oc, L - 6)
