@@ -31,8 +31,9 @@ HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
 def measured_traffic_bytes():
     """HBM bytes per launch of dm_step_kernel from the committed PMC profile (same command, 4096 envs)."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_v6_pmc_dm_step_kernel.csv")
+    import glob
     try:
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dm_step_kernel.csv")))[-1]
         vals = {r["counter"]: float(r["mean_per_dispatch_over_last_10_dispatches"]) for r in csv.DictReader(open(path))}
         return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
     except Exception:
