@@ -18,13 +18,14 @@ LIB_PATH = os.path.join(_HERE, "libdeepmimic_hip.so")
 DEBUG_STRIDE = 416
 
 REASONS = {0: None, 1: "low_z", 2: "high_z", 3: "max_ep_len", 4: "acyclical_end",
-           5: "sim_error", 6: "obs_out_of_bounds"}
+           5: "sim_error", 6: "obs_out_of_bounds", 7: "fallen without amnesty"}
+TASK_DPENV, TASK_COMBINED = 0, 1
 
 EXPORTS = ["dm_default_config", "dm_create", "dm_destroy", "dm_last_error", "dm_num_envs",
            "dm_load_clip", "dm_set_env_clips", "dm_reset", "dm_step", "dm_step_forced",
            "dm_set_state", "dm_get_state", "dm_get_counters", "dm_set_counters", "dm_set_debug",
            "dm_fill_random_actions", "dm_last_step_ms", "dm_enable_timing", "dm_get_work",
-           "dm_set_clip_flags"]
+           "dm_set_clip_flags", "dm_obs_dim", "dm_terms_dim", "dm_get_env_clips"]
 
 
 class DmConfig(C.Structure):
@@ -33,7 +34,8 @@ class DmConfig(C.Structure):
                 ("w_pose", C.c_float), ("w_vel", C.c_float), ("w_end_eff", C.c_float),
                 ("w_com", C.c_float), ("w_joint_limit", C.c_float), ("obs_bound", C.c_float),
                 ("seed", C.c_uint64), ("auto_reset", C.c_int32), ("device", C.c_int32),
-                ("lpt_schedule", C.c_int32), ("pad", C.c_int32)]
+                ("lpt_schedule", C.c_int32), ("task", C.c_int32),
+                ("amnesty_steps", C.c_int32), ("to_getup_len", C.c_int32)]
 
 
 _LIB = None
@@ -60,6 +62,9 @@ def load_library():
     L.dm_last_error.argtypes = [vp]
     L.dm_last_error.restype = C.c_char_p
     L.dm_num_envs.argtypes = [vp]
+    L.dm_obs_dim.argtypes = [vp]
+    L.dm_terms_dim.argtypes = [vp]
+    L.dm_get_env_clips.argtypes = [vp, vp, vp]
     L.dm_load_clip.argtypes = [vp, i32, i32, vp, vp, vp, vp]
     L.dm_set_env_clips.argtypes = [vp, vp, vp]
     L.dm_reset.argtypes = [vp, vp, vp, vp, vp]
@@ -113,6 +118,8 @@ class HipEngine:
         if rc != 0:
             raise RuntimeError("dm_create failed with code %d" % rc)
         self.h = h
+        self.obs_dim = self.L.dm_obs_dim(h)      # 67 (DPEnv) or 72 (DPCombinedEnv)
+        self.terms_dim = self.L.dm_terms_dim(h)  # 5 or 8
         self.clip_len = {}
         self._debug = None
 
@@ -149,13 +156,19 @@ class HipEngine:
         self._chk(self.L.dm_set_env_clips(self.h, _ptr(t), self._stream()), "dm_set_env_clips")
         self._keep = t
 
+    def get_env_clips(self):
+        """Per-env clip id (DPEnv task) or motion id 0 walk / 1 run / 2 getup / 3 to_getup (combined task)."""
+        out = self.torch.zeros(self.N, dtype=self.torch.int32, device=self.device)
+        self._chk(self.L.dm_get_env_clips(self.h, _ptr(out), self._stream()), "dm_get_env_clips")
+        return out
+
     # ---- buffers
     def alloc_outputs(self):
         t, d = self.torch, self.device
-        return dict(obs=t.zeros(self.N, NOBS, device=d), rew=t.zeros(self.N, device=d),
-                    done=t.zeros(self.N, dtype=t.uint8, device=d), terms=t.zeros(self.N, 5, device=d),
+        return dict(obs=t.zeros(self.N, self.obs_dim, device=d), rew=t.zeros(self.N, device=d),
+                    done=t.zeros(self.N, dtype=t.uint8, device=d), terms=t.zeros(self.N, self.terms_dim, device=d),
                     reason=t.zeros(self.N, dtype=t.int32, device=d),
-                    terminal_obs=t.zeros(self.N, NOBS, device=d))
+                    terminal_obs=t.zeros(self.N, self.obs_dim, device=d))
 
     def enable_debug(self, on=True):
         if on:

@@ -60,6 +60,9 @@ extern "C" void dm_default_config(DmConfig *c) {
   c->auto_reset = 1;
   c->device = 0;
   c->lpt_schedule = 1;
+  c->task = DM_TASK_DPENV;
+  c->amnesty_steps = 150;    // src/combined_env.py:34
+  c->to_getup_len = 180;     // :97
 }
 
 static void build_tables(const DmModel &m, DmDev &T) {
@@ -230,6 +233,8 @@ extern "C" int dm_destroy(DmHandle e) {
 
 extern "C" const char *dm_last_error(DmHandle e) { return e ? e->err.c_str() : "null handle"; }
 extern "C" int dm_num_envs(DmHandle e) { return e ? e->N : DM_EINVAL; }
+extern "C" int dm_obs_dim(DmHandle e) { return e ? (e->cfg.task == DM_TASK_COMBINED ? DM_NOBS_COMBINED : DM_NOBS) : DM_EINVAL; }
+extern "C" int dm_terms_dim(DmHandle e) { return e ? (e->cfg.task == DM_TASK_COMBINED ? 8 : 5) : DM_EINVAL; }
 
 extern "C" int dm_load_clip(DmHandle e, int clip_id, int L, const double *qpos, const double *qvel,
                             const double *body_xpos, const double *geom_xpos) {
@@ -253,6 +258,7 @@ extern "C" int dm_load_clip(DmHandle e, int clip_id, int L, const double *qpos, 
       r[72 + i] = (float)(c / mt);
       r[75 + i] = (float)q[i];
     }
+    r[78] = (float)v[0]; r[79] = (float)v[1];   // root linear velocity xy (DPCombinedEnv task reward)
     float *rr = &reset[(size_t)f * DMK_RESET_ROW];
     for (int i = 0; i < DM_NQ; i++) rr[i] = (float)q[i];
     for (int i = 0; i < DM_NV; i++) rr[35 + i] = (float)v[i];
@@ -271,6 +277,10 @@ __global__ void dm_schedule_kernel(const int32_t *cost, int32_t *order, int n);
 __global__ void dm_set_clip_kernel(float *state, const int32_t *ids, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) reinterpret_cast<int *>(state + (size_t)i * DMK_STATE_STRIDE)[DMS_CLIP] = ids ? ids[i] : 0;
+}
+__global__ void dm_get_clip_kernel(const float *state, int32_t *ids, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ids[i] = reinterpret_cast<const int *>(state + (size_t)i * DMK_STATE_STRIDE)[DMS_CLIP];
 }
 __global__ void dm_counters_kernel(float *state, int n, int32_t *idx, int32_t *len, float *rew, const int32_t *sidx,
                                    const int32_t *slen) {
@@ -294,6 +304,14 @@ __global__ void dm_get_state_kernel(const float *state, const int32_t *ids, int 
   if (qvel && lane < DM_NV) qvel[(size_t)slot * DM_NV + lane] = st[DMS_QVEL + lane];
   if (warm && lane < DM_NV) warm[(size_t)slot * DM_NV + lane] = st[DMS_WARM + lane];
   if (ctrl && lane < DM_NU) ctrl[(size_t)slot * DM_NU + lane] = st[DMS_CTRL + lane];
+}
+
+extern "C" int dm_get_env_clips(DmHandle e, int32_t *clip_ids, void *stream) {
+  if (!e || !clip_ids) return DM_EINVAL;
+  HIPCHK(e, hipSetDevice(e->cfg.device));
+  hipLaunchKernelGGL(dm_get_clip_kernel, dim3((e->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->dState, clip_ids, e->N);
+  HIPCHK(e, hipGetLastError());
+  return DM_OK;
 }
 
 extern "C" int dm_set_clip_flags(DmHandle e, int clip_id, int flags) {
@@ -320,6 +338,7 @@ static void fill_launch(DmEngine *e, DmLaunch &P, int mode) {
   P.vel_obs_scale = e->cfg.vel_obs_scale; P.low_z = e->cfg.low_z; P.high_z = e->cfg.high_z; P.obs_bound = e->cfg.obs_bound;
   P.w_pose = e->cfg.w_pose; P.w_vel = e->cfg.w_vel; P.w_ee = e->cfg.w_end_eff; P.w_com = e->cfg.w_com; P.w_jl = e->cfg.w_joint_limit;
   P.seed = e->cfg.seed;
+  P.amnesty_steps = e->cfg.amnesty_steps; P.to_getup_len = e->cfg.to_getup_len;
   P.debug = e->debug;
 }
 
@@ -329,7 +348,13 @@ static int launch(DmEngine *e, DmLaunch &P, int nslots, void *stream) {
   HIPCHK(e, hipSetDevice(e->cfg.device));
   hipStream_t s = (hipStream_t)stream;
   if (e->timing) hipEventRecord(e->ev0, s);
-  hipLaunchKernelGGL(dm_step_kernel, dim3((P.nslots + DMK_ENVS_PER_BLOCK - 1) / DMK_ENVS_PER_BLOCK), dim3(64 * DMK_ENVS_PER_BLOCK), 0, s, P);
+  const dim3 grid((P.nslots + DMK_ENVS_PER_BLOCK - 1) / DMK_ENVS_PER_BLOCK), block(64 * DMK_ENVS_PER_BLOCK);
+  if (e->cfg.task == DM_TASK_COMBINED) {
+    if (e->clipL[1] < 1 || e->clipL[2] < 2) return fail(e, DM_EINVAL, "combined task needs clips 0,1,2 = walk, run, getup");
+    hipLaunchKernelGGL(dm_step_combined_kernel, grid, block, 0, s, P);
+  } else {
+    hipLaunchKernelGGL(dm_step_kernel, grid, block, 0, s, P);
+  }
   if (e->timing) hipEventRecord(e->ev1, s);
   HIPCHK(e, hipGetLastError());
   return DM_OK;

@@ -146,6 +146,7 @@ struct DmLaunch {
   float *ar_scratch;            // N x 128 x 128: A-matrix columns beyond the register-resident 32 (touched only when nefc > 32)
   DmClipDev clips[8];
   int32_t N, nslots, mode, auto_reset, max_ep_length;
+  int32_t amnesty_steps, to_getup_len;   // DPCombinedEnv task only
   float vel_obs_scale, low_z, high_z, obs_bound;
   float w_pose, w_vel, w_ee, w_com, w_jl;
   uint64_t seed;

@@ -1420,7 +1420,13 @@ __device__ __forceinline__ float fwd_constraint(GDev &T, const int lane, const i
 }
 
 // ======================================================================================
-extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_PER_SIMD) dm_step_kernel(DmLaunch P) {
+// TASK 0: DPEnv (src/deepmimic_env.py).  TASK 1: DPCombinedEnv state machine (src/combined_env.py) on the same
+// physics; the state row's clip slot holds the motion id (0 walk, 1 run, 2 getup, 3 to_getup) and the idx slot n_steps.
+template <int TASK>
+__device__ __forceinline__ void step_body(const DmLaunch &P) {
+  constexpr int NOBS_T = TASK ? DM_NOBS_COMBINED : DM_NOBS;   // obs row stride
+  constexpr int NOBS_B = NOBS_T - 64;                          // obs entries held by obs_b lanes
+  constexpr int NTERMS = TASK ? 8 : 5;
   // Model tables are read from global memory at their use sites: 6 KB shared by every wave on the CU,
   // so they sit in the vector L1 / scalar cache; keeping them out of LDS leaves room for more envs.
   GDev &T = *(GDev *)P.T;
@@ -1458,10 +1464,13 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_
 
   // ---------------------------------------------------------------- load state
   const int clip_id = sti[DMS_CLIP];
-  const DmClipDev clip = P.clips[(clip_id >= 0 && clip_id < 8) ? clip_id : 0];
+  int motion = TASK ? ((clip_id >= 0 && clip_id < 4) ? clip_id : 0) : 0;
+  DmClipDev clip = P.clips[TASK ? (motion == 3 ? 2 : motion) : ((clip_id >= 0 && clip_id < 8) ? clip_id : 0)];
   if (clip.L < 1 || clip.rows == nullptr) return;  // no clip loaded for this env's clip id
+  if (TASK && (P.clips[0].L < 1 || P.clips[1].L < 1 || P.clips[2].L < 2)) return;  // walk, run, getup all needed
   int idx_curr = sti[DMS_IDX], ep_len = sti[DMS_EPLEN], rcnt = sti[DMS_RCNT];
-  idx_curr = idx_curr < 0 ? 0 : (idx_curr >= clip.L ? clip.L - 1 : idx_curr);
+  if (TASK) idx_curr = idx_curr < 0 ? 0 : idx_curr;  // n_steps: not wrapped (:454)
+  else idx_curr = idx_curr < 0 ? 0 : (idx_curr >= clip.L ? clip.L - 1 : idx_curr);
   float ep_rew = st[DMS_EPREW];
   if (lane < DMK_NQ) S.qpos[lane] = st[DMS_QPOS + lane];
   if (lane < DMK_NV) { S.qvel[lane] = st[DMS_QVEL + lane]; S.warm[lane] = st[DMS_WARM + lane]; }
@@ -1477,12 +1486,26 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_
       if (P.in_ctrl && lane < DMK_NU) S.ctrl[lane] = P.in_ctrl[(size_t)slot * DMK_NU + lane];
     }
   } else if (mode == DMK_MODE_RESET) {
-    int fi = P.idx_init ? P.idx_init[env] : (int)(dm_hash32(P.seed, env, rcnt, 0x5EED) % (uint32_t)clip.L);
-    fi = fi < 0 ? 0 : (fi >= clip.L ? clip.L - 1 : fi);
+    int fi;
+    if (TASK) {
+      // DPCombinedEnv.reset(rsi=True) (:219-227): walk with amnesty or getup, random frame; explicit idx_init
+      // keeps the env's motion id and sets n_steps
+      if (P.idx_init) { idx_curr = P.idx_init[env] < 0 ? 0 : P.idx_init[env]; }
+      else {
+        motion = (dm_hash32(P.seed, env, rcnt, 0x5EED) & 1) ? 2 : 0;
+        clip = P.clips[motion];
+        idx_curr = (int)(dm_hash32(P.seed, env, rcnt, 0x5EEE) % (uint32_t)clip.L) + (motion == 0 ? P.amnesty_steps + 10 : 0);
+      }
+      fi = (motion == 3) ? 1 : idx_curr % clip.L;
+    } else {
+      fi = P.idx_init ? P.idx_init[env] : (int)(dm_hash32(P.seed, env, rcnt, 0x5EED) % (uint32_t)clip.L);
+      fi = fi < 0 ? 0 : (fi >= clip.L ? clip.L - 1 : fi);
+      idx_curr = fi;
+    }
     const float *rr = clip.reset + (size_t)fi * DMK_RESET_ROW;
     if (lane < DMK_NQ) S.qpos[lane] = rr[lane];
     if (lane < DMK_NV) S.qvel[lane] = rr[35 + lane];
-    idx_curr = fi; ep_len = 0; ep_rew = 0; rcnt++;
+    ep_len = 0; ep_rew = 0; rcnt++;
   }
   SYNC();
 
@@ -1595,6 +1618,7 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_
     const bool task_pass = !after_reset && (mode == DMK_MODE_STEP || mode == DMK_MODE_FORCED);
     float obs_a = 0, obs_b = 0;  // obs[lane], obs[64 + lane]
     float terms[5] = {0, 0, 0, 0, 0};
+    float extra[3] = {0, 0, 0};  // TASK 1: imitation_reward, task_reward, n_bad_angles
     if (sim_err) {
       // MujocoException path (:366-378): zero obs, zero reward, done, empty info; MuJoCo resets mjData
       reward = 0; done = true; reason = DM_REASON_SIM_ERROR;
@@ -1628,17 +1652,35 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_
         lf = fl && (g1 == T.lfoot_geom || g2 == T.lfoot_geom);
       }
       const float rff = __any(rf) ? 1.f : 0.f, lff = __any(lf) ? 1.f : 0.f;
-      const float ph = clampf((float)idx_curr / (float)clip.L, 0.f, 1.f);
-      if (lane == 0) obs_b = rff;
-      if (lane == 1) obs_b = lff;
-      if (lane == 2) obs_b = ph;
+      // TASK 1: motion length / frame of the current motion; to_getup is a 180-step pseudo clip whose target is
+      // frame 1 of getup (MotionTransition getters, combined_env.py:67-99)
+      const int Lm = (TASK && motion == 3) ? P.to_getup_len : clip.L;
+      const int frame = TASK ? ((motion == 3) ? 1 : idx_curr % clip.L) : idx_curr;
+      if (TASK) {
+        // _get_obs (:495-505): no foot-contact obs (:25), phase, then get_player_action_obs (deepmimic_env.py:145-173)
+        // with PAWalk (heading (1,0,0), one-hot index 0) and pa_getup_state
+        const float ph = clampf((float)(idx_curr % Lm) / (float)Lm, 0.f, 1.f);
+        if (lane == 0) obs_b = ph;
+        if (lane == 1) obs_b = cy;            // hx = cos(-yaw)
+        if (lane == 2) obs_b = sy;            // hy = sin(-yaw)
+        if (lane == 3) obs_b = 1.f;
+        if (lane == 6) obs_b = (motion == 3) ? 1.f : 0.f;
+        if (lane == 7) obs_b = (motion == 2) ? 1.f : 0.f;
+      } else {
+        const float ph = clampf((float)idx_curr / (float)clip.L, 0.f, 1.f);
+        if (lane == 0) obs_b = rff;
+        if (lane == 1) obs_b = lff;
+        if (lane == 2) obs_b = ph;
+      }
 
       if (task_pass) {
         // ---- calc_imitation_reward (:193-256) against clip row idx_curr
         // row: [0:28) qpos[7:] | [28:56) qvel[6:] | [56:60) root quat | [60:72) ee xpos | [72:75) com
-        const float *row = clip.rows + (size_t)idx_curr * DMK_CLIP_ROW;
+        const float *row = clip.rows + (size_t)frame * DMK_CLIP_ROW;
         const float ra = row[lane];
-        float ecfg = wave_sum((lane < 28) ? fabsf(S.qpos[7 + (lane < 28 ? lane : 0)] - ra) : 0.f);
+        const float adiff = (lane < 28) ? fabsf(S.qpos[7 + (lane < 28 ? lane : 0)] - ra) : 0.f;  // config_angle_diffs
+        float ecfg = wave_sum(adiff);
+        const float dsum = ecfg;
         const float evel = wave_sum((lane >= 28 && lane < 56) ? fabsf(ra - S.qvel[6 + ((lane >= 28 && lane < 56) ? lane - 28 : 0)]) : 0.f);
         const float tquat[4] = {rl(ra, 56), rl(ra, 57), rl(ra, 58), rl(ra, 59)};
         const float cq[4] = {S.qpos[3], S.qpos[4], S.qpos[5], S.qpos[6]};
@@ -1668,18 +1710,52 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_
         const float qlim = wave_sum(viol) / 28.0f;
         terms[0] = r_cfg; terms[1] = r_vel; terms[2] = r_ee; terms[3] = r_com; terms[4] = qlim;
         reward = P.w_pose * r_cfg + P.w_vel * r_vel + P.w_ee * r_ee + P.w_com * r_com + P.w_jl * qlim;
-        // ---- termination (:418-442)
         const float zc = S.com[2];
         done = false;
         reason = DM_REASON_NONE;
-        if (!(clip.flags & DM_CLIP_FLOOR)) {                      // :420-424 (written every step, even when not done)
-          done = (zc < P.low_z) || (zc > P.high_z);
-          reason = (zc < P.low_z) ? DM_REASON_LOW_Z : DM_REASON_HIGH_Z;
+        if (TASK) {
+          // ---- DPCombinedEnv: task reward (combined_env.py:338-354)
+          const float ALIM = 0.2617993877991494f, MAX_ANGLE = 1.0471975511965976f;  // deg2rad(15), deg2rad(60)
+          const float droll = fabsf(rc[0] - rt[0]), dpitch = fabsf(rc[1] - rt[1]);
+          float imitation = reward, task_r = 0.f;
+          if (motion == 0 || motion == 1) {                       // heading + velocity error vs the clip's root velocity
+            const float ex = row[78] - S.qvel[0], ey = row[79] - S.qvel[1];
+            task_r = expf(-sqrtf(ex * ex + ey * ey) * 10.f);
+          }
+          if (motion == 3) { imitation = 0.f; task_r = expf(-(dsum + dpitch + droll) / 5.f) / 3.f; }
+          reward = imitation * 0.7f + task_r * 0.3f;
+          const unsigned long long badm = __ballot(adiff > ALIM);
+          const bool all_close = !__any(!(adiff < ALIM));          // lanes >= 28 carry 0
+          extra[0] = imitation; extra[1] = task_r;
+          extra[2] = (float)(__popcll(badm) + (dpitch > ALIM ? 1 : 0) + (droll > ALIM ? 1 : 0));  // debug_n_bad_angles
+          // ---- motion state machine + termination (:393-445)
+          if (idx_curr >= Lm - 1) {                               // out of time
+            // :396 compares PlayerAction objects by identity -> getup always hands over to run
+            if (motion == 2) { motion = 1; idx_curr = 0; }
+            if (motion == 3) { motion = 2; idx_curr = 0; }
+          }
+          if (dpitch < ALIM && droll < ALIM && all_close && motion == 3) { motion = 2; idx_curr = 0; }
+          if (motion == 0 || motion == 1) {
+            const bool fallen = (zc < P.low_z) || (zc > P.high_z) || (droll > MAX_ANGLE) || (dpitch > MAX_ANGLE);
+            if (fallen) {
+              if (!(idx_curr > P.amnesty_steps)) { done = true; reason = DM_REASON_FALLEN_NO_AMNESTY; }
+              motion = 3; idx_curr = 0;
+            }
+          }
+          if (P.max_ep_length != 0 && ep_len >= P.max_ep_length) { done = true; reason = DM_REASON_MAX_EP_LEN; }
+          clip = P.clips[motion == 3 ? 2 : motion];
+          idx_curr += 1;                                          // :454 (not wrapped)
+        } else {
+          // ---- termination (:418-442)
+          if (!(clip.flags & DM_CLIP_FLOOR)) {                      // :420-424 (written every step, even when not done)
+            done = (zc < P.low_z) || (zc > P.high_z);
+            reason = (zc < P.low_z) ? DM_REASON_LOW_Z : DM_REASON_HIGH_Z;
+          }
+          if (P.max_ep_length != 0 && ep_len >= P.max_ep_length) { done = true; reason = DM_REASON_MAX_EP_LEN; }
+          if ((clip.flags & DM_CLIP_ACYCLIC) && idx_curr + 1 == clip.L) { done = true; reason = DM_REASON_ACYCLIC_END; }  // :440-442
+          // ---- post-step counters (:452-455)
+          idx_curr = (idx_curr + 1) % clip.L;
         }
-        if (P.max_ep_length != 0 && ep_len >= P.max_ep_length) { done = true; reason = DM_REASON_MAX_EP_LEN; }
-        if ((clip.flags & DM_CLIP_ACYCLIC) && idx_curr + 1 == clip.L) { done = true; reason = DM_REASON_ACYCLIC_END; }  // :440-442
-        // ---- post-step counters (:452-455)
-        idx_curr = (idx_curr + 1) % clip.L;
         ep_rew += reward;
         ep_len += 1;
         // ---- observation guard (:465-476)
@@ -1687,6 +1763,7 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_
         if (__any(ob)) {
           obs_a = 0; obs_b = 0; reward = 0; done = true; reason = DM_REASON_OBS_BOUNDS;
           for (int i = 0; i < 5; i++) terms[i] = 0;
+          extra[0] = extra[1] = extra[2] = 0;
         }
       }
     }
@@ -1708,21 +1785,32 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_
       if (P.rew && lane == 0) P.rew[env] = reward;
       if (P.done && lane == 0) P.done[env] = done ? 1 : 0;
       if (P.reason && lane == 0) P.reason[env] = reason;
-      if (P.terms && lane < 5)
-        P.terms[(size_t)env * 5 + lane] = (lane == 0) ? terms[0] : (lane == 1) ? terms[1] : (lane == 2) ? terms[2] : (lane == 3) ? terms[3] : terms[4];
+      if (P.terms && lane < NTERMS)
+        P.terms[(size_t)env * NTERMS + lane] = (lane == 0) ? terms[0] : (lane == 1) ? terms[1] : (lane == 2) ? terms[2] : (lane == 3) ? terms[3]
+                                             : (lane == 4) ? terms[4] : (lane == 5) ? extra[0] : (lane == 6) ? extra[1] : extra[2];
       if (done && P.auto_reset && mode == DMK_MODE_STEP) {
         // VecEnv worker: info["terminal_observation"] = obs; obs = env.reset()
         if (P.terminal_obs) {
-          P.terminal_obs[(size_t)env * DM_NOBS + lane] = obs_a;
-          if (lane < 3) P.terminal_obs[(size_t)env * DM_NOBS + 64 + lane] = obs_b;
+          P.terminal_obs[(size_t)env * NOBS_T + lane] = obs_a;
+          if (lane < NOBS_B) P.terminal_obs[(size_t)env * NOBS_T + 64 + lane] = obs_b;
         }
-        const int fi = (int)(dm_hash32(P.seed, env, rcnt, 0x5EED) % (uint32_t)clip.L);
+        int fi;
+        if (TASK) {  // DPCombinedEnv.reset(rsi=True) (:219-227)
+          motion = (dm_hash32(P.seed, env, rcnt, 0x5EED) & 1) ? 2 : 0;
+          clip = P.clips[motion];
+          fi = (int)(dm_hash32(P.seed, env, rcnt, 0x5EEE) % (uint32_t)clip.L);
+          idx_curr = fi + (motion == 0 ? P.amnesty_steps + 10 : 0);
+          fi = idx_curr % clip.L;
+        } else {
+          fi = (int)(dm_hash32(P.seed, env, rcnt, 0x5EED) % (uint32_t)clip.L);
+          idx_curr = fi;
+        }
         rcnt++;
         const float *rr = clip.reset + (size_t)fi * DMK_RESET_ROW;
         SYNC();
         if (lane < DMK_NQ) S.qpos[lane] = rr[lane];
         if (lane < DMK_NV) S.qvel[lane] = rr[35 + lane];
-        idx_curr = fi; ep_len = 0; ep_rew = 0;
+        ep_len = 0; ep_rew = 0;
         SYNC();
         after_reset = true;
         sim_err = false;
@@ -1731,8 +1819,8 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_
       }
     }
     if (P.obs) {
-      P.obs[(size_t)env * DM_NOBS + lane] = obs_a;
-      if (lane < 3) P.obs[(size_t)env * DM_NOBS + 64 + lane] = obs_b;
+      P.obs[(size_t)env * NOBS_T + lane] = obs_a;
+      if (lane < NOBS_B) P.obs[(size_t)env * NOBS_T + 64 + lane] = obs_b;
     }
     break;
   }
@@ -1749,7 +1837,15 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_
   if (lane < DMK_NV) { st[DMS_QVEL + lane] = S.qvel[lane]; st[DMS_WARM + lane] = S.warm[lane]; }
   if (lane < DMK_NU) st[DMS_CTRL + lane] = S.ctrl[lane];
   if (lane == 0) { sti[DMS_IDX] = idx_curr; sti[DMS_EPLEN] = ep_len; st[DMS_EPREW] = ep_rew; sti[DMS_RCNT] = rcnt; }
+  if (TASK && lane == 0) sti[DMS_CLIP] = motion;
   if (P.cost && lane == 0) P.cost[env] = work;
+}
+
+extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_PER_SIMD) dm_step_kernel(DmLaunch P) {
+  step_body<0>(P);
+}
+extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_PER_SIMD) dm_step_combined_kernel(DmLaunch P) {
+  step_body<1>(P);
 }
 
 // Uniform random actions in [-2, 2) for bench.py config 2 (same generator as the oracle driver).

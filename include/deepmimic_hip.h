@@ -44,6 +44,12 @@ typedef struct DmEngine *DmHandle;
 #define DM_REASON_ACYCLIC_END 4
 #define DM_REASON_SIM_ERROR 5
 #define DM_REASON_OBS_BOUNDS 6
+#define DM_REASON_FALLEN_NO_AMNESTY 7 /* DPCombinedEnv "fallen without amnesty" (src/combined_env.py:436) */
+
+/* Task selector (DmConfig.task) */
+#define DM_TASK_DPENV 0     /* DPEnv            (src/deepmimic_env.py:272-484): obs 67, terms 5 */
+#define DM_TASK_COMBINED 1  /* DPCombinedEnv    (src/combined_env.py:101-533) on humanoid3d: obs 72, terms 8;
+                             * clips 0,1,2 = walk, run, getup; per-env motion id 0 walk 1 run 2 getup 3 to_getup */
 
 /* Task configuration — DPEnvConfig (src/deepmimic_env.py:258-270), RobotConfig.low_z
  * (src/config.py:13) and the reward weights hard-coded in step() (:400-404). */
@@ -58,7 +64,9 @@ typedef struct DmConfig {
   int32_t auto_reset;      /* 1: SubprocVecEnv worker semantics (reset inside step when done) */
   int32_t device;          /* HIP device ordinal */
   int32_t lpt_schedule;    /* 1 (default): dm_step launches envs longest-first by last step's work estimate */
-  int32_t pad;
+  int32_t task;            /* DM_TASK_DPENV (default) or DM_TASK_COMBINED */
+  int32_t amnesty_steps;   /* 150  DPCombinedEnvConfig.AMNESTY_STEPS (combined_env.py:34) */
+  int32_t to_getup_len;    /* 180  MTToGetup.length (combined_env.py:97) */
 } DmConfig;
 
 void dm_default_config(DmConfig *cfg);
@@ -69,6 +77,10 @@ int dm_create(const DmModel *model, const DmConfig *cfg, DmHandle *out);
 int dm_destroy(DmHandle h);
 const char *dm_last_error(DmHandle h);
 int dm_num_envs(DmHandle h);
+/* Row widths of the obs / terms buffers for the configured task: 67 / 5 (DPEnv) or 72 / 8 (DPCombinedEnv:
+ * the five calc_imitation_reward terms, info["imitation_reward"], info["task_reward"], debug_n_bad_angles). */
+int dm_obs_dim(DmHandle h);
+int dm_terms_dim(DmHandle h);
 
 /* Replaces: DPEnv.load_mocap -> MocapDM tables (deepmimic_env.py:321-324; mocap_v2.py:338-348).
  * HOST float64 tables: qpos[L*35], qvel[L*34], body_xpos[L*14*3], geom_xpos[L*16*3]. */
@@ -82,6 +94,9 @@ int dm_load_clip(DmHandle h, int clip_id, int L, const double *host_qpos, const 
 int dm_set_clip_flags(DmHandle h, int clip_id, int flags);
 /* Per-env clip assignment (device int32[N]; NULL = all envs use clip 0). */
 int dm_set_env_clips(DmHandle h, const int32_t *clip_ids, void *stream);
+/* Reads the per-env clip id back; under DM_TASK_COMBINED it is the motion id (0 walk, 1 run, 2 getup,
+ * 3 to_getup), i.e. `env.current_motion_mocap` of src/combined_env.py:190, and dm_set_env_clips sets it. */
+int dm_get_env_clips(DmHandle h, int32_t *clip_ids, void *stream);
 
 /* Replaces: DPEnv.reset()/reset_model(idx_init) (deepmimic_env.py:496-510) for the envs with
  * mask[i] != 0 (mask NULL = all).  idx_init NULL = random frame from the engine RNG

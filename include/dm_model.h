@@ -31,6 +31,7 @@ extern "C" {
 #define DM_NM 310       /* non-zeros of the sparse joint-space inertia */
 #define DM_MAXPAIR 128  /* capacity of the collision candidate table (104 used) */
 #define DM_NOBS 67      /* DPEnv observation (src/deepmimic_env.py:33-45) */
+#define DM_NOBS_COMBINED 72 /* DPCombinedEnv observation: 64 + phase + player-action obs 7 (src/combined_env.py:495-505) */
 #define DM_NEE 4        /* end-effector geoms (src/config.py:12) */
 #define DM_MAXCON 32    /* contact slots kept per env per forward evaluation (HIP build) */
 #define DM_MAXROW 128   /* constraint rows kept per env per forward evaluation (HIP build: up to two rows per lane) */

@@ -1146,6 +1146,142 @@ int dmo_env_reset(const DmModel *m, DmoData *d, DmoEnv *e, const DmoClip *clip, 
   return err;
 }
 
+/* ------------------------------------------------------------------ DPCombinedEnv semantics (src/combined_env.py) */
+#define COMB_AMNESTY_STEPS 150   /* DPCombinedEnvConfig.AMNESTY_STEPS :34 */
+#define COMB_MAX_EP_LENGTH 2000  /* :22 */
+#define COMB_TO_GETUP_LEN 180    /* MTToGetup.length :97 */
+
+static int comb_len(const DmoCombEnv *e, const DmoClip *clips) { /* current_motion_mocap.get_length() */
+  return e->motion == DMO_MOTION_TO_GETUP ? COMB_TO_GETUP_LEN : clips[e->motion].L;
+}
+static const DmoClip *comb_clip(const DmoCombEnv *e, const DmoClip *clips, int *frame) {
+  /* MotionTransition getters always return frame 1 of the target clip (:72-79) */
+  if (e->motion == DMO_MOTION_TO_GETUP) { *frame = 1; return &clips[DMO_MOTION_GETUP]; }
+  *frame = e->n_steps % clips[e->motion].L;
+  return &clips[e->motion];
+}
+
+void dmo_combined_obs(const DmModel *m, const DmoData *d, const DmoCombEnv *e, const DmoClip *clips, double *obs) {
+  double base[DM_NOBS];
+  int L = comb_len(e, clips);
+  dmo_get_obs(m, d, e->n_steps % L, L, base);                    /* shared get_obs (deepmimic_env.py:33-45) */
+  for (int i = 0; i < 64; i++) obs[i] = base[i];                  /* ADD_FOOT_CONTACT_OBS False (:25); no extra-contact geoms */
+  obs[64] = base[66];                                             /* phase */
+  /* get_player_action_obs (deepmimic_env.py:145-173) with PAWalk: heading (1,0,0), onehot index 0 */
+  double rpy[3];
+  dmo_quat_to_rpy(d->xquat[m->torso_body], rpy);
+  const double hwx = 1.0, hwy = 0.0;
+  obs[65] = hwx * cos(-rpy[2]) - hwy * sin(-rpy[2]);
+  obs[66] = hwx * sin(-rpy[2]) + hwy * cos(-rpy[2]);
+  obs[67] = 1; obs[68] = 0; obs[69] = 0;
+  obs[70] = (e->motion == DMO_MOTION_TO_GETUP) ? 1 : 0;           /* pa_getup_state (:499-504) */
+  obs[71] = (e->motion == DMO_MOTION_GETUP) ? 1 : 0;
+}
+
+static void comb_change(DmoCombEnv *e, int motion) { e->motion = motion; e->n_steps = 0; } /* :529-533 */
+
+int dmo_combined_step(const DmModel *m, DmoData *d, DmoCombEnv *e, const DmoClip *clips, const double *action,
+                      const double *fq, const double *fv, double *obs, double *reward, double *terms, int32_t *reason) {
+  int err = 0;
+  *reason = DMO_REASON_NONE;
+  if (fq && fv) {
+    err = dmo_set_state(m, d, fq, fv);                            /* :260-262 */
+  } else {
+    for (int a = 0; a < NU; a++) d->ctrl[a] = action[a] * 1.0;    /* :251 (ACT_SCALE applies to unitree_g1 only) */
+    err = dmo_step(m, d);                                         /* :267 */
+  }
+  if (err) {                                                      /* :271-284 */
+    dmo_data_reset(m, d);
+    memset(obs, 0, sizeof(double) * DMO_NOBS_COMBINED);
+    memset(terms, 0, sizeof(double) * 8);
+    *reward = 0;
+    *reason = DMO_REASON_SIM_ERROR;
+    return 1;
+  }
+  dmo_combined_obs(m, d, e, clips, obs);                          /* :313 (before any motion change) */
+  /* ---- reward (:325-358) */
+  int frame;
+  const DmoClip *clip = comb_clip(e, clips, &frame);
+  double imitation = dmo_reward(m, d, clip, frame, terms);
+  const double *tq = clip->qpos + (size_t)frame * NQ, *tv = clip->qvel + (size_t)frame * NV;
+  double rc[3], rt[3];
+  dmo_quat_to_rpy(d->qpos + 3, rc);
+  dmo_quat_to_rpy(tq + 3, rt);
+  double dsum = 0, dmax = 0;
+  int nbad = 0;
+  const double PI = 3.14159265358979323846;
+  const double ALIM = 15.0 * (PI / 180.0), MAX_ANGLE = 60.0 * (PI / 180.0); /* np.deg2rad(15), np.deg2rad(60) */
+  for (int i = 7; i < NQ; i++) {
+    double a = fabs(d->qpos[i] - tq[i]);
+    dsum += a;
+    if (a > dmax) dmax = a;
+    nbad += a > ALIM;
+  }
+  const double droll = fabs(rc[0] - rt[0]), dpitch = fabs(rc[1] - rt[1]);
+  nbad += (dpitch > ALIM) + (droll > ALIM);                       /* debug_n_bad_angles :411 */
+  double task = 0;
+  if (e->motion == DMO_MOTION_WALK || e->motion == DMO_MOTION_RUN) {   /* :340-346 */
+    double ex = tv[0] - d->qvel[0], ey = tv[1] - d->qvel[1];
+    task = exp(-sqrt(ex * ex + ey * ey) * 10.0);
+  }
+  if (e->motion == DMO_MOTION_TO_GETUP) {                         /* :347-351 */
+    imitation = 0;
+    task = exp(-(dsum + dpitch + droll) / 5.0) / 3.0;
+  }
+  *reward = imitation * 0.7 + task * 0.3;                         /* :352-354 */
+  terms[5] = imitation; terms[6] = task; terms[7] = nbad;
+  /* ---- termination / motion state machine (:393-445) */
+  int done = 0;
+  const int out_of_time = e->n_steps >= comb_len(e, clips) - 1;   /* :394 */
+  if (out_of_time) {
+    /* :396 `current_player_action == PAWalk()` compares two distinct objects -> always False -> run */
+    if (e->motion == DMO_MOTION_GETUP) comb_change(e, DMO_MOTION_RUN);
+    if (e->motion == DMO_MOTION_TO_GETUP) comb_change(e, DMO_MOTION_GETUP);
+  }
+  /* is_player_action_change is hard-wired False (:300) */
+  const int successful = (dpitch < ALIM) && (droll < ALIM) && (dmax < ALIM); /* :406-410 */
+  if (successful && e->motion == DMO_MOTION_TO_GETUP) comb_change(e, DMO_MOTION_GETUP);
+  if (e->motion == DMO_MOTION_WALK || e->motion == DMO_MOTION_RUN) { /* :416-440 (motion as changed above) */
+    double mt = 0, zc = 0;
+    for (int b = 0; b < NB; b++) { mt += m->body_mass[b]; zc += m->body_mass[b] * d->xipos[b][2]; }
+    zc /= mt;
+    int fallen = (zc < 0.7) || (zc > 2.0);
+    if (droll > MAX_ANGLE) fallen = 1;
+    if (dpitch > MAX_ANGLE) fallen = 1;
+    if (fallen) {
+      if (!(e->n_steps > COMB_AMNESTY_STEPS)) { done = 1; *reason = DMO_REASON_FALLEN_NO_AMNESTY; }
+      comb_change(e, DMO_MOTION_TO_GETUP);
+    }
+  }
+  if (e->episode_length >= COMB_MAX_EP_LENGTH) { done = 1; *reason = DMO_REASON_MAX_EP_LEN; } /* :442-445 */
+  /* ---- post-step (:454-460) */
+  e->n_steps += 1;
+  e->episode_reward += *reward;
+  e->episode_length += 1;
+  for (int i = 0; i < DMO_NOBS_COMBINED; i++)                     /* :472-484 */
+    if (obs[i] > 100.0 || obs[i] < -100.0) {
+      memset(obs, 0, sizeof(double) * DMO_NOBS_COMBINED);
+      memset(terms, 0, sizeof(double) * 8);
+      *reward = 0;
+      *reason = DMO_REASON_OBS_BOUNDS;
+      return 1;
+    }
+  return done;
+}
+
+int dmo_combined_reset(const DmModel *m, DmoData *d, DmoCombEnv *e, const DmoClip *clips, int motion, int n_steps,
+                       double *obs) {
+  e->motion = motion;                                             /* :219-227 */
+  e->n_steps = n_steps;
+  e->episode_reward = 0;                                          /* :233-235 */
+  e->episode_length = 0;
+  int frame;
+  const DmoClip *clip = comb_clip(e, clips, &frame);              /* get_current_motion_state :199-203 */
+  int err = dmo_set_state(m, d, clip->qpos + (size_t)frame * NQ, clip->qvel + (size_t)frame * NV);
+  dmo_combined_obs(m, d, e, clips, obs);
+  return err;
+}
+
 /* ------------------------------------------------------------------ CPU baseline driver */
 static uint32_t hash32(uint64_t seed, uint32_t env, uint32_t step, uint32_t j) {
   /* counter-based generator shared with the HIP bench path (csrc/dm_kernels.hip: dm_hash32) */

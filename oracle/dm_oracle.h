@@ -118,6 +118,26 @@ int dmo_env_step(const DmModel *m, DmoData *d, DmoEnv *e, const DmoClip *clip,
 int dmo_env_reset(const DmModel *m, DmoData *d, DmoEnv *e, const DmoClip *clip, int idx_init,
                   double *obs67);
 
+/* ---- DPCombinedEnv (src/combined_env.py) on the humanoid3d model: walk / run / getup / to_getup state machine.
+ * The reference class is hard-wired to unitree_g1 (:165); this restates its step()/reset()/_get_obs() with the
+ * humanoid3d RobotConfig (no action scale, no extra-contact geoms, low_z 0.7).  clips[3] = walk, run, getup. */
+#define DMO_NOBS_COMBINED 72
+enum { DMO_MOTION_WALK = 0, DMO_MOTION_RUN = 1, DMO_MOTION_GETUP = 2, DMO_MOTION_TO_GETUP = 3 };
+enum { DMO_REASON_FALLEN_NO_AMNESTY = 7 };
+typedef struct DmoCombEnv {
+  int32_t motion, n_steps, episode_length, pad;
+  double episode_reward;
+} DmoCombEnv;
+/* _get_obs (:495-505): qpos[7:], S*qvel[6:], torso(8), phase(1), player-action obs (hx, hy, onehot3, getup2) */
+void dmo_combined_obs(const DmModel *m, const DmoData *d, const DmoCombEnv *e, const DmoClip *clips, double *obs72);
+/* step (:243-493).  terms8 = the five calc_imitation_reward terms, imitation_reward, task_reward, n_bad_angles */
+int dmo_combined_step(const DmModel *m, DmoData *d, DmoCombEnv *e, const DmoClip *clips, const double *action,
+                      const double *force_qpos, const double *force_qvel, double *obs72, double *reward,
+                      double *terms8, int32_t *reason);
+/* reset (:205-241) with the two random draws made explicit: motion in {walk, getup} and n_steps */
+int dmo_combined_reset(const DmModel *m, DmoData *d, DmoCombEnv *e, const DmoClip *clips, int motion, int n_steps,
+                       double *obs72);
+
 /* rotation helpers exposed for tests */
 void dmo_quat_to_rpy(const double *wxyz, double *rpy);
 

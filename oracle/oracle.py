@@ -27,6 +27,14 @@ class _Env(C.Structure):
                 ("episode_reward", C.c_double)]
 
 
+class _CombEnv(C.Structure):
+    _fields_ = [("motion", C.c_int32), ("n_steps", C.c_int32), ("episode_length", C.c_int32), ("pad", C.c_int32),
+                ("episode_reward", C.c_double)]
+
+
+NOBS_COMBINED = 72
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
@@ -51,6 +59,9 @@ def lib():
         L.dmo_reward.restype = C.c_double
         L.dmo_env_step.argtypes = [C.c_void_p] * 11
         L.dmo_env_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.dmo_combined_obs.argtypes = [C.c_void_p] * 5
+        L.dmo_combined_step.argtypes = [C.c_void_p] * 11
+        L.dmo_combined_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.dmo_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
         L.dmo_set.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
         L.dmo_get_int.argtypes = [C.c_void_p, C.c_char_p]
@@ -172,6 +183,38 @@ class OracleSim:
             pq = pv = None
         done = self.L.dmo_env_step(C.byref(self.cm), self.d, C.byref(self.env), C.byref(clip.c), _p(a),
                                    pq, pv, _p(obs), C.byref(rew), _p(terms), C.byref(reason))
+        return obs, rew.value, bool(done), terms, reason.value
+
+
+class OracleCombined(OracleSim):
+    """One fp64 DPCombinedEnv (src/combined_env.py) on humanoid3d: clips = (walk, run, getup)."""
+
+    def __init__(self, model, clips):
+        super().__init__(model)
+        assert len(clips) == 3
+        self.clips = clips
+        self.carr = (_Clip * 3)(*[c.c for c in clips])
+        self.cenv = _CombEnv(0, 0, 0, 0, 0.0)
+
+    def comb_reset(self, motion, n_steps):
+        obs = np.zeros(NOBS_COMBINED)
+        self.L.dmo_combined_reset(C.byref(self.cm), self.d, C.byref(self.cenv), self.carr, motion, n_steps, _p(obs))
+        return obs
+
+    def comb_step(self, action, force_state=None):
+        obs = np.zeros(NOBS_COMBINED)
+        rew = C.c_double(0)
+        terms = np.zeros(8)
+        reason = C.c_int32(0)
+        a = np.ascontiguousarray(action, np.float64)
+        if force_state is not None:
+            fq = np.ascontiguousarray(force_state[0], np.float64)
+            fv = np.ascontiguousarray(force_state[1], np.float64)
+            pq, pv = _p(fq), _p(fv)
+        else:
+            pq = pv = None
+        done = self.L.dmo_combined_step(C.byref(self.cm), self.d, C.byref(self.cenv), self.carr, _p(a), pq, pv,
+                                        _p(obs), C.byref(rew), _p(terms), C.byref(reason))
         return obs, rew.value, bool(done), terms, reason.value
 
 
