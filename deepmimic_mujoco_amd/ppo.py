@@ -154,7 +154,8 @@ class PPO:
         self.normalize_advantage = normalize_advantage
         self.buffer_dtype = buffer_dtype
         torch.manual_seed(seed)  # identical initial weights on every rank; no parameter broadcast needed
-        self.policy = (policy if policy is not None else MlpPolicy(net_arch=tuple(net_arch))).to(self.device)
+        self.obs_dim = int(env.observation_space.shape[0]) if env is not None else 67   # 67 DPEnv, 72 DPCombinedEnv
+        self.policy = (policy if policy is not None else MlpPolicy(obs_dim=self.obs_dim, net_arch=tuple(net_arch))).to(self.device)
         on_gpu = self.device.type == "cuda"
         # The optimizer step of one minibatch is ~60 small kernels: launch-bound.  On one GPU it is captured
         # once into a hipGraph and replayed (640 replays per PPO iteration with the reference's settings).
@@ -177,7 +178,7 @@ class PPO:
     def collect_rollouts(self):
         T, N, dev = self.n_steps, self.n_envs, self.device
         bd = self.buffer_dtype
-        buf = dict(obs=torch.zeros(T, N, 67, device=dev, dtype=bd), act=torch.zeros(T, N, 28, device=dev, dtype=bd),
+        buf = dict(obs=torch.zeros(T, N, self.obs_dim, device=dev, dtype=bd), act=torch.zeros(T, N, 28, device=dev, dtype=bd),
                    rew=torch.zeros(T, N, device=dev), done=torch.zeros(T, N, device=dev),
                    val=torch.zeros(T, N, device=dev), logp=torch.zeros(T, N, device=dev))
         if self._last_obs is None:
@@ -243,7 +244,7 @@ class PPO:
         """Replay the captured optimizer step on static input buffers (capture on first use)."""
         if self._graph is None:
             B, dev = self.batch_size, self.device
-            self._gin = dict(obs=torch.zeros(B, 67, device=dev), act=torch.zeros(B, 28, device=dev),
+            self._gin = dict(obs=torch.zeros(B, self.obs_dim, device=dev), act=torch.zeros(B, 28, device=dev),
                              adv=torch.zeros(B, device=dev), ret=torch.zeros(B, device=dev),
                              logp=torch.zeros(B, device=dev))
             # warm-up iterations must not change the model: snapshot parameters and optimizer state

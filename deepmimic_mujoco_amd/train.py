@@ -18,6 +18,8 @@ import torch.distributed as dist
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--motion", default="walk", help="clip name or comma list (multi-clip: env i -> clip i mod k)")
+    ap.add_argument("--env", default="deep_mimic_mujoco", choices=["deep_mimic_mujoco", "dp_combined_env"],
+                    help="env_name of src/sb3_ppo.py:247-248 (dp_combined_env: walk/run/getup state machine on humanoid3d)")
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=32)          # 32 x 4096 = the reference's 4096 x 32 batch
     ap.add_argument("--epochs", type=int, default=20)           # src/sb3_ppo.py:259
@@ -43,8 +45,12 @@ def main(argv=None):
     from .ppo import PPO
 
     motions = args.motion.split(",")
-    env = HipDeepMimicVecEnv(args.envs, motion=motions if len(motions) > 1 else motions[0], device=local_rank,
-                             seed=1234 + 7919 * rank)
+    if args.env == "dp_combined_env":                                   # src/sb3_ppo.py:276-278
+        from .combined_env import HipCombinedVecEnv
+        env = HipCombinedVecEnv(args.envs, device=local_rank, seed=1234 + 7919 * rank)
+    else:
+        env = HipDeepMimicVecEnv(args.envs, motion=motions if len(motions) > 1 else motions[0], device=local_rank,
+                                 seed=1234 + 7919 * rank)
     ppo = PPO(env, net_arch=tuple(int(x) for x in args.arch.split(",")), n_steps=args.horizon,
               batch_size=args.minibatch, n_epochs=args.epochs, learning_rate=args.lr, seed=args.seed,
               buffer_dtype=torch.bfloat16 if args.bf16_buffer else torch.float32)

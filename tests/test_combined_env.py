@@ -292,3 +292,16 @@ def test_gpu_combined_vecenv_autoreset_and_mirror(model):
     assert abs(info["task_reward"] - 1.0) < 1e-6 and not d and e1.current_motion_mocap is e1.walk_mocap
     assert e1.current_motion_n_steps == 201
     e1.close()
+
+
+@pytest.mark.gpu
+def test_gpu_ppo_on_combined_env():
+    """src/sb3_ppo.py trains `dp_combined_env` by default (:247-278): the learner takes the 72-d observation."""
+    from deepmimic_mujoco_amd.combined_env import HipCombinedVecEnv
+    from deepmimic_mujoco_amd.ppo import PPO
+    venv = HipCombinedVecEnv(128, seed=3)
+    ppo = PPO(venv, net_arch=(64, 32), n_steps=16, batch_size=512, n_epochs=2, learning_rate=3e-4)
+    assert ppo.obs_dim == 72
+    ppo.learn(2 * 16 * 128, log_interval=0)
+    assert ppo.num_timesteps == 2 * 16 * 128 and np.isfinite(ppo.stats["loss"])
+    venv.close()

@@ -249,3 +249,55 @@ def test_floor_and_acyclic_motion_semantics(model):
         else:
             assert d and info["done_reason"] == "acyclical_end" and ereason == 4
     env.close()
+
+
+def test_eval_env_in_thread_next_to_batched_env(model, clips, oracle_clips):
+    """SURVEY §8b threading: the eval env lives in a daemon thread of the learner process (sb3_ppo.py:173-174) and
+    steps concurrently with the batched training env.  Handles share no mutable state: results of the threaded
+    single env must equal those of the same rollout run alone."""
+    import threading
+    import torch
+    from deepmimic_mujoco_amd.deepmimic_env import DPEnv, HipDeepMimicVecEnv
+
+    def eval_rollout(out):
+        env = DPEnv(motion="walk")
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            obs = [env.reset_model(idx_init=5)]
+            rews = []
+            rng = np.random.default_rng(11)
+            for t in range(60):
+                o, r, d, info = env.step(rng.uniform(-1, 1, 28))
+                obs.append(o)
+                rews.append(r)
+                if d:
+                    break
+        env.close()
+        out.append((np.array(obs), np.array(rews)))
+
+    alone = []
+    eval_rollout(alone)
+    venv = HipDeepMimicVecEnv(2048, motion="run")
+    venv.reset_tensor()
+    threaded = []
+    th = threading.Thread(target=eval_rollout, args=(threaded,), daemon=True)
+    th.start()
+    act = torch.zeros(2048, 28, device=venv.device)
+    ref = None
+    for i in range(200):
+        venv.engine.fill_random_actions(act, i)
+        venv.step_tensor(act)
+    th.join(timeout=120)
+    assert not th.is_alive() and len(threaded) == 1
+    torch.cuda.synchronize()
+    assert np.array_equal(alone[0][0], threaded[0][0]) and np.array_equal(alone[0][1], threaded[0][1])
+    # and the batched env was not disturbed: same 200 steps again from the same start give the same state
+    q1 = venv.engine.get_state()[0].clone()
+    venv2 = HipDeepMimicVecEnv(2048, motion="run")
+    venv2.reset_tensor()
+    for i in range(200):
+        venv2.engine.fill_random_actions(act, i)
+        venv2.step_tensor(act)
+    assert torch.equal(q1, venv2.engine.get_state()[0])
+    venv.close()
+    venv2.close()
