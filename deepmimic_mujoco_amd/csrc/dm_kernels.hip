@@ -1169,34 +1169,34 @@ __device__ __noinline__ float fwd_constraint_wide(GDev &T, const int lane, const
     if (!(cost > 0)) { fa = fwa; fb = fwb; ra = rwa; rb = rwb; }
   }
   const float scale = T.pgs_scale, tol = T.tolerance;
+  const int max_iter = T.iterations;
   int iter = 0;
-  while (iter < T.iterations) {
-    float impv = 0;
+  while (iter < max_iter) {  // same sweep as the one-row-per-lane path: residuals only, forces committed per sweep
     float na = ar[lane], nb = ar[64 + lane];
+    const float nfa = -fa, nfb = -fb;
+    float rsa = ra, rsb = rb;
 #pragma unroll 1
-    for (int i = 0; i < nefc; i++) {
+    for (int i = 0; i < 64; i++) {
       const float ca = na, cb = nb;
-      if (i + 1 < nefc) { na = ar[(i + 1) * 128 + lane]; nb = ar[(i + 1) * 128 + 64 + lane]; }
-      const int src = i & 63;
-      float dli;
-      if (i < 64) {
-        const float fn = fmaxf(0.f, fmaf(-ra, ARinva, fa));
-        const float dl = fn - fa;
-        const float t = dl * fmaf(0.5f * dl, ARda, ra);
-        dli = rl(dl, src);
-        impv -= rl(t, src);
-        fa = (lane == src) ? fn : fa;
-      } else {
-        const float fn = fmaxf(0.f, fmaf(-rb, ARinvb, fb));
-        const float dl = fn - fb;
-        const float t = dl * fmaf(0.5f * dl, ARdb, rb);
-        dli = rl(dl, src);
-        impv -= rl(t, src);
-        fb = (lane == src) ? fn : fb;
-      }
+      na = ar[(i + 1) * 128 + lane]; nb = ar[(i + 1) * 128 + 64 + lane];   // nefc > 64: column i + 1 exists
+      const float dli = rl(fmaxf(nfa, -ra * ARinva), i);
+      rsa = (lane == i) ? ra : rsa;
       ra = fmaf(ca, dli, ra);
       rb = fmaf(cb, dli, rb);
     }
+#pragma unroll 1
+    for (int i = 64; i < nefc; i++) {
+      const float ca = na, cb = nb;
+      if (i + 1 < nefc) { na = ar[(i + 1) * 128 + lane]; nb = ar[(i + 1) * 128 + 64 + lane]; }
+      const float dli = rl(fmaxf(nfb, -rb * ARinvb), i - 64);
+      rsb = (lane == i - 64) ? rb : rsb;
+      ra = fmaf(ca, dli, ra);
+      rb = fmaf(cb, dli, rb);
+    }
+    const float dla = fmaxf(nfa, -rsa * ARinva), dlb = fmaxf(nfb, -rsb * ARinvb);
+    const float impv = -wave_sum(dla * fmaf(0.5f * dla, ARda, rsa) + dlb * fmaf(0.5f * dlb, ARdb, rsb));
+    fa += dla;
+    fb += dlb;
     iter++;
     if (impv * scale < tol) break;
   }
@@ -1289,7 +1289,11 @@ __device__ __forceinline__ float fwd_constraint(GDev &T, const int lane, const i
       for (int k = 0; k < DMK_NV; k++) ARd += J[k] * J[k];
       StaticFor<0, DMK_REGROW>::run([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        if (i >= nefc) return false;  // rows beyond nefc are never read
+        if (i >= nefc) {  // PGS walks the columns in blocks of four: zero the tail of the last block, stop after it
+          if ((i & 3) == 0) return false;
+          AR[i] = 0.f;
+          return true;
+        }
         float acc0 = 0, acc1 = 0;
 #pragma unroll
         for (int k = 0; k < DMK_NV; k += 2) {
@@ -1332,22 +1336,34 @@ __device__ __forceinline__ float fwd_constraint(GDev &T, const int lane, const i
         float cost = wave_sum(fw * (0.5f * (rw - bb) + bb));
         if (!(cost > 0)) { f = fw; r = rw; }
       }
-      // ---- projected Gauss-Seidel: row i's update is broadcast, every lane keeps its own residual
+      // ---- projected Gauss-Seidel.  Lane j's force changes only at step j of a sweep, so a sweep carries the
+      // residual alone: step i broadcasts dl_i = max(-f_i, -r_i / A_ii) (= projected force minus force) and every
+      // lane updates its residual; lane i records the residual it saw.  The force and the cost decrease
+      // (mj_solPGS "improvement") are committed once per sweep from the recorded residual.  Six VALU
+      // instructions per row on a four-deep dependent chain; the row bound is tested once per block of four
+      // (a row >= nefc has f = 0, 1/A_ii = 0 => dl = 0, and its column was zeroed above).
       const float scale = T.pgs_scale, tol = T.tolerance;
+      const int max_iter = T.iterations;
       int iter = 0;
-      while (iter < T.iterations) {
-        float impv = 0;
-        StaticFor<0, DMK_REGROW>::run([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          if (i >= nefc) return false;
-          // every lane evaluates its own row; only row i's update is committed and broadcast
-          const float fn = fmaxf(0.f, fmaf(-r, ARinv, f));
-          const float dl = fn - f;
-          const float t = dl * fmaf(0.5f * dl, ARd, r);   // cost decrease of row i if lane == i
-          const float dli = rl(dl, i);
-          impv -= rl(t, i);
-          r = fmaf(AR[i], dli, r);
-          f = (lane == i) ? fn : f;
+      while (iter < max_iter) {
+        int lane_s = lane;
+        asm volatile("" : "+v"(lane_s));  // keeps the per-row lane compares inside the sweep (else 64 SGPRs of masks spill)
+        const float nf = -f;
+        float rs = r;
+        StaticFor<0, DMK_REGROW / 4>::run([&](auto bc) {
+          constexpr int b = decltype(bc)::value * 4;
+          if (b >= nefc) return false;
+          auto step = [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const float dl = fmaxf(nf, -r * ARinv);
+            const float dli = rl(dl, i);
+            rs = (lane_s == i) ? r : rs;
+            r = fmaf(AR[i], dli, r);
+          };
+          step(std::integral_constant<int, b>{});
+          step(std::integral_constant<int, b + 1>{});
+          step(std::integral_constant<int, b + 2>{});
+          step(std::integral_constant<int, b + 3>{});
           return true;
         });
         if (nefc > DMK_REGROW) {                            // overflow columns, streamed one row ahead
@@ -1356,15 +1372,15 @@ __device__ __forceinline__ float fwd_constraint(GDev &T, const int lane, const i
           for (int i = DMK_REGROW; i < nefc; i++) {
             const float acur = anext;
             if (i + 1 < nefc) anext = arx[(i + 1 - DMK_REGROW) * 64];
-            const float fn = fmaxf(0.f, fmaf(-r, ARinv, f));
-            const float dl = fn - f;
-            const float t = dl * fmaf(0.5f * dl, ARd, r);
+            const float dl = fmaxf(nf, -r * ARinv);
             const float dli = rl(dl, i);
-            impv -= rl(t, i);
+            rs = (lane_s == i) ? r : rs;
             r = fmaf(acur, dli, r);
-            f = (lane == i) ? fn : f;
           }
         }
+        const float dl = fmaxf(nf, -rs * ARinv);
+        const float impv = -wave_sum(dl * fmaf(0.5f * dl, ARd, rs));
+        f += dl;
         iter++;
         if (impv * scale < tol) break;
       }
