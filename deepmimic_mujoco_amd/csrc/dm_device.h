@@ -99,8 +99,11 @@ struct EnvLds {
     struct {
       float crb[DMK_NB][10];
       float qloc[DMK_NB][8];          // body rotation relative to its parent (4) + offset in the parent frame (3)
-      float cdofdot[DMK_NV][6];
-      float cacc[DMK_NB][6], cfrc[DMK_NB][6], cfrcsub[DMK_NB][6];
+      union {
+        struct { float cdofdot[DMK_NV][6]; float cacc[DMK_NB][6]; };
+        alignas(16) float mbuf[DMK_NV][8];   // I_crb(body(k)) cdof_k per dof, broadcast while the columns of M are built
+      };
+      float cfrc[DMK_NB][6], cfrcsub[DMK_NB][6];
     } v;
     struct {
       float tr[20][DM_NV + 1];        // force-weighted constraint rows, transposed through LDS (finish)

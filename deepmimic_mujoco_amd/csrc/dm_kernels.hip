@@ -69,6 +69,30 @@ struct StaticFor {
 __device__ __forceinline__ float rl(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
+// a where the lane's bit is set in the compile-time lane mask, b elsewhere: one v_cndmask with the mask in SGPRs
+// (a per-lane bit test would cost three VALU instructions)
+template <unsigned long long MASK>
+__device__ __forceinline__ float lane_sel(float a, float b) {
+  float out;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(out) : "v"(b), "v"(a), "s"(MASK));
+  return out;
+}
+template <unsigned long long MASK>
+__device__ __forceinline__ int lane_sel_i(int a, int b) {
+  int out;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(out) : "v"(b), "v"(a), "s"(MASK));
+  return out;
+}
+// Column elimination step for dof K: walk the static ancestor chain I = parent(K), parent(parent(K)), ...
+template <int K, int I>
+struct ElimAnc {
+  static __device__ __forceinline__ void run(float (&C)[DMK_NV], const float Cs) {
+    if constexpr (I >= 0) {
+      C[I] = fmaf(-rl(Cs, I), C[K], C[I]);
+      ElimAnc<K, (I >= 0 ? topo::PARENT[I >= 0 ? I : 0] : -1)>::run(C, Cs);
+    }
+  }
+};
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
@@ -626,64 +650,65 @@ __device__ __forceinline__ void fwd_smooth(GDev &T, const int lane) {
     for (int i = 0; i < 10; i++) S.u.v.crb[lb][i] = acc[i];
   }
   SYNC();
-  // ---- row i of M in the registers of lane i, indexed by the ABSOLUTE depth of the ancestor:
-  // Mr[d] = M[i][ancestor of i at depth d] (d < depth_i), Md = M[i][i]
-  float Mr[DMK_MAXANC], Md = 1.f;
-  for (int d = 0; d < DMK_MAXANC; d++) Mr[d] = 0.f;
-  if (isdof) {
-    float buf[6], cd[6], I[10];
-    for (int i = 0; i < 10; i++) I[i] = S.u.v.crb[d_body][i];
-    for (int i = 0; i < 6; i++) cd[i] = S.cdof[lk][i];
-    mul_inert_vec(buf, I, cd);
-    Md = T.d_arm[lk];
-    for (int i = 0; i < 6; i++) Md += cd[i] * buf[i];
-#pragma unroll
-    for (int d = 0; d < DMK_MAXANC; d++) {
-      const int j = T.d_ancabs[lk][d];
-      if (d < d_nanc) {
-        float v = 0;
-        for (int i = 0; i < 6; i++) v += S.cdof[j][i] * buf[i];
-        Mr[d] = v;
-      }
+  // ---- M by COLUMNS: lane j keeps C[k] = M[k][j] for every dof k of its subtree (0 elsewhere).  Lane k publishes
+  // buf_k = I_crb(body(k)) cdof_k; every lane dots its own cdof with each buf_k (uniform LDS reads), the static lane
+  // set "ancestor-or-self of k" masks the result, the armature goes on the diagonal.  All register indices are static.
+  float C[DMK_NV];
+  {
+    float cd[6] = {0, 0, 0, 0, 0, 0};
+    if (isdof) {
+      float buf[6], I[10];
+      for (int i = 0; i < 10; i++) I[i] = S.u.v.crb[d_body][i];
+      for (int i = 0; i < 6; i++) cd[i] = S.cdof[lk][i];
+      mul_inert_vec(buf, I, cd);
+      for (int i = 0; i < 6; i++) S.u.v.mbuf[lk][i] = buf[i];
     }
+    SYNC();
+    const float armv = isdof ? T.d_arm[lk] : 0.f;
+    StaticFor<0, DMK_NV>::run([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      float dot = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) dot = fmaf(cd[i], g_S.u.v.mbuf[k][i], dot);
+      const float off = lane_sel<topo::anc_mask(k)>(dot, 0.f);                 // strict ancestors of k keep M[k][j]
+      C[k] = lane_sel<(1ull << k)>(dot + armv, off);                           // lane k: diagonal + armature
+      return true;
+    });
   }
   PROF(2);
-  // ---- L^T D L in registers: eliminate dof k = 33..1; its row is broadcast with v_readlane, every
-  // ancestor lane i applies M[i][j] -= M[k][j] M[k][i] / M[k][k].  Slots d >= depth_i of a lane hold
-  // values that are never read, so the update needs no per-slot predicate.
+  // ---- L^T D L on the columns: eliminate dof k = 33..1.  M[k][k] and the multipliers M[k][i] / M[k][k] of the
+  // ancestors i of k are broadcast from static lanes with v_readlane; every lane applies
+  // C[i] -= C[k] * M[k][i] / M[k][k] to the registers of the ancestors i — lanes outside the ancestor set of k hold
+  // C[k] = 0, so no predicate is needed.  2 VALU per (k, ancestor) pair, 276 pairs.
+  StaticFor<0, DMK_NV - 1>::run([&](auto ic) {
+    constexpr int k = DMK_NV - 1 - decltype(ic)::value;   // 33 .. 1
+    const float rk = __builtin_amdgcn_rcpf(rl(C[k], k));
+    const float Cs = C[k] * rk;
+    ElimAnc<k, topo::PARENT[k]>::run(C, Cs);
+    return true;
+  });
+  // publish the factor in the sparse MuJoCo layout (row k: M(k,k), M(k,parent), ...), rows UNSCALED:
+  // L[i][j] = M[i][j] * dinv[i] is applied by the users.  Lane j owns M[k][j] at S.M[MADR[k] + NANC[k] - depth_j];
+  // lanes outside the ancestor set of k write to a spare slot.
+  const int d_nanc_s = isdof ? d_nanc : 0;
   {
-    const uint64_t desc = T.d_desc[lk];   // bit k: dof k is a strict descendant of this lane's dof
-    const bool b0 = d_nanc & 1, b1 = d_nanc & 2, b2 = d_nanc & 4, b3 = d_nanc & 8;
-#pragma unroll 1
-    for (int kk = DMK_NV - 1; kk >= 1; kk--) {
-      const float rk = __builtin_amdgcn_rcpf(rl(Md, kk));
-      float val[DMK_MAXANC];   // row kk; slots beyond its depth hold finite never-read values, no predicate needed
-#pragma unroll
-      for (int d = 0; d < DMK_MAXANC; d++) val[d] = rl(Mr[d], kk);
-      // M[kk][this lane's dof] = val[depth of this lane]: 4-level select tree on the bits of the depth
-      const float s01 = b0 ? val[1] : val[0], s23 = b0 ? val[3] : val[2], s45 = b0 ? val[5] : val[4];
-      const float s67 = b0 ? val[7] : val[6], s89 = b0 ? val[9] : val[8], sab = b0 ? val[11] : val[10];
-      const float t0 = b1 ? s23 : s01, t1 = b1 ? s67 : s45, t2 = b1 ? sab : s89;
-      const float mki = b3 ? t2 : (b2 ? t1 : t0);
-      const float t = (isdof && ((desc >> kk) & 1ull)) ? mki * rk : 0.f;
-#pragma unroll
-      for (int d = 0; d < DMK_MAXANC; d++) Mr[d] = fmaf(-val[d], t, Mr[d]);
-      Md = fmaf(-mki, t, Md);
-    }
+    StaticFor<0, DMK_NV>::run([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      const int real = topo::MADR[k] + topo::NANC[k] - d_nanc_s;
+      const int idx = lane_sel_i<(topo::anc_mask(k) | (1ull << k))>(real, DM_NM + 1);
+      g_S.M[idx] = C[k];
+      return true;
+    });
   }
-  // publish the factor in the sparse MuJoCo layout (row i: M(i,i), M(i,parent), ...), rows UNSCALED:
-  // L[i][j] = M[i][j] * dinv[i] is applied by the users
+  SYNC();
   float dv = 0.f;
   const int mrow = T.d_madr[lk] + d_nanc;          // S.M[mrow - depth(j)] = M[lane][j]
   const uint64_t ancm = T.d_ancm[lk];              // bit j: dof j is a strict ancestor of this lane's dof
   if (isdof) {
+    const float Md = S.M[T.d_madr[lk]];
     dv = 1.0f / Md;
     S.dinv[lk] = dv;
     S.dsqrtinv[lk] = 1.0f / sqrtf(Md);
-    S.M[mrow - d_nanc] = Md;
-#pragma unroll
-    for (int d = 0; d < DMK_MAXANC; d++)
-      if (d < d_nanc) S.M[mrow - d] = Mr[d];
   }
   SYNC();
   PROF(3);
