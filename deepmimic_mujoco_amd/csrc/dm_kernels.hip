@@ -737,7 +737,7 @@ __device__ __forceinline__ void fwd_smooth(GDev &T, const int lane) {
     if (lb == 1) {
       for (int k = 0; k < 3; k++) {
         const float qv = S.qvel[k];
-        for (int i = 0; i < 6; i++) { S.u.v.cdofdot[k][i] = 0; cv[i] += S.cdof[k][i] * qv; }
+        for (int i = 0; i < 6; i++) cv[i] += S.cdof[k][i] * qv;
       }
       float dd[3][6];
 #pragma unroll
@@ -749,7 +749,7 @@ __device__ __forceinline__ void fwd_smooth(GDev &T, const int lane) {
 #pragma unroll
       for (int k = 3; k < 6; k++) {
         const float qv = S.qvel[k];
-        for (int i = 0; i < 6; i++) { S.u.v.cdofdot[k][i] = dd[k - 3][i]; u[i] += dd[k - 3][i] * qv; cv[i] += S.cdof[k][i] * qv; }
+        for (int i = 0; i < 6; i++) { u[i] += dd[k - 3][i] * qv; cv[i] += S.cdof[k][i] * qv; }
       }
     } else {
 #pragma unroll
@@ -760,7 +760,7 @@ __device__ __forceinline__ void fwd_smooth(GDev &T, const int lane) {
           const float qv = S.qvel[k];
           for (int i = 0; i < 6; i++) cd[i] = S.cdof[k][i];
           cross_motion(dd, cv, cd);
-          for (int i = 0; i < 6; i++) { S.u.v.cdofdot[k][i] = dd[i]; u[i] += dd[i] * qv; cv[i] += cd[i] * qv; }
+          for (int i = 0; i < 6; i++) { u[i] += dd[i] * qv; cv[i] += cd[i] * qv; }
         }
       }
     }
