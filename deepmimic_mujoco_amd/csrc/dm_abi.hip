@@ -28,7 +28,9 @@ struct DmEngine {
   float *debug = nullptr;
   int32_t *dOrder = nullptr;   // slot -> env permutation for dm_step (longest-first)
   int32_t *dCost = nullptr;    // per-env work estimate written by dm_step
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  static constexpr int NEV = 512;              // ring of event pairs: one per dm_step while timing is on
+  hipEvent_t ev0[NEV] = {}, ev1[NEV] = {};
+  long nrec = 0;                               // launches recorded since dm_enable_timing(1)
   bool timing = false;
   float last_ms = 0;
   std::string err;
@@ -209,8 +211,7 @@ extern "C" int dm_create(const DmModel *model, const DmConfig *cfg, DmHandle *ou
     hipFree(e->dArScratch); hipFree(e->dState); hipFree(e->dT); delete e; return DM_ENOMEM;
   }
   hipMemset(e->dCost, 0, e->N * sizeof(int32_t));
-  hipEventCreate(&e->ev0);
-  hipEventCreate(&e->ev1);
+  for (int i = 0; i < DmEngine::NEV; i++) { hipEventCreate(&e->ev0[i]); hipEventCreate(&e->ev1[i]); }
   *out = e;
   return DM_OK;
 }
@@ -225,8 +226,7 @@ extern "C" int dm_destroy(DmHandle e) {
   if (e->dOrder) hipFree(e->dOrder);
   if (e->dCost) hipFree(e->dCost);
   if (e->dT) hipFree(e->dT);
-  if (e->ev0) hipEventDestroy(e->ev0);
-  if (e->ev1) hipEventDestroy(e->ev1);
+  for (int i = 0; i < DmEngine::NEV; i++) { if (e->ev0[i]) hipEventDestroy(e->ev0[i]); if (e->ev1[i]) hipEventDestroy(e->ev1[i]); }
   delete e;
   return DM_OK;
 }
@@ -347,7 +347,8 @@ static int launch(DmEngine *e, DmLaunch &P, int nslots, void *stream) {
   if (e->clipL[0] < 1) return fail(e, DM_EINVAL, "no clip loaded (dm_load_clip clip 0 first)");
   HIPCHK(e, hipSetDevice(e->cfg.device));
   hipStream_t s = (hipStream_t)stream;
-  if (e->timing) hipEventRecord(e->ev0, s);
+  const int evi = (int)(e->nrec % DmEngine::NEV);
+  if (e->timing) hipEventRecord(e->ev0[evi], s);
   const dim3 grid((P.nslots + DMK_ENVS_PER_BLOCK - 1) / DMK_ENVS_PER_BLOCK), block(64 * DMK_ENVS_PER_BLOCK);
   if (e->cfg.task == DM_TASK_COMBINED) {
     if (e->clipL[1] < 1 || e->clipL[2] < 2) return fail(e, DM_EINVAL, "combined task needs clips 0,1,2 = walk, run, getup");
@@ -355,7 +356,7 @@ static int launch(DmEngine *e, DmLaunch &P, int nslots, void *stream) {
   } else {
     hipLaunchKernelGGL(dm_step_kernel, grid, block, 0, s, P);
   }
-  if (e->timing) hipEventRecord(e->ev1, s);
+  if (e->timing) { hipEventRecord(e->ev1[evi], s); e->nrec++; }
   HIPCHK(e, hipGetLastError());
   return DM_OK;
 }
@@ -478,11 +479,28 @@ extern "C" int dm_fill_random_actions(DmHandle e, float *actions, uint32_t step_
 extern "C" int dm_enable_timing(DmHandle e, int enable) {
   if (!e) return DM_EINVAL;
   e->timing = enable != 0;
+  e->nrec = 0;
   return DM_OK;
 }
 extern "C" int dm_last_step_ms(DmHandle e, float *ms) {
-  if (!e || !ms || !e->timing) return DM_EINVAL;
-  HIPCHK(e, hipEventSynchronize(e->ev1));
-  HIPCHK(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
+  if (!e || !ms || !e->timing || e->nrec < 1) return DM_EINVAL;
+  const int i = (int)((e->nrec - 1) % DmEngine::NEV);
+  HIPCHK(e, hipEventSynchronize(e->ev1[i]));
+  HIPCHK(e, hipEventElapsedTime(ms, e->ev0[i], e->ev1[i]));
+  return DM_OK;
+}
+extern "C" int dm_mean_step_ms(DmHandle e, float *ms, int32_t *count) {
+  if (!e || !ms || !e->timing || e->nrec < 1) return DM_EINVAL;
+  const long n = e->nrec < DmEngine::NEV ? e->nrec : DmEngine::NEV;
+  double acc = 0;
+  for (long k = 0; k < n; k++) {
+    const int i = (int)((e->nrec - 1 - k) % DmEngine::NEV);
+    float t = 0;
+    HIPCHK(e, hipEventSynchronize(e->ev1[i]));
+    HIPCHK(e, hipEventElapsedTime(&t, e->ev0[i], e->ev1[i]));
+    acc += t;
+  }
+  *ms = (float)(acc / (double)n);
+  if (count) *count = (int32_t)n;
   return DM_OK;
 }
