@@ -93,6 +93,31 @@ struct ElimAnc {
     }
   }
 };
+// Triangular solves with the published sparse factor (lane = dof, rows UNSCALED: L[i][j] = M[i][j] * dinv[i]).
+// The broadcast value comes from a static lane, the factor entry from a per-lane base plus a static offset, and the
+// set of lanes a step touches is a compile-time lane mask: 5 instructions per step.
+// x <- L^-T x (then scaled by the caller).  negdep = -(depth of this lane's dof).
+__device__ __forceinline__ float solve_LT(float x, const float dv, const int negdep, const float *M) {
+  StaticFor<0, DMK_NV - 1>::run([&](auto ic) {
+    constexpr int i = DMK_NV - 1 - decltype(ic)::value;   // 33 .. 1
+    const float xi = rl(x * dv, i);
+    const float l = lane_sel<topo::anc_mask(i)>(M[topo::MADR[i] + topo::NANC[i] + negdep], 0.f);
+    x = fmaf(-l, xi, x);
+    return true;
+  });
+  return x;
+}
+// z <- z - M[:, j] x_j with x = z * dinv (D^-1 and L^-1 fused); mrow = MADR[lane] + depth(lane).
+__device__ __forceinline__ float solve_L(float x, const float dv, const int mrow, const float *M) {
+  StaticFor<0, DMK_NV - 1>::run([&](auto jc) {
+    constexpr int j = decltype(jc)::value;                 // 0 .. 32
+    const float xj = rl(x * dv, j);
+    const float l = lane_sel<topo::desc_mask(j)>(M[mrow - topo::NANC[j]], 0.f);
+    x = fmaf(-l, xj, x);
+    return true;
+  });
+  return x;
+}
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
@@ -805,23 +830,8 @@ __device__ __forceinline__ void fwd_smooth(GDev &T, const int lane) {
     if (da >= 0) act = T.d_gear[lk] * clampf(S.ctrl[da], T.d_clo[lk], T.d_chi[lk]);
     xs = -T.d_damp[lk] * S.qvel[lk] - bias + act;
   }
-  {
-    const uint64_t descm = T.d_desc[lk];
-#pragma unroll
-    for (int i = DMK_NV - 1; i >= 1; i--) {   // x <- L^-T x  (L[i][j] = M[i][j] * dinv[i])
-      const float xi = rl(xs * dv, i);
-      const bool isa = (descm >> i) & 1ull;    // this lane's dof is an ancestor of i
-      const float l = S.M[isa ? topo::MADR[i] + topo::NANC[i] - d_nanc : 0];
-      if (isa) xs -= l * xi;
-    }
-#pragma unroll
-    for (int j = 0; j < DMK_NV - 1; j++) {    // z <- z - M[:, j] x_j with x = z * dinv  (D^-1 and L^-1 fused)
-      const float xj = rl(xs * dv, j);
-      const bool isd = (ancm >> j) & 1ull;     // j is an ancestor of this lane's dof
-      const float l = S.M[isd ? mrow - topo::NANC[j] : 0];
-      if (isd) xs -= l * xj;
-    }
-  }
+  xs = solve_LT(xs, dv, -d_nanc_s, g_S.M);
+  xs = solve_L(xs, dv, isdof ? mrow : DMK_MAXANC, g_S.M);
   xs *= dv;
   if (isdof) S.qacc_smooth[lk] = xs;
   SYNC();
@@ -1236,13 +1246,7 @@ __device__ __noinline__ float fwd_constraint_wide(GDev &T, const int lane, const
   const int mrow = T.d_madr[lk] + T.d_nanc[lk];
   const uint64_t ancm = T.d_ancm[lk];
   v *= S.dsqrtinv[lk] * S.M[T.d_madr[lk]];               // z = D (D^-1/2 v)
-#pragma unroll
-  for (int j = 0; j < DMK_NV - 1; j++) {                 // x = L^-1 (.) with x = z * dinv
-    const float xj = rl(v * dv, j);
-    const bool isd = (ancm >> j) & 1ull;
-    const float l = S.M[isd ? mrow - topo::NANC[j] : 0];
-    if (isd) v -= l * xj;
-  }
+  v = solve_L(v, dv, (lane < DMK_NV) ? mrow : DMK_MAXANC, g_S.M);   // x = L^-1 (.) with x = z * dinv
   return xs + v * dv;
 }
 
@@ -1440,13 +1444,7 @@ __device__ __forceinline__ float fwd_constraint(GDev &T, const int lane, const i
       const int mrow = T.d_madr[lk] + T.d_nanc[lk];
       const uint64_t ancm = T.d_ancm[lk];
       v *= S.dsqrtinv[lk] * S.M[T.d_madr[lk]];               // z = D (D^-1/2 v)
-#pragma unroll
-      for (int j = 0; j < DMK_NV - 1; j++) {                 // x = L^-1 (.) with x = z * dinv
-        const float xj = rl(v * dv, j);
-        const bool isd = (ancm >> j) & 1ull;
-        const float l = S.M[isd ? mrow - topo::NANC[j] : 0];
-        if (isd) v -= l * xj;
-      }
+      v = solve_L(v, dv, (lane < DMK_NV) ? mrow : DMK_MAXANC, g_S.M);   // x = L^-1 (.) with x = z * dinv
       qacc_out = xs + v * dv;
 #ifndef DM_PROFILE
       if (dbg_force && lane < DMK_LANEROW) dbg_force[lane] = (lane < nefc) ? f : 0.f;
