@@ -180,6 +180,9 @@ static int check_model(DmEngine *e, const DmModel &m) {
   for (int k = 0; k < DM_NV; k++)
     if (m.dof_parent[k] != topo::PARENT[k] || m.dof_Madr[k] != topo::MADR[k])
       return fail(e, DM_EINVAL, "dof tree differs from the compiled-in topology (regenerate csrc/dm_topology.h)");
+  for (int b = 0; b < DM_NBODY; b++)
+    if (m.body_parent[b] != topo::BPARENT[b])
+      return fail(e, DM_EINVAL, "body tree differs from the compiled-in topology (regenerate csrc/dm_topology.h)");
   return DM_OK;
 }
 

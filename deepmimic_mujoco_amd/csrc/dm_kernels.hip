@@ -666,13 +666,19 @@ __device__ __forceinline__ void fwd_smooth(GDev &T, const int lane) {
   SYNC();
   PROF(1);
   // ---- composite inertia per body via the subtree mask (lane = body)
-  if (isbody) {
+  {
+    // body c adds its cinert to c and to every ancestor of c: a compile-time lane set (dm_topology.h)
     float acc[10];
     for (int i = 0; i < 10; i++) acc[i] = 0;
-    for (int c = 1; c < DMK_NB; c++)
-      if ((b_sub >> c) & 1u)
-        for (int i = 0; i < 10; i++) acc[i] += S.cinert[c][i];
-    for (int i = 0; i < 10; i++) S.u.v.crb[lb][i] = acc[i];
+    StaticFor<1, DMK_NB>::run([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      const float w = lane_sel<topo::body_ancself_mask(c)>(1.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 10; i++) acc[i] = fmaf(w, g_S.cinert[c][i], acc[i]);
+      return true;
+    });
+    if (isbody)
+      for (int i = 0; i < 10; i++) S.u.v.crb[lb][i] = acc[i];
   }
   SYNC();
   // ---- M by COLUMNS: lane j keeps C[k] = M[k][j] for every dof k of its subtree (0 elsewhere).  Lane k publishes
@@ -811,12 +817,17 @@ __device__ __forceinline__ void fwd_smooth(GDev &T, const int lane) {
   }
   SYNC();
   // Pass D (lane = body): subtree sums of cfrc
-  if (isbody) {
+  {
     float acc[6] = {0, 0, 0, 0, 0, 0};
-    for (int c = 1; c < DMK_NB; c++)
-      if ((b_sub >> c) & 1u)
-        for (int i = 0; i < 6; i++) acc[i] += S.u.v.cfrc[c][i];
-    for (int i = 0; i < 6; i++) S.u.v.cacc[lb][i] = acc[i];      // (scratch reuse: subtree force)
+    StaticFor<1, DMK_NB>::run([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      const float w = lane_sel<topo::body_ancself_mask(c)>(1.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 6; i++) acc[i] = fmaf(w, g_S.u.v.cfrc[c][i], acc[i]);
+      return true;
+    });
+    if (isbody)
+      for (int i = 0; i < 6; i++) S.u.v.cacc[lb][i] = acc[i];      // (scratch reuse: subtree force)
   }
   SYNC();
   PROF2(10);
