@@ -550,8 +550,15 @@ __device__ __forceinline__ void fwd_smooth(GDev &T, const int lane) {
     if (lb == 1) {
       for (int i = 0; i < 4; i++) q[i] = S.qpos[3 + i];
     } else {
+      {  // first hinge: q is still the identity (spelled out: without fast-math hipcc keeps the 0 * x products)
+        const int k = b_dofadr;
+        const float al[3] = {T.d_axis[k][0], T.d_axis[k][1], T.d_axis[k][2]};
+        S.xaxis[k][0] = al[0]; S.xaxis[k][1] = al[1]; S.xaxis[k][2] = al[2];       // parent-frame axis for now
+        const float c = S.cs[k][0], sn = S.cs[k][1];
+        q[0] = c; q[1] = al[0] * sn; q[2] = al[1] * sn; q[3] = al[2] * sn;
+      }
 #pragma unroll
-      for (int j = 0; j < 3; j++) {
+      for (int j = 1; j < 3; j++) {
         if (j < b_dofnum) {
           const int k = b_dofadr + j;
           const float al[3] = {T.d_axis[k][0], T.d_axis[k][1], T.d_axis[k][2]};
@@ -571,9 +578,12 @@ __device__ __forceinline__ void fwd_smooth(GDev &T, const int lane) {
   SYNC();
   // ---- P2 (lane = body): compose along the ancestor chain root -> self
   if (isbody) {
-    float q[4] = {1.f, 0.f, 0.f, 0.f}, pos[3] = {0.f, 0.f, 0.f};
+    // the chain always starts at the root body (byte 0 of b_chainb = 1): start from its local pose
+    float q[4], pos[3];
+    for (int i = 0; i < 4; i++) q[i] = S.u.v.qloc[1][i];
+    for (int i = 0; i < 3; i++) pos[i] = S.u.v.qloc[1][4 + i];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+    for (int c = 1; c < 4; c++) {
       const int cb = (b_chain4 >> (8 * c)) & 0xFF;
       if (cb != 0) {
         float ql[4], pl[3], t[3], qn[4];
