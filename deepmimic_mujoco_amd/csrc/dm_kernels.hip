@@ -920,28 +920,37 @@ __device__ __forceinline__ int fwd_collide(GDev &T, const int lane) {
               for (int i = 0; i < 3; i++) e[i] = x2[i] - ax[i] * z2[1];
               np_plane_sphere<1>(c, margin, x1, pn, e, z2[0]);
               c.t[0] = ax[0]; c.t[1] = ax[1]; c.t[2] = ax[2];
-            } else {  // box: the (at most 4) corners below the centre and within margin
-              float df[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
-              float dist = dot3(df, pn);
-              int cnt = 0;
+            } else {  // box: the (at most 4) corners below the centre and within margin, in corner order
+              // corner i = x2 + s0 A0 + s1 A1 + s2 A2 (A_j = half-size_j * column j of the box frame, s_j = +-1 from
+              // bit j of i), so its height over the centre is +-a0 +-a1 +-a2 with a_j = pn . A_j: the eight tests cost
+              // two additions each and only the (at most four) accepted corners are built
+              const float df[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
+              const float dist = dot3(df, pn);
+              float A[3][3], a[3];
+#pragma unroll
+              for (int j = 0; j < 3; j++) {
+                A[j][0] = M2[j] * z2[j]; A[j][1] = M2[3 + j] * z2[j]; A[j][2] = M2[6 + j] * z2[j];
+                a[j] = pn[0] * A[j][0] + pn[1] * A[j][1] + pn[2] * A[j][2];
+              }
+              unsigned okm = 0;
 #pragma unroll
               for (int i = 0; i < 8; i++) {
-                float v[3] = {z2[0] * ((i & 1) ? 1.f : -1.f), z2[1] * ((i & 2) ? 1.f : -1.f), z2[2] * ((i & 4) ? 1.f : -1.f)};
-                float corner[3];
-                mat_vec(corner, M2, v);
-                float ld = dot3(pn, corner);
-                bool ok = !(dist + ld > margin || ld > 0) && cnt < 4;
-                float cdist = dist + ld;
-                float cp[3] = {corner[0] + x2[0] - pn[0] * 0.5f * cdist, corner[1] + x2[1] - pn[1] * 0.5f * cdist,
-                               corner[2] + x2[2] - pn[2] * 0.5f * cdist};
+                const float ld = ((i & 1) ? a[0] : -a[0]) + ((i & 2) ? a[1] : -a[1]) + ((i & 4) ? a[2] : -a[2]);
+                okm |= (!(dist + ld > margin || ld > 0)) ? (1u << i) : 0u;
+              }
 #pragma unroll
-                for (int s = 0; s < 4; s++)
-                  if (ok && cnt == s) {
-                    c.d[s] = cdist;
-                    for (int q = 0; q < 3; q++) { c.p[s][q] = cp[q]; c.n[s][q] = pn[q]; }
-                    c.valid |= 1 << s;
-                  }
-                cnt += ok ? 1 : 0;
+              for (int s = 0; s < 4; s++) {
+                if (okm) {
+                  const int i = __ffs(okm) - 1;
+                  okm &= okm - 1;
+                  const float s0 = (i & 1) ? 1.f : -1.f, s1 = (i & 2) ? 1.f : -1.f, s2 = (i & 4) ? 1.f : -1.f;
+                  const float corner[3] = {s0 * A[0][0] + s1 * A[1][0] + s2 * A[2][0], s0 * A[0][1] + s1 * A[1][1] + s2 * A[2][1],
+                                           s0 * A[0][2] + s1 * A[1][2] + s2 * A[2][2]};
+                  const float cdist = dist + dot3(pn, corner);
+                  c.d[s] = cdist;
+                  for (int q = 0; q < 3; q++) { c.p[s][q] = corner[q] + x2[q] - pn[q] * 0.5f * cdist; c.n[s][q] = pn[q]; }
+                  c.valid |= 1 << s;
+                }
               }
             }
           } else if (t2 != DM_GEOM_BOX) {  // sphere/capsule vs sphere/capsule
@@ -1137,10 +1146,8 @@ __device__ __forceinline__ void build_row(GDev &T, EnvLds &S, const int r, const
         const float4 ca = *reinterpret_cast<const float4 *>(&S.cdof[k][0]);
         const float2 cb = *reinterpret_cast<const float2 *>(&S.cdof[k][4]);
         float val = ca.x * wa[0] + ca.y * wa[1] + ca.z * wa[2] + ca.w * wl[0] + cb.x * wl[1] + cb.y * wl[2];
-        float sg = (float)((int)((cm2 >> k) & 1ull) - (int)((cm1 >> k) & 1ull));
-        float j = sg * val;
-        if (rtype == 0) j = (k == ldof) ? lsign : 0.f;
-        if (rtype < 0) j = 0.f;
+        float sg = (float)((int)((cm2 >> k) & 1ull) - (int)((cm1 >> k) & 1ull));   // 0 for limit / unused rows (no chains)
+        float j = (k == ldof) ? lsign : sg * val;
         J[k] = j;
         vel += j * S.qvel[k];
         jqs += j * S.qacc_smooth[k];
