@@ -1396,26 +1396,34 @@ __device__ __forceinline__ float fwd_constraint(GDev &T, const int lane, const i
       // ---- projected Gauss-Seidel.  Lane j's force changes only at step j of a sweep, so a sweep carries the
       // residual alone: step i broadcasts dl_i = max(-f_i, -r_i / A_ii) (= projected force minus force) and every
       // lane updates its residual; lane i records the residual it saw.  The force and the cost decrease
-      // (mj_solPGS "improvement") are committed once per sweep from the recorded residual.  Six VALU
-      // instructions per row on a four-deep dependent chain; the row bound is tested once per block of four
-      // (a row >= nefc has f = 0, 1/A_ii = 0 => dl = 0, and its column was zeroed above).
+      // (mj_solPGS "improvement") are committed once per sweep from the recorded residual.  The row bound is tested
+      // once per block of four (a row >= nefc has f = 0, 1/A_ii = 0 => dl = 0, and its column was zeroed above).
+      // The residual is carried scaled, g = -r / A_ii, with the columns pre-multiplied by -1 / A_ii of the lane's
+      // own row: the step is then dl_i = max(-f_i, g_i) and g += As[i] dl_i — five VALU per row.
       const float scale = T.pgs_scale, tol = T.tolerance;
       const int max_iter = T.iterations;
+      const float nAinv = -ARinv;
+      float g = r * nAinv;
+      StaticFor<0, DMK_REGROW / 4>::run([&](auto bc) {
+        constexpr int b = decltype(bc)::value * 4;
+        if (b >= nefc) return false;
+        AR[b] *= nAinv; AR[b + 1] *= nAinv; AR[b + 2] *= nAinv; AR[b + 3] *= nAinv;
+        return true;
+      });
       int iter = 0;
       while (iter < max_iter) {
         int lane_s = lane;
         asm volatile("" : "+v"(lane_s));  // keeps the per-row lane compares inside the sweep (else 64 SGPRs of masks spill)
         const float nf = -f;
-        float rs = r;
+        float gs = g;
         StaticFor<0, DMK_REGROW / 4>::run([&](auto bc) {
           constexpr int b = decltype(bc)::value * 4;
           if (b >= nefc) return false;
           auto step = [&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            const float dl = fmaxf(nf, -r * ARinv);
-            const float dli = rl(dl, i);
-            rs = (lane_s == i) ? r : rs;
-            r = fmaf(AR[i], dli, r);
+            const float dli = rl(fmaxf(nf, g), i);
+            gs = (lane_s == i) ? g : gs;
+            g = fmaf(AR[i], dli, g);
           };
           step(std::integral_constant<int, b>{});
           step(std::integral_constant<int, b + 1>{});
@@ -1427,16 +1435,15 @@ __device__ __forceinline__ float fwd_constraint(GDev &T, const int lane, const i
           float anext = arx[0];
 #pragma unroll 1
           for (int i = DMK_REGROW; i < nefc; i++) {
-            const float acur = anext;
+            const float acur = anext * nAinv;
             if (i + 1 < nefc) anext = arx[(i + 1 - DMK_REGROW) * 64];
-            const float dl = fmaxf(nf, -r * ARinv);
-            const float dli = rl(dl, i);
-            rs = (lane_s == i) ? r : rs;
-            r = fmaf(acur, dli, r);
+            const float dli = rl(fmaxf(nf, g), i);
+            gs = (lane_s == i) ? g : gs;
+            g = fmaf(acur, dli, g);
           }
         }
-        const float dl = fmaxf(nf, -rs * ARinv);
-        const float impv = -wave_sum(dl * fmaf(0.5f * dl, ARd, rs));
+        const float dl = fmaxf(nf, gs);
+        const float impv = -wave_sum(dl * ARd * (0.5f * dl - gs));   // dl (dl A_ii / 2 + r) with r = -g A_ii
         f += dl;
         iter++;
         if (impv * scale < tol) break;
