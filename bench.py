@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--motion", default="walk")
     ap.add_argument("--actions", default="random", choices=["random", "zero"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the auxiliary two-sub-batch measurement (profiling runs)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     args = ap.parse_args()
 
@@ -145,7 +146,7 @@ def main():
     # streams with no barrier between them, as a double-buffered rollout does (policy on one half while the other
     # half simulates): the ramp-down of one launch overlaps the next launch of the other half.
     pipelined = None
-    if world == 1 and N % 2 == 0 and args.actions == "random":
+    if world == 1 and N % 2 == 0 and args.actions == "random" and not args.no_pipelined:
         K, n2 = 2, N // 2
         subs = []
         for k in range(K):
