@@ -25,7 +25,7 @@ EXPORTS = ["dm_default_config", "dm_create", "dm_destroy", "dm_last_error", "dm_
            "dm_load_clip", "dm_set_env_clips", "dm_reset", "dm_step", "dm_step_forced",
            "dm_set_state", "dm_get_state", "dm_get_counters", "dm_set_counters", "dm_set_debug",
            "dm_fill_random_actions", "dm_last_step_ms", "dm_enable_timing", "dm_get_work",
-           "dm_set_clip_flags", "dm_obs_dim", "dm_terms_dim", "dm_get_env_clips", "dm_mean_step_ms"]
+           "dm_set_clip_flags", "dm_obs_dim", "dm_terms_dim", "dm_get_env_clips", "dm_mean_step_ms", "dm_ppo_loss"]
 
 
 class DmConfig(C.Structure):
@@ -80,6 +80,7 @@ def load_library():
     L.dm_fill_random_actions.argtypes = [vp, vp, C.c_uint32, vp]
     L.dm_last_step_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.dm_enable_timing.argtypes = [vp, i32]
+    L.dm_ppo_loss.argtypes = [vp] * 7 + [i32, i32, C.c_float, C.c_float, C.c_float, i32] + [vp] * 6
     L.dm_mean_step_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     for name in EXPORTS:
         if name not in ("dm_default_config", "dm_last_error"):

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "dm_kernels.hip"
+#include "dm_ppo.hip"
 
 struct DmEngine {
   DmConfig cfg;

@@ -1,0 +1,159 @@
+// Fused PPO clipped-surrogate loss, forward and backward in one pass (gfx950).
+//
+// Replaces, in the learner of the rollout loop (reference: src/sb3_ppo.py:307-313 -> [EXT] SB3 PPO.train,
+// DiagGaussianDistribution.log_prob / entropy, F.mse_loss), the ~70 elementwise / reduction kernels PyTorch
+// launches per minibatch between the policy head and the loss scalar — the optimizer step of the reference's
+// [256,128] network is launch-bound.  Semantics (SB3 defaults): per-minibatch advantage normalisation
+// (adv - mean) / (std_unbiased + 1e-8); ratio = exp(logp - old_logp);
+//   policy_loss  = -mean(min(adv * ratio, adv * clamp(ratio, 1 - eps, 1 + eps)))
+//   value_loss   = mean((ret - value)^2)
+//   entropy_loss = -mean(entropy),  entropy = sum_j (0.5 + 0.5 log(2 pi) + log_std_j)
+//   loss = policy_loss + ent_coef * entropy_loss + vf_coef * value_loss
+// Outputs the loss terms and d loss / d (mean, log_std, value).  One thread per sample; B x A <= 4096 x 28 floats, so
+// the kernel is latency-, not bandwidth-bound: what matters is that it is two launches instead of seventy.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+
+constexpr int PPO_MAXA = 32;     // action dimensions supported (28 here)
+constexpr int PPO_BLOCK = 256;
+
+__device__ __forceinline__ float ppo_wave_sum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// block-wide sum of `v`, result valid in thread 0
+__device__ __forceinline__ float ppo_block_sum(float v, float *red) {
+  v = ppo_wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float s = 0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) s += red[i];
+  return s;
+}
+
+// stats[0] = mean(adv), stats[1] = 1 / (std_unbiased(adv) + 1e-8); also clears the accumulators of the main kernel
+__global__ void ppo_prepare_kernel(const float *adv, int B, int normalize, float *stats, float *out8, float *grad_log_std, int A) {
+  __shared__ float red[16];
+  float s = 0;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) s += adv[i];
+  const float tot = ppo_block_sum(s, red);
+  __shared__ float mean_s;
+  if (threadIdx.x == 0) mean_s = tot / (float)B;
+  __syncthreads();
+  const float mean = mean_s;
+  float q = 0;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) { const float d = adv[i] - mean; q += d * d; }
+  const float qq = ppo_block_sum(q, red);
+  if (threadIdx.x == 0) {
+    if (normalize && B > 1) { stats[0] = mean; stats[1] = 1.0f / (sqrtf(qq / (float)(B - 1)) + 1e-8f); }
+    else { stats[0] = 0.f; stats[1] = 1.f; }
+  }
+  if (threadIdx.x < 8) out8[threadIdx.x] = 0.f;
+  if ((int)threadIdx.x < A) grad_log_std[threadIdx.x] = 0.f;
+}
+
+__global__ void ppo_loss_kernel(const float *mean, const float *log_std, const float *value, const float *act,
+                                const float *old_logp, const float *adv, const float *ret, int B, int A, float clip,
+                                float vf_coef, float ent_coef, const float *stats, float *grad_mean, float *grad_log_std,
+                                float *grad_value, float *out8) {
+  __shared__ float red[16];
+  __shared__ float ls_s[PPO_MAXA], iv_s[PPO_MAXA];
+  if ((int)threadIdx.x < A) { ls_s[threadIdx.x] = log_std[threadIdx.x]; iv_s[threadIdx.x] = expf(-2.f * log_std[threadIdx.x]); }
+  __syncthreads();
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool on = b < B;
+  const float invB = 1.0f / (float)B;
+  float z2[PPO_MAXA];              // ((a - mu) / sigma)^2 per action, reused for d/d log_std
+  float logp = 0, a_n = 0, dlogp = 0;
+  float pg = 0, vl = 0, kl = 0, cf = 0;
+  if (on) {
+    float sum_ls = 0;
+#pragma unroll
+    for (int j = 0; j < PPO_MAXA; j++) {
+      z2[j] = 0;
+      if (j < A) {
+        const float d = act[(size_t)b * A + j] - mean[(size_t)b * A + j];
+        z2[j] = d * d * iv_s[j];
+        logp += -0.5f * z2[j];
+        sum_ls += ls_s[j];
+      }
+    }
+    logp += -sum_ls - 0.5f * 1.8378770664093453f * (float)A;   // log(2 pi)
+    a_n = (adv[b] - stats[0]) * stats[1];
+    const float lr = logp - old_logp[b];
+    const float ratio = expf(lr);
+    const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+    const float p1 = a_n * ratio, p2 = a_n * rc;
+    pg = -fminf(p1, p2);
+    // d min(p1, p2) / d ratio: inside the clip range both branches carry a_n (ties split evenly by autograd: same sum);
+    // outside, only the unclipped branch has a gradient and only when it is the smaller one
+    const bool inside = (ratio >= 1.f - clip) && (ratio <= 1.f + clip);
+    const float dr = (inside || p1 < p2) ? a_n : 0.f;
+    dlogp = -invB * dr * ratio;
+    const float dv = value[b] - ret[b];
+    vl = dv * dv;
+    grad_value[b] = vf_coef * 2.f * invB * dv;
+    kl = (ratio - 1.f) - lr;                                  // SB3 approx_kl estimator
+    cf = (fabsf(ratio - 1.f) > clip) ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < PPO_MAXA; j++)
+      if (j < A) {
+        const float d = act[(size_t)b * A + j] - mean[(size_t)b * A + j];
+        grad_mean[(size_t)b * A + j] = dlogp * d * iv_s[j];
+      }
+  }
+  // block reductions -> atomics (16 blocks at B = 4096)
+  const float s_pg = ppo_block_sum(pg, red), s_vl = ppo_block_sum(vl, red);
+  const float s_kl = ppo_block_sum(kl, red), s_cf = ppo_block_sum(cf, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(&out8[1], s_pg * invB);
+    atomicAdd(&out8[2], s_vl * invB);
+    atomicAdd(&out8[4], s_kl * invB);
+    atomicAdd(&out8[5], s_cf * invB);
+  }
+#pragma unroll
+  for (int j = 0; j < PPO_MAXA; j++) {
+    if (j < A) {
+      const float g = ppo_block_sum(on ? dlogp * (z2[j] - 1.f) : 0.f, red);
+      if (threadIdx.x == 0) atomicAdd(&grad_log_std[j], g);
+    }
+  }
+}
+
+// loss = pg + ent_coef * (-entropy) + vf_coef * vl ; d loss / d log_std_j gets -ent_coef from the entropy term
+__global__ void ppo_finish_kernel(const float *log_std, int A, float vf_coef, float ent_coef, const float *stats, float *grad_log_std,
+                                  float *out8) {
+  if (threadIdx.x == 0) {
+    float ent = 0;
+    for (int j = 0; j < A; j++) ent += 0.5f + 0.5f * 1.8378770664093453f + log_std[j];
+    out8[3] = ent;
+    out8[0] = out8[1] + vf_coef * out8[2] - ent_coef * ent;
+    out8[6] = stats[0];
+    out8[7] = stats[1];
+  }
+  if ((int)threadIdx.x < A) grad_log_std[threadIdx.x] -= ent_coef;
+}
+
+}  // namespace
+
+// C-ABI (include/deepmimic_hip.h).  All pointers are device pointers; `scratch` holds >= 2 floats.
+extern "C" int dm_ppo_loss(const float *mean, const float *log_std, const float *value, const float *act, const float *old_logp,
+                           const float *adv, const float *ret, int B, int A, float clip_range, float vf_coef, float ent_coef,
+                           int normalize_advantage, float *grad_mean, float *grad_log_std, float *grad_value, float *out8,
+                           float *scratch, void *stream) {
+  if (!mean || !log_std || !value || !act || !old_logp || !adv || !ret || !grad_mean || !grad_log_std || !grad_value || !out8 ||
+      !scratch || B < 1 || A < 1 || A > PPO_MAXA)
+    return -22;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ppo_prepare_kernel, dim3(1), dim3(1024), 0, s, adv, B, normalize_advantage, scratch, out8, grad_log_std, A);
+  hipLaunchKernelGGL(ppo_loss_kernel, dim3((B + PPO_BLOCK - 1) / PPO_BLOCK), dim3(PPO_BLOCK), 0, s, mean, log_std, value, act,
+                     old_logp, adv, ret, B, A, clip_range, vf_coef, ent_coef, scratch, grad_mean, grad_log_std, grad_value, out8);
+  hipLaunchKernelGGL(ppo_finish_kernel, dim3(1), dim3(64), 0, s, log_std, A, vf_coef, ent_coef, scratch, grad_log_std, out8);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}

@@ -92,6 +92,45 @@ class ExtractedPolicy:
         return f @ self.p["WA"] + self.p["BA"]
 
 
+class FusedPPOLoss(torch.autograd.Function):
+    """loss = policy_loss + ent_coef * entropy_loss + vf_coef * value_loss of SB3's PPO.train, forward and backward in
+    one pass of `dm_ppo_loss` (csrc/dm_ppo.hip) on the current stream.  The gradient buffers are static per shape, so
+    the call can sit inside a captured hipGraph.  `stats` (8 floats, see include/deepmimic_hip.h) stays on the device."""
+
+    _bufs = {}
+
+    @staticmethod
+    def buffers(B, A, dev):
+        key = (B, A, str(dev))
+        if key not in FusedPPOLoss._bufs:
+            z = lambda *s: torch.zeros(*s, device=dev)
+            FusedPPOLoss._bufs[key] = dict(gm=z(B, A), gl=z(A), gv=z(B), out=z(8), scratch=z(8))
+        return FusedPPOLoss._bufs[key]
+
+    @staticmethod
+    def forward(ctx, mean, log_std, value, act, old_logp, adv, ret, clip_range, vf_coef, ent_coef, normalize):
+        from . import _lib
+        import ctypes as C
+        L = _lib.load_library()
+        B, A = mean.shape
+        b = FusedPPOLoss.buffers(B, A, mean.device)
+        args = [t.detach().contiguous().float() for t in (mean, log_std, value, act, old_logp, adv, ret)]
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rc = L.dm_ppo_loss(*[p(t) for t in args], B, A, float(clip_range), float(vf_coef), float(ent_coef),
+                           1 if normalize else 0, p(b["gm"]), p(b["gl"]), p(b["gv"]), p(b["out"]), p(b["scratch"]),
+                           C.c_void_p(torch.cuda.current_stream(mean.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("dm_ppo_loss failed (%d)" % rc)
+        ctx.b = b
+        ctx._keep = args
+        return b["out"][0]
+
+    @staticmethod
+    def backward(ctx, g):
+        b = ctx.b
+        return (g * b["gm"], g * b["gl"], g * b["gv"]) + (None,) * 8
+
+
 def compute_gae(rewards, values, dones, last_values, gamma, lam):
     """SB3 ``RolloutBuffer.compute_returns_and_advantage`` [EXT]: tensors [T, N]; dones[t] is the done
     flag returned by step t (so the value after it is not bootstrapped)."""
@@ -144,7 +183,7 @@ class PPO:
     def __init__(self, env, net_arch=(256, 128), n_steps=4096, batch_size=4096, n_epochs=20, learning_rate=4e-4,
                  gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5,
                  normalize_advantage=True, seed=0, device=None, buffer_dtype=torch.float32, policy=None,
-                 use_hip_graph=None):
+                 use_hip_graph=None, fused_loss=True):
         self.env = env
         self.device = device if device is not None else getattr(env, "device", torch.device("cpu"))
         self.n_envs = env.num_envs if env is not None else 0
@@ -152,6 +191,7 @@ class PPO:
         self.gamma, self.gae_lambda, self.clip_range = gamma, gae_lambda, clip_range
         self.ent_coef, self.vf_coef, self.max_grad_norm = ent_coef, vf_coef, max_grad_norm
         self.normalize_advantage = normalize_advantage
+        self.fused_loss = fused_loss          # dm_ppo_loss (HIP) for the loss tail when the batch is on the GPU
         self.buffer_dtype = buffer_dtype
         torch.manual_seed(seed)  # identical initial weights on every rank; no parameter broadcast needed
         self.obs_dim = int(env.observation_space.shape[0]) if env is not None else 67   # 67 DPEnv, 72 DPCombinedEnv
@@ -225,14 +265,24 @@ class PPO:
         self.stats["loss"] = float(loss_sum / max(nsteps, 1))   # one host sync per train() call
         return self.stats["loss"]
 
-    def _minibatch_step(self, obs, act, adv, ret, old_logp):
+    def _loss_torch(self, obs, act, adv, ret, old_logp):
+        """The loss of SB3 PPO.train written with PyTorch ops (CPU tests, and the reference for the fused kernel)."""
         if self.normalize_advantage and obs.shape[0] > 1:
             adv = (adv - adv.mean()) / (adv.std() + 1e-8)
         value, logp, entropy = self.policy.evaluate_actions(obs, act)
         ratio = torch.exp(logp - old_logp)
         pg = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - self.clip_range, 1 + self.clip_range)).mean()
         vl = torch.nn.functional.mse_loss(ret, value)
-        loss = pg + self.vf_coef * vl - self.ent_coef * entropy.mean()
+        return pg + self.vf_coef * vl - self.ent_coef * entropy.mean()
+
+    def _loss_fused(self, obs, act, adv, ret, old_logp):
+        mean = self.policy.action_net(self.policy.pi(obs))
+        value = self.policy.value_net(self.policy.vf(obs)).squeeze(-1)
+        return FusedPPOLoss.apply(mean, self.policy.log_std, value, act, old_logp, adv, ret, self.clip_range, self.vf_coef,
+                                  self.ent_coef, self.normalize_advantage and obs.shape[0] > 1)
+
+    def _minibatch_step(self, obs, act, adv, ret, old_logp):
+        loss = (self._loss_fused if (self.fused_loss and obs.is_cuda) else self._loss_torch)(obs, act, adv, ret, old_logp)
         self.optimizer.zero_grad(set_to_none=False)
         loss.backward()
         self.grad_sync()                         # the ONE collective of the data-parallel learner

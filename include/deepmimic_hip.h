@@ -158,6 +158,18 @@ int dm_last_step_ms(DmHandle h, float *ms);
 int dm_mean_step_ms(DmHandle h, float *ms, int32_t *count);
 int dm_enable_timing(DmHandle h, int enable);
 
+/* ---- learner side of the rollout loop --------------------------------------------------------------------------
+ * Fused PPO clipped-surrogate loss, forward + backward (csrc/dm_ppo.hip).  Replaces the elementwise / reduction tail of
+ * SB3's PPO.train [EXT] (called from src/sb3_ppo.py:307-313): log_prob and entropy of the diagonal Gaussian, ratio,
+ * clipped surrogate, F.mse_loss value loss, per-minibatch advantage normalisation, and their gradients.
+ * Device pointers: mean[B*A], log_std[A], value[B], act[B*A], old_logp[B], adv[B], ret[B] in; grad_mean[B*A],
+ * grad_log_std[A], grad_value[B] out; out8 = {loss, policy_loss, value_loss, entropy, approx_kl, clip_fraction,
+ * adv_mean, 1/(adv_std + 1e-8)}; scratch >= 2 floats.  A <= 32.  Stream-ordered; returns 0 or a negative DM_E* code. */
+int dm_ppo_loss(const float *mean, const float *log_std, const float *value, const float *act, const float *old_logp,
+                const float *adv, const float *ret, int B, int A, float clip_range, float vf_coef, float ent_coef,
+                int normalize_advantage, float *grad_mean, float *grad_log_std, float *grad_value, float *out8,
+                float *scratch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

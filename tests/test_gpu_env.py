@@ -301,3 +301,39 @@ def test_eval_env_in_thread_next_to_batched_env(model, clips, oracle_clips):
     assert torch.equal(q1, venv2.engine.get_state()[0])
     venv.close()
     venv2.close()
+
+
+def test_fused_ppo_loss_matches_autograd():
+    """dm_ppo_loss (HIP, forward + backward) against the PyTorch-op loss of SB3's PPO.train: loss terms and all
+    parameter gradients, with and without advantage normalisation, incl. samples outside the clip range."""
+    import torch
+    from deepmimic_mujoco_amd.ppo import PPO, MlpPolicy
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    for B, normalize in ((4096, True), (1000, False), (257, True)):
+        grads = {}
+        for fused in (False, True):
+            torch.manual_seed(5)
+            pol = MlpPolicy(net_arch=(64, 32)).to(dev)
+            with torch.no_grad():
+                pol.log_std.copy_(torch.linspace(-0.5, 0.3, 28))
+            ppo = PPO(None, policy=pol, device=dev, batch_size=B, normalize_advantage=normalize, use_hip_graph=False,
+                      fused_loss=fused, ent_coef=0.01)
+            g = torch.Generator(device=dev); g.manual_seed(11)
+            obs = torch.randn(B, 67, device=dev, generator=g)
+            act = torch.randn(B, 28, device=dev, generator=g) * 0.7
+            adv = torch.randn(B, device=dev, generator=g) * 2 + 0.3
+            ret = torch.randn(B, device=dev, generator=g)
+            with torch.no_grad():
+                _, logp, _ = pol.evaluate_actions(obs, act)
+            old_logp = logp + torch.randn(B, device=dev, generator=g) * 0.3     # ratios well outside [0.8, 1.2] too
+            loss = (ppo._loss_fused if fused else ppo._loss_torch)(obs, act, adv, ret, old_logp)
+            pol.zero_grad()
+            loss.backward()
+            grads[fused] = (float(loss.detach()), {n: p.grad.clone() for n, p in pol.named_parameters()})
+        l0, g0 = grads[False]
+        l1, g1 = grads[True]
+        assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0)), (l0, l1)
+        for n in g0:
+            scale = float(g0[n].abs().max()) + 1e-12
+            assert float((g0[n] - g1[n]).abs().max()) < 2e-5 * scale + 1e-9, (n, B, normalize)
