@@ -62,7 +62,6 @@ __global__ void ppo_loss_kernel(const float *mean, const float *log_std, const f
                                 const float *old_logp, const float *adv, const float *ret, int B, int A, float clip,
                                 float vf_coef, float ent_coef, const float *stats, float *grad_mean, float *grad_log_std,
                                 float *grad_value, float *out8) {
-  __shared__ float red[16];
   __shared__ float ls_s[PPO_MAXA], iv_s[PPO_MAXA];
   if ((int)threadIdx.x < A) { ls_s[threadIdx.x] = log_std[threadIdx.x]; iv_s[threadIdx.x] = expf(-2.f * log_std[threadIdx.x]); }
   __syncthreads();
@@ -108,21 +107,31 @@ __global__ void ppo_loss_kernel(const float *mean, const float *log_std, const f
         grad_mean[(size_t)b * A + j] = dlogp * d * iv_s[j];
       }
   }
-  // block reductions -> atomics (16 blocks at B = 4096)
-  const float s_pg = ppo_block_sum(pg, red), s_vl = ppo_block_sum(vl, red);
-  const float s_kl = ppo_block_sum(kl, red), s_cf = ppo_block_sum(cf, red);
-  if (threadIdx.x == 0) {
-    atomicAdd(&out8[1], s_pg * invB);
-    atomicAdd(&out8[2], s_vl * invB);
-    atomicAdd(&out8[4], s_kl * invB);
-    atomicAdd(&out8[5], s_cf * invB);
+  // reductions: every wave reduces its 4 + A partial sums with shuffles, lane 0 parks them in LDS, one barrier, then
+  // thread q adds the block's partials of quantity q into the global accumulator (16 blocks at B = 4096)
+  __shared__ float part[PPO_BLOCK / 64][4 + PPO_MAXA];
+  const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  {
+    const float s_pg = ppo_wave_sum(pg), s_vl = ppo_wave_sum(vl), s_kl = ppo_wave_sum(kl), s_cf = ppo_wave_sum(cf);
+    if (ln == 0) { part[w][0] = s_pg; part[w][1] = s_vl; part[w][2] = s_kl; part[w][3] = s_cf; }
   }
 #pragma unroll
   for (int j = 0; j < PPO_MAXA; j++) {
     if (j < A) {
-      const float g = ppo_block_sum(on ? dlogp * (z2[j] - 1.f) : 0.f, red);
-      if (threadIdx.x == 0) atomicAdd(&grad_log_std[j], g);
+      const float g = ppo_wave_sum(on ? dlogp * (z2[j] - 1.f) : 0.f);
+      if (ln == 0) part[w][4 + j] = g;
     }
+  }
+  __syncthreads();
+  const int q = threadIdx.x;
+  if (q < 4 + A) {
+    float t = 0;
+    for (int i = 0; i < PPO_BLOCK / 64; i++) t += part[i][q];
+    if (q == 0) atomicAdd(&out8[1], t * invB);
+    else if (q == 1) atomicAdd(&out8[2], t * invB);
+    else if (q == 2) atomicAdd(&out8[4], t * invB);
+    else if (q == 3) atomicAdd(&out8[5], t * invB);
+    else atomicAdd(&grad_log_std[q - 4], t);
   }
 }
 

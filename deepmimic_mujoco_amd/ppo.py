@@ -283,7 +283,9 @@ class PPO:
 
     def _minibatch_step(self, obs, act, adv, ret, old_logp):
         loss = (self._loss_fused if (self.fused_loss and obs.is_cuda) else self._loss_torch)(obs, act, adv, ret, old_logp)
-        self.optimizer.zero_grad(set_to_none=False)
+        # grads are re-created by backward (no zero-fill, no accumulate-add per parameter); inside a captured
+        # hipGraph they live in the graph's private pool, so their addresses are the same at every replay
+        self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         self.grad_sync()                         # the ONE collective of the data-parallel learner
         nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
