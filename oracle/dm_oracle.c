@@ -640,6 +640,30 @@ static void make_frame(double *f) { /* [EXT] mju_makeFrame */
   cross3(f + 6, f, f + 3);
 }
 
+/* Test hook: one primitive pair through the same dispatch as collision().  out: n x 10 doubles (dist, pos3, normal3,
+ * tangent3); returns n, or -1 for an unsupported type pair. */
+int dmo_narrowphase(int t1, const double *x1, const double *M1, const double *z1, int t2, const double *x2,
+                    const double *M2, const double *z2, double margin, double *out) {
+  RawCon rc[8];
+  int n = -1;
+  if (t1 == DM_GEOM_PLANE && t2 == DM_GEOM_SPHERE) n = c_plane_sphere(rc, margin, x1, M1, x2, z2[0]);
+  else if (t1 == DM_GEOM_PLANE && t2 == DM_GEOM_CAPSULE) n = c_plane_capsule(rc, margin, x1, M1, x2, M2, z2);
+  else if (t1 == DM_GEOM_PLANE && t2 == DM_GEOM_BOX) n = c_plane_box(rc, margin, x1, M1, x2, M2, z2);
+  else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_SPHERE) n = c_sphere_sphere(rc, margin, x1, z1[0], x2, z2[0]);
+  else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_CAPSULE) n = c_sphere_capsule(rc, margin, x1, z1[0], x2, M2, z2);
+  else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_BOX) n = c_sphere_box(rc, margin, x1, z1[0], x2, M2, z2);
+  else if (t1 == DM_GEOM_CAPSULE && t2 == DM_GEOM_CAPSULE) n = c_capsule_capsule(rc, margin, x1, M1, z1, x2, M2, z2);
+  else if (t1 == DM_GEOM_CAPSULE && t2 == DM_GEOM_BOX) n = c_capsule_box(rc, margin, x1, M1, z1, x2, M2, z2);
+  else if (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX) n = c_box_box(rc, margin, x1, M1, z1, x2, M2, z2);
+  for (int k = 0; k < n; k++) {
+    out[10 * k] = rc[k].dist;
+    memcpy(out + 10 * k + 1, rc[k].pos, 3 * sizeof(double));
+    memcpy(out + 10 * k + 4, rc[k].normal, 3 * sizeof(double));
+    memcpy(out + 10 * k + 7, rc[k].tangent, 3 * sizeof(double));
+  }
+  return n;
+}
+
 static void collision(const DmModel *m, DmoData *d) { /* [EXT] mj_collision */
   d->ncon = 0;
   for (int p = 0; p < m->npair; p++) {

@@ -138,6 +138,10 @@ int dmo_combined_step(const DmModel *m, DmoData *d, DmoCombEnv *e, const DmoClip
 int dmo_combined_reset(const DmModel *m, DmoData *d, DmoCombEnv *e, const DmoClip *clips, int motion, int n_steps,
                        double *obs72);
 
+/* narrowphase test hook (geom types of include/dm_model.h; sizes as in DmModel.geom_size; mats row-major 3x3) */
+int dmo_narrowphase(int t1, const double *x1, const double *M1, const double *z1, int t2, const double *x2,
+                    const double *M2, const double *z2, double margin, double *out_n_x_10);
+
 /* rotation helpers exposed for tests */
 void dmo_quat_to_rpy(const double *wxyz, double *rpy);
 

@@ -62,6 +62,8 @@ def lib():
         L.dmo_combined_obs.argtypes = [C.c_void_p] * 5
         L.dmo_combined_step.argtypes = [C.c_void_p] * 11
         L.dmo_combined_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.dmo_narrowphase.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_double, C.c_void_p]
         L.dmo_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
         L.dmo_set.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
         L.dmo_get_int.argtypes = [C.c_void_p, C.c_char_p]
@@ -216,6 +218,17 @@ class OracleCombined(OracleSim):
         done = self.L.dmo_combined_step(C.byref(self.cm), self.d, C.byref(self.cenv), self.carr, _p(a), pq, pv,
                                         _p(obs), C.byref(rew), _p(terms), C.byref(reason))
         return obs, rew.value, bool(done), terms, reason.value
+
+
+def narrowphase(t1, x1, M1, z1, t2, x2, M2, z2, margin=0.001):
+    """One primitive pair through the oracle's collision dispatch -> list of (dist, pos[3], normal[3], tangent[3])."""
+    a = [np.ascontiguousarray(v, np.float64).ravel() for v in (x1, M1, z1, x2, M2, z2)]
+    out = np.zeros(80)
+    n = lib().dmo_narrowphase(t1, _p(a[0]), _p(a[1]), _p(a[2]), t2, _p(a[3]), _p(a[4]), _p(a[5]), float(margin), _p(out))
+    if n < 0:
+        raise ValueError("unsupported geom type pair")
+    return [(out[10 * k], out[10 * k + 1:10 * k + 4].copy(), out[10 * k + 4:10 * k + 7].copy(), out[10 * k + 7:10 * k + 10].copy())
+            for k in range(n)]
 
 
 def quat_to_rpy(q):
