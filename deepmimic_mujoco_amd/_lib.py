@@ -25,7 +25,7 @@ EXPORTS = ["dm_default_config", "dm_create", "dm_destroy", "dm_last_error", "dm_
            "dm_load_clip", "dm_set_env_clips", "dm_reset", "dm_step", "dm_step_forced",
            "dm_set_state", "dm_get_state", "dm_get_counters", "dm_set_counters", "dm_set_debug",
            "dm_fill_random_actions", "dm_last_step_ms", "dm_enable_timing", "dm_get_work",
-           "dm_set_clip_flags", "dm_obs_dim", "dm_terms_dim", "dm_get_env_clips", "dm_mean_step_ms", "dm_ppo_loss"]
+           "dm_set_clip_flags", "dm_obs_dim", "dm_terms_dim", "dm_get_env_clips", "dm_mean_step_ms", "dm_ppo_loss", "dm_forward"]
 
 
 class DmConfig(C.Structure):
@@ -72,6 +72,7 @@ def load_library():
     L.dm_step_forced.argtypes = [vp] * 9
     L.dm_set_state.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp]
     L.dm_get_state.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
+    L.dm_forward.argtypes = [vp, vp, i32, vp]
     L.dm_get_counters.argtypes = [vp, vp, vp, vp, vp]
     L.dm_set_counters.argtypes = [vp, vp, vp, vp]
     L.dm_set_debug.argtypes = [vp, vp]
@@ -199,6 +200,10 @@ class HipEngine:
         n = qpos.shape[0]
         self._chk(self.L.dm_set_state(self.h, _ptr(env_ids), n, _ptr(qpos), _ptr(qvel), _ptr(warm), _ptr(ctrl),
                                       1 if run_forward else 0, self._stream()), "dm_set_state")
+
+    def forward(self, env_ids=None, n=None):
+        """sim.forward(): re-evaluate the derived quantities at the stored state."""
+        self._chk(self.L.dm_forward(self.h, _ptr(env_ids), self.N if n is None else n, self._stream()), "dm_forward")
 
     def get_state(self, env_ids=None, n=None):
         t, d = self.torch, self.device

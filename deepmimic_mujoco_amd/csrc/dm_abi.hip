@@ -407,6 +407,14 @@ extern "C" int dm_set_state(DmHandle e, const int32_t *env_ids, int n, const flo
   return launch(e, P, n, stream);
 }
 
+extern "C" int dm_forward(DmHandle e, const int32_t *env_ids, int n, void *stream) {
+  if (!e || n < 1 || n > e->N) return fail(e, DM_EINVAL, "dm_forward: bad argument");
+  DmLaunch P;
+  fill_launch(e, P, DMK_MODE_SETSTATE);
+  P.env_ids = env_ids; P.run_forward = 1;     // in_qpos == null: state is kept
+  return launch(e, P, n, stream);
+}
+
 extern "C" int dm_get_state(DmHandle e, const int32_t *env_ids, int n, float *qpos, float *qvel, float *warm,
                             float *ctrl, void *stream) {
   if (!e || n < 1 || n > e->N) return fail(e, DM_EINVAL, "dm_get_state: bad argument");

@@ -1553,8 +1553,10 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
   if (mode == DMK_MODE_STEP) {
     if (lane < DMK_NU) S.ctrl[lane] = P.actions[(size_t)env * DMK_NU + lane];  // ctrl = action * 1.0 (:347)
   } else if (mode == DMK_MODE_FORCED || mode == DMK_MODE_SETSTATE) {
-    if (lane < DMK_NQ) S.qpos[lane] = P.in_qpos[(size_t)slot * DMK_NQ + lane];
-    if (lane < DMK_NV) S.qvel[lane] = P.in_qvel[(size_t)slot * DMK_NV + lane];
+    if (P.in_qpos) {   // null in SETSTATE mode = dm_forward: keep the stored state, only re-run the forward evaluation
+      if (lane < DMK_NQ) S.qpos[lane] = P.in_qpos[(size_t)slot * DMK_NQ + lane];
+      if (lane < DMK_NV) S.qvel[lane] = P.in_qvel[(size_t)slot * DMK_NV + lane];
+    }
     if (mode == DMK_MODE_SETSTATE) {
       if (P.in_warm && lane < DMK_NV) S.warm[lane] = P.in_warm[(size_t)slot * DMK_NV + lane];
       if (P.in_ctrl && lane < DMK_NU) S.ctrl[lane] = P.in_ctrl[(size_t)slot * DMK_NU + lane];

@@ -105,8 +105,7 @@ class _SimView:
         return self._env._time
 
     def forward(self):
-        q, v = self._env._state()
-        self._env.set_state(q, v)
+        self._env._eng.forward()
 
 
 class DPEnv:

@@ -122,6 +122,9 @@ int dm_step_forced(DmHandle h, const float *qpos, const float *qvel, float *obs,
  * returned).  Used for teacher-forced parity tests and checkpointing of the env batch. */
 int dm_set_state(DmHandle h, const int32_t *env_ids, int n, const float *qpos, const float *qvel,
                  const float *qacc_warmstart, const float *ctrl, int run_forward, void *stream);
+/* Replaces: sim.forward() on the current state (src/deepmimic_env.py:491): recomputes every derived quantity and the
+ * warm start from the stored qpos / qvel without changing them.  env_ids NULL = envs 0..n-1. */
+int dm_forward(DmHandle h, const int32_t *env_ids, int n, void *stream);
 int dm_get_state(DmHandle h, const int32_t *env_ids, int n, float *qpos, float *qvel,
                  float *qacc_warmstart, float *ctrl, void *stream);
 /* task counters: idx_curr, episode_length int32[N]; episode_reward float[N] (deepmimic_env.py:452-455) */

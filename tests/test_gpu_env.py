@@ -337,3 +337,32 @@ def test_fused_ppo_loss_matches_autograd():
         for n in g0:
             scale = float(g0[n].abs().max()) + 1e-12
             assert float((g0[n] - g1[n]).abs().max()) < 2e-5 * scale + 1e-9, (n, B, normalize)
+
+
+def test_dm_forward_recomputes_without_changing_the_state(model, clips, oracle_clips):
+    """dm_forward = sim.forward() (src/deepmimic_env.py:491): derived arrays and warm start at the stored state."""
+    import torch
+    from deepmimic_mujoco_amd._lib import HipEngine
+    from oracle.oracle import OracleSim
+    rng = np.random.default_rng(5)
+    n = 32
+    eng = HipEngine(model, n, auto_reset=False)
+    eng.load_clip(0, clips["walk"])
+    q, v = clips["walk"].tables()[:2]
+    idx = rng.integers(0, len(q), n)
+    qpos = torch.tensor(q[idx] + rng.normal(0, 0.02, (n, 35)), dtype=torch.float32, device=eng.device)
+    qvel = torch.tensor(v[idx] + rng.normal(0, 0.2, (n, 34)), dtype=torch.float32, device=eng.device)
+    eng.set_state(qpos, qvel, run_forward=False)          # store only
+    dbg = eng.enable_debug()
+    eng.forward()
+    torch.cuda.synchronize()
+    q2, v2, warm, _ = eng.get_state()
+    assert torch.equal(q2[:, :3], qpos[:, :3]) and torch.equal(q2[:, 7:], qpos[:, 7:]) and torch.equal(v2, qvel)
+    d = dbg.cpu().numpy()
+    for i in range(n):
+        o = OracleSim(model)
+        o.set_state(qpos[i].double().cpu().numpy(), qvel[i].double().cpu().numpy())
+        assert np.abs(d[i, 0:42] - o.get("xpos").ravel()).max() < 1e-5
+        assert np.abs(d[i, 174:208] - o.get("qacc")).max() < 2e-3 * max(1.0, np.abs(o.get("qacc")).max())
+        assert np.abs(warm[i].cpu().numpy() - o.get("qacc_warmstart")).max() < 2e-3 * max(1.0, np.abs(o.get("qacc")).max())
+    eng.close()
