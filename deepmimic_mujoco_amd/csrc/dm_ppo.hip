@@ -166,3 +166,65 @@ extern "C" int dm_ppo_loss(const float *mean, const float *log_std, const float 
   hipLaunchKernelGGL(ppo_finish_kernel, dim3(1), dim3(64), 0, s, log_std, A, vf_coef, ent_coef, scratch, grad_log_std, out8);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight and bias gradient of a linear layer of the policy / value MLP:  dW[o][i] = sum_b dY[b][o] X[b][i],
+// db[o] = sum_b dY[b][o], for a minibatch of B = 4096 rows and layers no larger than 256 x 256.  The output is tiny
+// and the reduction long, so the library GEMM walks all of K on two dozen workgroups (25 us per layer, five layers per
+// optimizer step).  Here every wave owns one 32 x 32 output tile and one slice of the batch: v_mfma_f32_32x32x2f32 with
+// A[row = o][k = b] = dY[b][o0 + row] and B[k = b][col = i] = X[b][i0 + col] (both coalesced 128-byte row reads),
+// partial tiles are added to dW with float atomics (dW and db zeroed by the caller on the same stream).
+namespace {
+
+typedef float ppo_f16v __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(64) ppo_wgrad_kernel(const float *dY, const float *X, float *dW, float *db, int B, int O, int I,
+                                                       int kchunk) {
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  const int i0 = blockIdx.x * 32, o0 = blockIdx.y * 32, b0 = blockIdx.z * kchunk;
+  const bool oa = (o0 + r) < O, ia = (i0 + r) < I;
+  const float *pa = dY + (size_t)(b0 + h) * O + (o0 + r);
+  const float *px = X + (size_t)(b0 + h) * I + (i0 + r);
+  ppo_f16v acc;
+#pragma unroll
+  for (int j = 0; j < 16; j++) acc[j] = 0.f;
+  float dbacc = 0.f;
+  constexpr int U = 8;
+  for (int b = 0; b < kchunk; b += 2 * U) {
+    float a[U], x[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      a[u] = oa ? pa[(size_t)(b + 2 * u) * O] : 0.f;
+      x[u] = ia ? px[(size_t)(b + 2 * u) * I] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], x[u], acc, 0, 0, 0);
+      dbacc += a[u];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const int row = (j >> 2) * 8 + h * 4 + (j & 3);
+    if ((o0 + row) < O && ia) atomicAdd(&dW[(size_t)(o0 + row) * I + i0 + r], acc[j]);
+  }
+  if (blockIdx.x == 0) {
+    const float v = dbacc + __shfl_xor(dbacc, 32);
+    if (h == 0 && oa) atomicAdd(&db[o0 + r], v);
+  }
+}
+
+}  // namespace
+
+// dW [O x I] and db [O] must be zero on entry (stream-ordered).  B must be a multiple of 64.
+extern "C" int dm_linear_wgrad(const float *dY, const float *X, float *dW, float *db, int B, int O, int I, void *stream) {
+  if (!dY || !X || !dW || !db || B < 64 || (B % 64) != 0 || O < 1 || I < 1) return -22;
+  const int tiles = ((O + 31) / 32) * ((I + 31) / 32);
+  int splitk = 1;
+  while (splitk * 2 * tiles <= 1024 && B / (splitk * 2) >= 64 && (B % (splitk * 2 * 16)) == 0) splitk *= 2;
+  const int kchunk = B / splitk;                       // multiple of 16 by construction
+  if (kchunk % 16 != 0) return -22;
+  hipLaunchKernelGGL(ppo_wgrad_kernel, dim3((I + 31) / 32, (O + 31) / 32, splitk), dim3(64), 0, (hipStream_t)stream, dY, X, dW, db, B,
+                     O, I, kchunk);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}

@@ -25,6 +25,43 @@ import torch.distributed as dist
 from torch import nn
 
 
+class _HipLinearFn(torch.autograd.Function):
+    """y = x W^T + b; the backward computes dW and db with `dm_linear_wgrad` (MFMA split-K over the batch, csrc/dm_ppo.hip)
+    and dX with the library GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.addmm(b, x, w.t())
+
+    @staticmethod
+    def backward(ctx, gy):
+        import ctypes as C
+        from . import _lib
+        x, w = ctx.saved_tensors
+        gx = gy @ w if ctx.needs_input_grad[0] else None
+        gy = gy.contiguous()
+        gw = torch.zeros_like(w)
+        gb = torch.zeros(w.shape[0], device=w.device, dtype=w.dtype)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rc = _lib.load_library().dm_linear_wgrad(p(gy), p(x), p(gw), p(gb), x.shape[0], w.shape[0], w.shape[1],
+                                                 C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("dm_linear_wgrad failed (%d)" % rc)
+        return gx, gw, gb
+
+
+class HipLinear(nn.Linear):
+    """nn.Linear whose weight / bias gradients come from the hand-written kernel when the batch is a large CUDA
+    minibatch (the optimizer step of the reference's [256,128] net is bound by the library's K = 4096 GEMMs)."""
+
+    def forward(self, x):
+        if (x.is_cuda and x.dim() == 2 and x.shape[0] >= 1024 and x.shape[0] % 64 == 0 and x.dtype == torch.float32
+                and x.is_contiguous() and torch.is_grad_enabled() and max(self.weight.shape) <= 256):
+            return _HipLinearFn.apply(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 class MlpPolicy(nn.Module):
     """SB3 ``ActorCriticPolicy`` with ``net_arch=[h1, h2]`` (shared sizes, separate trunks), tanh."""
 
@@ -34,14 +71,14 @@ class MlpPolicy(nn.Module):
         def trunk():
             layers, d = [], obs_dim
             for hdim in net_arch:
-                layers += [nn.Linear(d, hdim), nn.Tanh()]
+                layers += [HipLinear(d, hdim), nn.Tanh()]
                 d = hdim
             return nn.Sequential(*layers), d
 
         self.pi, dpi = trunk()
         self.vf, dvf = trunk()
-        self.action_net = nn.Linear(dpi, act_dim)
-        self.value_net = nn.Linear(dvf, 1)
+        self.action_net = HipLinear(dpi, act_dim)
+        self.value_net = HipLinear(dvf, 1)
         self.log_std = nn.Parameter(torch.full((act_dim,), float(log_std_init)))
         for seq in (self.pi, self.vf):
             for m in seq:

@@ -173,6 +173,12 @@ int dm_ppo_loss(const float *mean, const float *log_std, const float *value, con
                 int normalize_advantage, float *grad_mean, float *grad_log_std, float *grad_value, float *out8,
                 float *scratch, void *stream);
 
+/* Weight / bias gradient of one linear layer of the policy or value MLP (csrc/dm_ppo.hip, MFMA split-K):
+ * dW[O x I] += dY^T X, db[O] += column sums of dY, for dY [B x O], X [B x I] row-major, B a multiple of 64.
+ * dW and db must be zero on entry.  Replaces the weight-gradient GEMM + bias reduction of torch.nn.Linear's backward
+ * inside SB3's PPO.train [EXT] for the launch-bound [256,128] network of src/sb3_ppo.py:265. */
+int dm_linear_wgrad(const float *dY, const float *X, float *dW, float *db, int B, int O, int I, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
