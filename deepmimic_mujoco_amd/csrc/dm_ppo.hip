@@ -228,3 +228,29 @@ extern "C" int dm_linear_wgrad(const float *dY, const float *X, float *dW, float
                      O, I, kchunk);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Minibatch gather of the rollout buffer: out_x[r] = x[idx[r]] for the five per-sample arrays of PPO.train
+// (observations [n x D], actions [n x A], advantages, returns, old log-probs) in one launch instead of five
+// index_select kernels.  idx is int64 (torch.randperm).
+namespace {
+__global__ void ppo_gather_kernel(const long long *idx, int B, const float *obs, int D, const float *act, int A, const float *adv,
+                                  const float *ret, const float *logp, float *o_obs, float *o_act, float *o_adv, float *o_ret,
+                                  float *o_logp) {
+  const int r = blockIdx.x;              // one 128-thread block per gathered row
+  if (r >= B) return;
+  const long long s = idx[r];
+  for (int c = threadIdx.x; c < D; c += blockDim.x) o_obs[(size_t)r * D + c] = obs[(size_t)s * D + c];
+  for (int c = threadIdx.x; c < A; c += blockDim.x) o_act[(size_t)r * A + c] = act[(size_t)s * A + c];
+  if (threadIdx.x == 0) { o_adv[r] = adv[s]; o_ret[r] = ret[s]; o_logp[r] = logp[s]; }
+}
+}  // namespace
+
+extern "C" int dm_ppo_gather(const long long *idx, int B, const float *obs, int D, const float *act, int A, const float *adv,
+                             const float *ret, const float *logp, float *o_obs, float *o_act, float *o_adv, float *o_ret,
+                             float *o_logp, void *stream) {
+  if (!idx || B < 1 || !obs || !act || !adv || !ret || !logp || !o_obs || !o_act || !o_adv || !o_ret || !o_logp) return -22;
+  hipLaunchKernelGGL(ppo_gather_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, idx, B, obs, D, act, A, adv, ret, logp, o_obs,
+                     o_act, o_adv, o_ret, o_logp);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}

@@ -179,6 +179,12 @@ int dm_ppo_loss(const float *mean, const float *log_std, const float *value, con
  * inside SB3's PPO.train [EXT] for the launch-bound [256,128] network of src/sb3_ppo.py:265. */
 int dm_linear_wgrad(const float *dY, const float *X, float *dW, float *db, int B, int O, int I, void *stream);
 
+/* Minibatch gather of the rollout buffer for PPO.train [EXT]: out_x[r] = x[idx[r]], r < B, for obs [n x D], act [n x A],
+ * adv, ret, old log-prob in one launch (idx: int64 as produced by torch.randperm). */
+int dm_ppo_gather(const long long *idx, int B, const float *obs, int D, const float *act, int A, const float *adv,
+                  const float *ret, const float *logp, float *o_obs, float *o_act, float *o_adv, float *o_ret, float *o_logp,
+                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif
