@@ -31,13 +31,19 @@ def main(argv=None):
     ap.add_argument("--bf16-buffer", action="store_true", help="store rollout obs/actions in bf16 (config 5)")
     ap.add_argument("--save", default="")
     ap.add_argument("--json", action="store_true", help="print a JSON throughput summary on rank 0")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + several ranks on one GPU only rehearses the multi-rank path")
     args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+            local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     rank = dist.get_rank() if world > 1 else 0
 
