@@ -254,3 +254,52 @@ extern "C" int dm_ppo_gather(const long long *idx, int B, const float *obs, int 
                      o_act, o_adv, o_ret, o_logp);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Gradient-norm clipping + Adam on one flat parameter / gradient / moment buffer (all tensors of the policy are views
+// of it): three launches instead of the ~9 of clip_grad_norm_ + torch.optim.Adam.  Semantics of
+// torch.nn.utils.clip_grad_norm_(max_norm) followed by torch.optim.Adam(lr, betas, eps) (no weight decay, no amsgrad).
+// state[0] = sum of squared gradients (scratch), state[1] = step count (float), both on the device so the sequence
+// can be replayed from a captured hipGraph.
+namespace {
+__global__ void adam_begin_kernel(float *state) {
+  if (threadIdx.x == 0) { state[0] = 0.f; state[1] += 1.f; }
+}
+__global__ void adam_sumsq_kernel(const float *g, int n, float *state) {
+  float s = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s += g[i] * g[i];
+  s = ppo_wave_sum(s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&state[0], red[0] + red[1] + red[2] + red[3]);
+}
+__global__ void adam_update_kernel(float *p, const float *g, float *m, float *v, int n, float lr, float b1, float b2, float eps,
+                                   float max_norm, const float *state) {
+  const float total = sqrtf(state[0]);
+  const float coef = fminf(1.f, max_norm / (total + 1e-6f));          // clip_grad_norm_
+  const float t = state[1];
+  const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
+  const float step_size = lr / bc1;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float gi = g[i] * coef;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= step_size * mi / (sqrtf(vi) / bc2s + eps);
+  }
+}
+}  // namespace
+
+extern "C" int dm_adam_clip_step(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
+                                 float max_norm, float *state2, void *stream) {
+  if (!p || !g || !m || !v || !state2 || n < 1) return -22;
+  hipStream_t s = (hipStream_t)stream;
+  int blocks = (n + 256 * 8 - 1) / (256 * 8);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(adam_begin_kernel, dim3(1), dim3(64), 0, s, state2);
+  hipLaunchKernelGGL(adam_sumsq_kernel, dim3(blocks), dim3(256), 0, s, g, n, state2);
+  hipLaunchKernelGGL(adam_update_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, max_norm, state2);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}

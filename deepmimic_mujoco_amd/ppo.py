@@ -221,11 +221,80 @@ class FlatGradAllReduce:
             off += n
 
 
+class FlatAdam:
+    """clip_grad_norm_ + Adam on one flat buffer (`dm_adam_clip_step`, csrc/dm_ppo.hip): every parameter of the policy
+    becomes a view of `flat_p`, every gradient is gathered in `flat_g` (the HipLinear layers write theirs there
+    directly), and the whole update is three launches.  With several ranks `flat_g` is also what is all-reduced: the
+    one collective of the data-parallel learner, without staging copies.  GPU only; `state` mimics torch.optim's layout
+    far enough for the snapshot / restore around hipGraph capture."""
+
+    def __init__(self, policy, lr, betas=(0.9, 0.999), eps=1e-5, max_grad_norm=0.5):
+        self.params = [p for p in policy.parameters()]
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.n, self.lr, self.betas, self.eps, self.max_grad_norm = n, lr, betas, eps, max_grad_norm
+        self.flat_p = torch.empty(n, device=dev)
+        self.flat_g = torch.zeros(n, device=dev)
+        self.m, self.v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        self.state2 = torch.zeros(2, device=dev)          # [sum of squares scratch, step count]
+        self.slices = []
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                self.flat_p[off:off + k].copy_(p.reshape(-1))
+                p.data = self.flat_p[off:off + k].view_as(p)
+                self.slices.append(self.flat_g[off:off + k].view_as(p))
+                off += k
+        # HipLinear layers accumulate their weight / bias gradients straight into flat_g
+        byid = {id(p): g for p, g in zip(self.params, self.slices)}
+        for mod in policy.modules():
+            if isinstance(mod, HipLinear):
+                mod._grad_arena = (byid[id(mod.weight)], byid[id(mod.bias)])
+        self.state = {"flat": {"exp_avg": self.m, "exp_avg_sq": self.v, "state2": self.state2}}
+        self.calls = 0          # collectives issued (multi-rank)
+
+    def zero_grad(self, set_to_none=True):
+        self.flat_g.zero_()
+        for p in self.params:
+            p.grad = None
+
+    def gather_grads(self):
+        """Gradients that autograd produced outside flat_g (log_std, layers on the library path) are copied in."""
+        for p, g in zip(self.params, self.slices):
+            if p.grad is not None and p.grad.data_ptr() != g.data_ptr():
+                g.copy_(p.grad)
+
+    def all_reduce(self):
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
+            self.flat_g.div_(dist.get_world_size())
+            self.calls += 1
+
+    def step(self):
+        import ctypes as C
+        from . import _lib
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rc = _lib.load_library().dm_adam_clip_step(p(self.flat_p), p(self.flat_g), p(self.m), p(self.v), self.n, self.lr,
+                                                   self.betas[0], self.betas[1], self.eps, self.max_grad_norm, p(self.state2),
+                                                   C.c_void_p(torch.cuda.current_stream(self.flat_p.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("dm_adam_clip_step failed (%d)" % rc)
+
+    def state_dict(self):
+        return {"flat_adam": True, "exp_avg": self.m.clone(), "exp_avg_sq": self.v.clone(), "state2": self.state2.clone(),
+                "lr": self.lr, "betas": self.betas, "eps": self.eps, "max_grad_norm": self.max_grad_norm}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["exp_avg"]); self.v.copy_(sd["exp_avg_sq"]); self.state2.copy_(sd["state2"])
+        self.lr, self.betas, self.eps = sd["lr"], tuple(sd["betas"]), sd["eps"]
+
+
 class PPO:
     def __init__(self, env, net_arch=(256, 128), n_steps=4096, batch_size=4096, n_epochs=20, learning_rate=4e-4,
                  gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5,
                  normalize_advantage=True, seed=0, device=None, buffer_dtype=torch.float32, policy=None,
-                 use_hip_graph=None, fused_loss=True):
+                 use_hip_graph=None, fused_loss=True, flat_adam=True):
         self.env = env
         self.device = device if device is not None else getattr(env, "device", torch.device("cpu"))
         self.n_envs = env.num_envs if env is not None else 0
@@ -242,10 +311,14 @@ class PPO:
         # The optimizer step of one minibatch is ~60 small kernels: launch-bound.  On one GPU it is captured
         # once into a hipGraph and replayed (640 replays per PPO iteration with the reference's settings).
         self.use_hip_graph = (on_gpu and not dist.is_initialized()) if use_hip_graph is None else bool(use_hip_graph)
-        self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5, fused=on_gpu,
-                                          capturable=on_gpu and self.use_hip_graph)
+        self.flat_adam = on_gpu and flat_adam
+        if self.flat_adam:
+            self.optimizer = FlatAdam(self.policy, lr=learning_rate, eps=1e-5, max_grad_norm=max_grad_norm)
+        else:
+            self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5, fused=on_gpu,
+                                              capturable=on_gpu and self.use_hip_graph)
         self._graph = None
-        self.grad_sync = FlatGradAllReduce(self.policy.parameters())
+        self.grad_sync = self.optimizer if self.flat_adam else FlatGradAllReduce(self.policy.parameters())
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         if dist.is_initialized():  # decorrelate action noise across ranks after the common init
             torch.manual_seed(seed + 1000 * (self.rank + 1))
@@ -336,6 +409,16 @@ class PPO:
             off += nw + nb
 
     def _minibatch_step(self, obs, act, adv, ret, old_logp):
+        if self.flat_adam:
+            # every gradient lands in one flat buffer (one memset), clipping + Adam are one fused update on it, and
+            # with several ranks that buffer is the operand of the ONE collective of the data-parallel learner
+            self.optimizer.zero_grad()
+            loss = (self._loss_fused if self.fused_loss else self._loss_torch)(obs, act, adv, ret, old_logp)
+            loss.backward()
+            self.optimizer.gather_grads()
+            self.optimizer.all_reduce()
+            self.optimizer.step()
+            return loss.detach()
         if obs.is_cuda:
             if getattr(self, "_arena", None) is None:
                 self._make_grad_arena()

@@ -185,6 +185,12 @@ int dm_ppo_gather(const long long *idx, int B, const float *obs, int D, const fl
                   const float *ret, const float *logp, float *o_obs, float *o_act, float *o_adv, float *o_ret, float *o_logp,
                   void *stream);
 
+/* torch.nn.utils.clip_grad_norm_(max_norm) + torch.optim.Adam.step() [EXT, as used by SB3's PPO.train] on one flat
+ * parameter / gradient / moment buffer of n floats.  state2 = {scratch, step count} on the device (zero-initialised by
+ * the caller once); no weight decay, no amsgrad. */
+int dm_adam_clip_step(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
+                      float max_norm, float *state2, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

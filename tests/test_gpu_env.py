@@ -387,3 +387,33 @@ def test_hip_linear_wgrad_matches_torch():
             assert float((gw - ref_w).abs().max()) < 2e-4 * sw, (B, I, O)
             assert float((gb - ref_b).abs().max()) < 2e-4 * float(ref_b.abs().max() + 1), (B, I, O)
             assert torch.allclose(gx, ref_x, rtol=1e-4, atol=1e-4)
+
+
+def test_flat_adam_matches_clip_grad_norm_plus_torch_adam():
+    """dm_adam_clip_step on the flat buffers against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam (fused) over
+    several optimizer steps of the same minibatches, with every custom piece on (fused loss, HipLinear) on one side
+    and plain PyTorch on the other."""
+    import torch
+    from deepmimic_mujoco_amd.ppo import PPO, MlpPolicy
+    dev = torch.device("cuda", 0)
+    B = 2048
+    results = []
+    for custom in (False, True):
+        torch.manual_seed(21)
+        pol = MlpPolicy(net_arch=(256, 128)).to(dev)
+        ppo = PPO(None, policy=pol, device=dev, batch_size=B, use_hip_graph=False, fused_loss=custom, flat_adam=custom,
+                  learning_rate=3e-3, max_grad_norm=0.5)
+        g = torch.Generator(device=dev); g.manual_seed(4)
+        for it in range(6):
+            obs = torch.randn(B, 67, device=dev, generator=g)
+            act = torch.randn(B, 28, device=dev, generator=g) * 0.5
+            adv = torch.randn(B, device=dev, generator=g) * (10.0 if it % 2 else 0.1)   # clipped and unclipped norms
+            ret = torch.randn(B, device=dev, generator=g)
+            with torch.no_grad():
+                _, logp, _ = pol.evaluate_actions(obs, act)
+            old_logp = logp + torch.randn(B, device=dev, generator=g) * 0.2
+            ppo._minibatch_step(obs, act, adv, ret, old_logp)
+        results.append({n: p.detach().clone() for n, p in pol.named_parameters()})
+    for n in results[0]:
+        a, b = results[0][n], results[1][n]
+        assert float((a - b).abs().max()) < 2e-4 * (float(a.abs().max()) + 1e-3), n
