@@ -53,6 +53,10 @@ class _HipLinearFn(torch.autograd.Function):
                                                  C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
         if rc != 0:
             raise RuntimeError("dm_linear_wgrad failed (%d)" % rc)
+        if arena is not None:
+            # the gradients already sit in the optimizer's flat buffer: handing views to autograd would make
+            # AccumulateGrad clone them (a view cannot be stolen) and the optimizer copy them back — 2 copies per tensor
+            return gx, None, None, None
         return gx, gw, gb, None
 
 
@@ -396,18 +400,6 @@ class PPO:
         return FusedPPOLoss.apply(mean, self.policy.log_std, value, act, old_logp, adv, ret, self.clip_range, self.vf_coef,
                                   self.ent_coef, self.normalize_advantage and obs.shape[0] > 1)
 
-    def _make_grad_arena(self):
-        """One flat buffer for the weight / bias gradients of every HipLinear layer: zeroed with a single memset per
-        optimizer step instead of two fills per layer (dm_linear_wgrad accumulates into zeroed outputs)."""
-        mods = [m for m in self.policy.modules() if isinstance(m, HipLinear)]
-        n = sum(m.weight.numel() + m.bias.numel() for m in mods)
-        self._arena = torch.zeros(n, device=self.device)
-        off = 0
-        for m in mods:
-            nw, nb = m.weight.numel(), m.bias.numel()
-            m._grad_arena = (self._arena[off:off + nw].view_as(m.weight), self._arena[off + nw:off + nw + nb])
-            off += nw + nb
-
     def _minibatch_step(self, obs, act, adv, ret, old_logp):
         if self.flat_adam:
             # every gradient lands in one flat buffer (one memset), clipping + Adam are one fused update on it, and
@@ -419,10 +411,6 @@ class PPO:
             self.optimizer.all_reduce()
             self.optimizer.step()
             return loss.detach()
-        if obs.is_cuda:
-            if getattr(self, "_arena", None) is None:
-                self._make_grad_arena()
-            self._arena.zero_()
         loss = (self._loss_fused if (self.fused_loss and obs.is_cuda) else self._loss_torch)(obs, act, adv, ret, old_logp)
         # grads are re-created by backward (no zero-fill, no accumulate-add per parameter); inside a captured
         # hipGraph they live in the graph's private pool, so their addresses are the same at every replay

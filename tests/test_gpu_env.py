@@ -318,7 +318,7 @@ def test_fused_ppo_loss_matches_autograd():
             with torch.no_grad():
                 pol.log_std.copy_(torch.linspace(-0.5, 0.3, 28))
             ppo = PPO(None, policy=pol, device=dev, batch_size=B, normalize_advantage=normalize, use_hip_graph=False,
-                      fused_loss=fused, ent_coef=0.01)
+                      fused_loss=fused, flat_adam=False, ent_coef=0.01)
             g = torch.Generator(device=dev); g.manual_seed(11)
             obs = torch.randn(B, 67, device=dev, generator=g)
             act = torch.randn(B, 28, device=dev, generator=g) * 0.7
