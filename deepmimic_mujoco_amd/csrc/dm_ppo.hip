@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(64) ppo_wgrad_kernel(const float *dY, const fl
 #pragma unroll
   for (int j = 0; j < 16; j++) acc[j] = 0.f;
   float dbacc = 0.f;
-  constexpr int U = 8;
+  constexpr int U = 32;                  // 64 loads per lane in flight: the kernel is latency-, not MFMA-bound
   for (int b = 0; b < kchunk; b += 2 * U) {
     float a[U], x[U];
 #pragma unroll
@@ -221,9 +221,9 @@ extern "C" int dm_linear_wgrad(const float *dY, const float *X, float *dW, float
   if (!dY || !X || !dW || !db || B < 64 || (B % 64) != 0 || O < 1 || I < 1) return -22;
   const int tiles = ((O + 31) / 32) * ((I + 31) / 32);
   int splitk = 1;
-  while (splitk * 2 * tiles <= 1024 && B / (splitk * 2) >= 64 && (B % (splitk * 2 * 16)) == 0) splitk *= 2;
-  const int kchunk = B / splitk;                       // multiple of 16 by construction
-  if (kchunk % 16 != 0) return -22;
+  while (splitk * 2 * tiles <= 1024 && B / (splitk * 2) >= 64 && (B % (splitk * 2 * 64)) == 0) splitk *= 2;
+  const int kchunk = B / splitk;                       // multiple of 64 (one unrolled group of the kernel)
+  if (kchunk % 64 != 0) return -22;
   hipLaunchKernelGGL(ppo_wgrad_kernel, dim3((I + 31) / 32, (O + 31) / 32, splitk), dim3(64), 0, (hipStream_t)stream, dY, X, dW, db, B,
                      O, I, kchunk);
   return hipGetLastError() == hipSuccess ? 0 : -5;
