@@ -298,7 +298,7 @@ class PPO:
     def __init__(self, env, net_arch=(256, 128), n_steps=4096, batch_size=4096, n_epochs=20, learning_rate=4e-4,
                  gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5,
                  normalize_advantage=True, seed=0, device=None, buffer_dtype=torch.float32, policy=None,
-                 use_hip_graph=None, fused_loss=True, flat_adam=True):
+                 use_hip_graph=None, fused_loss=True, flat_adam=True, two_stream=True):
         self.env = env
         self.device = device if device is not None else getattr(env, "device", torch.device("cpu"))
         self.n_envs = env.num_envs if env is not None else 0
@@ -307,6 +307,7 @@ class PPO:
         self.ent_coef, self.vf_coef, self.max_grad_norm = ent_coef, vf_coef, max_grad_norm
         self.normalize_advantage = normalize_advantage
         self.fused_loss = fused_loss          # dm_ppo_loss (HIP) for the loss tail when the batch is on the GPU
+        self.two_stream = two_stream          # value trunk on a second stream (parallel graph branches)
         self.buffer_dtype = buffer_dtype
         torch.manual_seed(seed)  # identical initial weights on every rank; no parameter broadcast needed
         self.obs_dim = int(env.observation_space.shape[0]) if env is not None else 67   # 67 DPEnv, 72 DPCombinedEnv
@@ -395,8 +396,21 @@ class PPO:
         return pg + self.vf_coef * vl - self.ent_coef * entropy.mean()
 
     def _loss_fused(self, obs, act, adv, ret, old_logp):
-        mean = self.policy.action_net(self.policy.pi(obs))
-        value = self.policy.value_net(self.policy.vf(obs)).squeeze(-1)
+        # The policy and value trunks are independent until the loss: the value trunk runs on a second stream, forward
+        # and (autograd replays each node on its forward stream) backward, so the two chains of small launch-bound
+        # kernels overlap — also as parallel branches of the captured hipGraph.
+        cur = torch.cuda.current_stream(obs.device)
+        if self.two_stream:
+            if getattr(self, "_vf_stream", None) is None:
+                self._vf_stream = torch.cuda.Stream(device=obs.device)
+            self._vf_stream.wait_stream(cur)
+            with torch.cuda.stream(self._vf_stream):
+                value = self.policy.value_net(self.policy.vf(obs)).squeeze(-1)
+            mean = self.policy.action_net(self.policy.pi(obs))
+            cur.wait_stream(self._vf_stream)
+        else:
+            mean = self.policy.action_net(self.policy.pi(obs))
+            value = self.policy.value_net(self.policy.vf(obs)).squeeze(-1)
         return FusedPPOLoss.apply(mean, self.policy.log_std, value, act, old_logp, adv, ret, self.clip_range, self.vf_coef,
                                   self.ent_coef, self.normalize_advantage and obs.shape[0] > 1)
 
@@ -407,6 +421,10 @@ class PPO:
             self.optimizer.zero_grad()
             loss = (self._loss_fused if self.fused_loss else self._loss_torch)(obs, act, adv, ret, old_logp)
             loss.backward()
+            if getattr(self, "_vf_stream", None) is not None:
+                # the layer kernels of the value trunk hand no gradient tensor to autograd (they write flat_g), so the
+                # engine has no leaf to synchronise on: join the second stream explicitly before the update
+                torch.cuda.current_stream(obs.device).wait_stream(self._vf_stream)
             self.optimizer.gather_grads()
             self.optimizer.all_reduce()
             self.optimizer.step()
