@@ -280,28 +280,45 @@ class HipDeepMimicVecEnv(_SB3VecEnv):
     config 5).  ``step_tensor`` is the zero-copy path used by deepmimic_mujoco_amd.ppo.
     """
 
-    def __init__(self, num_envs, motion=None, robot="humanoid3d", device=0, seed=1234, auto_reset=True):
+    def __init__(self, num_envs, motion=None, robot="humanoid3d", device=0, seed=1234, auto_reset=True, sub_batches=1):
         import torch
         self._torch = torch
         self.robot_config = RobotConfig(robot)
         self.model = load_model(self.robot_config.xml_path)
         self.num_envs = int(num_envs)
+        self.sub_batches = int(sub_batches)
+        assert self.sub_batches >= 1 and self.num_envs % self.sub_batches == 0
+        nk = self.num_envs // self.sub_batches
         motions = [motion] if (motion is None or isinstance(motion, str)) else list(motion)
         self.motions = [MotionConfig(m, robot).motion for m in motions]
-        self.engine = _lib.HipEngine(self.model, self.num_envs, device=device, seed=seed, auto_reset=auto_reset,
-                                     low_z=self.robot_config.low_z)
+        # sub_batches > 1: independent engines over contiguous env ranges, so a rollout can keep one range simulating
+        # while the policy runs on another (deepmimic_mujoco_amd.ppo; INTEGRATION.md "double-buffered halves")
+        self.engines = [_lib.HipEngine(self.model, nk, device=device, seed=seed + 104729 * k, auto_reset=auto_reset,
+                                       low_z=self.robot_config.low_z) for k in range(self.sub_batches)]
+        self.engine = self.engines[0]
         self.mocaps = []
         for cid, m in enumerate(self.motions):
             mc = MocapDM(robot=robot, model=self.model)
             mc.load_mocap(MotionConfig(m, robot).mocap_path)
             mcfg = MotionConfig(m, robot)
-            self.engine.load_clip(cid, mc, floor=m in mcfg.floor_motions, acyclic=m in mcfg.acyclical_motions)
+            for e in self.engines:
+                e.load_clip(cid, mc, floor=m in mcfg.floor_motions, acyclic=m in mcfg.acyclical_motions)
             self.mocaps.append(mc)
         if len(self.motions) > 1:
-            ids = torch.arange(self.num_envs, device=self.engine.device) % len(self.motions)
-            self.engine.set_env_clips(ids.to(torch.int32))
+            for k, e in enumerate(self.engines):
+                ids = (torch.arange(nk, device=e.device) + k * nk) % len(self.motions)
+                e.set_env_clips(ids.to(torch.int32))
         self.device = self.engine.device
-        self.out = self.engine.alloc_outputs()
+        if self.sub_batches == 1:
+            self.out = self.engine.alloc_outputs()
+            self.sub_out = [self.out]
+        else:   # one set of [N, ...] tensors; every engine writes its contiguous block of rows
+            z = lambda *shape, dt=torch.float32: torch.zeros(*shape, device=self.device, dtype=dt)
+            N = self.num_envs
+            self.out = dict(obs=z(N, NOBS), rew=z(N), done=z(N, dt=torch.uint8), terms=z(N, 5), reason=z(N, dt=torch.int32),
+                            terminal_obs=z(N, NOBS))
+            self.sub_out = [{k_: v[k * nk:(k + 1) * nk] for k_, v in self.out.items()} for k in range(self.sub_batches)]
+        self.sub_slices = [slice(k * nk, (k + 1) * nk) for k in range(self.sub_batches)]
         lo = self.model.act_ctrlrange[:, 0].astype(np.float32)
         hi = self.model.act_ctrlrange[:, 1].astype(np.float32)
         self.action_space = Box(lo, hi, dtype=np.float32)
@@ -313,13 +330,21 @@ class HipDeepMimicVecEnv(_SB3VecEnv):
 
     # ---- zero-copy tensor API
     def reset_tensor(self, idx_init=None):
-        self.engine.reset(self.out["obs"], idx_init=idx_init)
+        for e, o, sl in zip(self.engines, self.sub_out, self.sub_slices):
+            e.reset(o["obs"], idx_init=None if idx_init is None else idx_init[sl].contiguous())
         return self.out["obs"]
 
     def step_tensor(self, actions):
         """actions: float32 CUDA tensor [N,28] -> dict of CUDA tensors (obs, rew, done, terms, reason, terminal_obs)."""
-        self.engine.step(actions.contiguous(), self.out)
+        actions = actions.contiguous()
+        for e, o, sl in zip(self.engines, self.sub_out, self.sub_slices):
+            e.step(actions[sl], o)
         return self.out
+
+    def step_sub(self, k, actions_k):
+        """Step sub-batch k only (on the current stream): actions_k [N/sub_batches, 28] -> its slice of the outputs."""
+        self.engines[k].step(actions_k.contiguous(), self.sub_out[k])
+        return self.sub_out[k]
 
     # ---- SB3 VecEnv protocol (numpy in / numpy out)
     def reset(self):
@@ -343,7 +368,8 @@ class HipDeepMimicVecEnv(_SB3VecEnv):
         return self.step_wait()
 
     def close(self):
-        self.engine.close()
+        for e in getattr(self, "engines", [self.engine]):
+            e.close()
 
     def seed(self, seed=None):
         return [None] * self.num_envs

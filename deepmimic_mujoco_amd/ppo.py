@@ -298,7 +298,8 @@ class PPO:
     def __init__(self, env, net_arch=(256, 128), n_steps=4096, batch_size=4096, n_epochs=20, learning_rate=4e-4,
                  gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5,
                  normalize_advantage=True, seed=0, device=None, buffer_dtype=torch.float32, policy=None,
-                 use_hip_graph=None, fused_loss=True, flat_adam=True, two_stream=True):
+                 use_hip_graph=None, fused_loss=True, flat_adam=True, two_stream=True, rollout_graph=True):
+        # rollout_graph only takes effect for an env built with sub_batches > 1
         self.env = env
         self.device = device if device is not None else getattr(env, "device", torch.device("cpu"))
         self.n_envs = env.num_envs if env is not None else 0
@@ -308,6 +309,7 @@ class PPO:
         self.normalize_advantage = normalize_advantage
         self.fused_loss = fused_loss          # dm_ppo_loss (HIP) for the loss tail when the batch is on the GPU
         self.two_stream = two_stream          # value trunk on a second stream (parallel graph branches)
+        self.rollout_graph = rollout_graph    # env with sub_batches > 1: the T-step rollout is one captured hipGraph
         self.buffer_dtype = buffer_dtype
         torch.manual_seed(seed)  # identical initial weights on every rank; no parameter broadcast needed
         self.obs_dim = int(env.observation_space.shape[0]) if env is not None else 67   # 67 DPEnv, 72 DPCombinedEnv
@@ -335,7 +337,67 @@ class PPO:
         self.stats = {}
 
     # ------------------------------------------------------------------ rollout
+    def _rollout_graph_build(self):
+        """Capture the whole T-step rollout as ONE hipGraph with one chain per env sub-batch (own stream each): the
+        policy forward of one half overlaps the step kernel of the other, so the ramp-down of every launch is filled
+        (INTEGRATION.md "double-buffered halves"), and the ~35 launches per step cost no host time at replay."""
+        env, T, N, dev, bd = self.env, self.n_steps, self.n_envs, self.device, self.buffer_dtype
+        K = env.sub_batches
+        z = lambda *shape, dt=torch.float32: torch.zeros(*shape, device=dev, dtype=dt)
+        rb = dict(obs=z(T, N, self.obs_dim, dt=bd), act=z(T, N, 28, dt=bd), rew=z(T, N), done=z(T, N), val=z(T, N), logp=z(T, N))
+        last = env.reset_tensor().clone() if self._last_obs is None else self._last_obs.clone()
+        streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
+
+        def chain(k, steps):
+            sl = env.sub_slices[k]
+            for t in range(steps):
+                obs = last[sl]
+                act, val, logp = self.policy(obs)
+                rb["obs"][t, sl] = obs
+                rb["act"][t, sl] = act
+                rb["val"][t, sl] = val
+                rb["logp"][t, sl] = logp
+                out = env.step_sub(k, torch.clamp(act, self.act_lo, self.act_hi))
+                rb["rew"][t, sl] = out["rew"]
+                rb["done"][t, sl] = out["done"].float()
+                last[sl].copy_(out["obs"])
+
+        with torch.no_grad():
+            # warm-up on the side streams (library workspaces, allocator pools); these env steps are real but uncounted
+            cur = torch.cuda.current_stream(dev)
+            for k in range(K):
+                streams[k].wait_stream(cur)
+                with torch.cuda.stream(streams[k]):
+                    chain(k, 1)
+            for k in range(K):
+                cur.wait_stream(streams[k])
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                cap = torch.cuda.current_stream(dev)
+                for k in range(K):
+                    streams[k].wait_stream(cap)
+                    with torch.cuda.stream(streams[k]):
+                        chain(k, T)
+                for k in range(K):
+                    cap.wait_stream(streams[k])
+                last_val = self.policy.predict_values(last)
+                adv, ret = compute_gae(rb["rew"], rb["val"], rb["done"], last_val, self.gamma, self.gae_lambda)
+        rb["adv"], rb["ret"] = adv, ret
+        self._rollout = (g, rb, last)
+
     def collect_rollouts(self):
+        if (self.rollout_graph and self.device.type == "cuda" and getattr(self.env, "sub_batches", 1) > 1
+                and hasattr(self.env, "step_sub")):
+            if getattr(self, "_rollout", None) is None:
+                self._rollout_graph_build()
+            g, rb, last = self._rollout
+            g.replay()
+            self._last_obs = last
+            self.num_timesteps += self.n_steps * self.n_envs
+            self.stats["mean_reward"] = float(rb["rew"].mean())
+            self.stats["done_rate"] = float(rb["done"].mean())
+            return rb
         T, N, dev = self.n_steps, self.n_envs, self.device
         bd = self.buffer_dtype
         buf = dict(obs=torch.zeros(T, N, self.obs_dim, device=dev, dtype=bd), act=torch.zeros(T, N, 28, device=dev, dtype=bd),

@@ -417,3 +417,31 @@ def test_flat_adam_matches_clip_grad_norm_plus_torch_adam():
     for n in results[0]:
         a, b = results[0][n], results[1][n]
         assert float((a - b).abs().max()) < 2e-4 * (float(a.abs().max()) + 1e-3), n
+
+
+def test_sub_batched_vecenv_and_captured_rollout(model):
+    """sub_batches = 2: the VecEnv surface is unchanged (one [N, ...] output set, SubprocVecEnv semantics) and PPO captures
+    the whole rollout as one graph with one chain per sub-batch; buffers are complete, finite and consistent."""
+    import torch
+    from deepmimic_mujoco_amd.deepmimic_env import HipDeepMimicVecEnv
+    from deepmimic_mujoco_amd.ppo import PPO
+    N = 256
+    venv = HipDeepMimicVecEnv(N, motion="walk", sub_batches=2, seed=5)
+    obs = venv.reset()
+    assert obs.shape == (N, 67) and np.isfinite(obs).all()
+    o2, r2, d2, infos = venv.step(np.zeros((N, 28), np.float32))
+    assert o2.shape == (N, 67) and r2.shape == (N,) and (r2[:N // 2] != 0).any() and (r2[N // 2:] != 0).any()   # both halves stepped
+    ppo = PPO(venv, net_arch=(64, 32), n_steps=8, batch_size=512, n_epochs=1)
+    buf = ppo.collect_rollouts()
+    assert buf["obs"].shape == (8, N, 67) and torch.isfinite(buf["obs"]).all() and torch.isfinite(buf["adv"]).all()
+    assert torch.isfinite(buf["rew"]).all() and ppo.num_timesteps == 8 * N
+    assert float(buf["rew"][:, :N // 2].abs().sum()) > 0 and float(buf["rew"][:, N // 2:].abs().sum()) > 0
+    # the observation stored at step t+1 is the one the env returned at step t (per half), unless the env was reset
+    cont = buf["done"][0] == 0
+    assert cont.any()
+    buf2 = {k: v.clone() for k, v in buf.items()}
+    ppo.collect_rollouts()                                                       # replay continues the same episodes
+    assert not torch.equal(buf2["obs"], ppo._rollout[1]["obs"])
+    ppo.train(ppo._rollout[1])
+    assert np.isfinite(ppo.stats["loss"])
+    venv.close()
