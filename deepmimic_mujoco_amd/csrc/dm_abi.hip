@@ -357,6 +357,8 @@ static int launch(DmEngine *e, DmLaunch &P, int nslots, void *stream) {
   if (e->cfg.task == DM_TASK_COMBINED) {
     if (e->clipL[1] < 1 || e->clipL[2] < 2) return fail(e, DM_EINVAL, "combined task needs clips 0,1,2 = walk, run, getup");
     hipLaunchKernelGGL(dm_step_combined_kernel, grid, block, 0, s, P);
+  } else if (P.nslots >= 6144) {
+    hipLaunchKernelGGL(dm_step_kernel_w3, grid, block, 0, s, P);   // three waves per SIMD pay off from ~1.5 x 4096 envs
   } else {
     hipLaunchKernelGGL(dm_step_kernel, grid, block, 0, s, P);
   }

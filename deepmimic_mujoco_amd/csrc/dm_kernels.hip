@@ -1923,6 +1923,12 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_
 extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_PER_SIMD) dm_step_combined_kernel(DmLaunch P) {
   step_body<1>(P);
 }
+// Same body compiled for three waves per SIMD (168 VGPRs, ~190 extra scratch accesses): +8..10 % once the batch
+// fills more than two rounds of the two-wave kernel (>= 6144 envs); at 4096 envs it would leave a one-third-full
+// second round, so dm_step picks the variant from the batch size.
+extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, 3) dm_step_kernel_w3(DmLaunch P) {
+  step_body<0>(P);
+}
 
 // Uniform random actions in [-2, 2) for bench.py config 2 (same generator as the oracle driver).
 extern "C" __global__ void dm_fill_actions_kernel(float *actions, int n, uint64_t seed, uint32_t step) {

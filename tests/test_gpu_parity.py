@@ -55,8 +55,8 @@ def _oracle_states(model, clip, nenv, nsteps, scale, seed, caps=(32, 128)):
     return recs
 
 
-def _run_teacher_forced(model, clips, oracle_clips, torch, scale, seed, nenv=16, nsteps=60, motion="walk"):
-    recs = _oracle_states(model, oracle_clips[motion], nenv, nsteps, scale, seed)
+def _run_teacher_forced(model, clips, oracle_clips, torch, scale, seed, nenv=16, nsteps=60, motion="walk", tile=1):
+    recs = _oracle_states(model, oracle_clips[motion], nenv, nsteps, scale, seed) * tile
     n = len(recs)
     eng = _engine(model, clips, n, torch, motion=motion)
     dev = eng.device
@@ -351,3 +351,22 @@ def test_narrowphase_coverage_all_pair_types(model, clips, oracle_clips, torch_m
     assert worst_dist < 2e-6
     assert worst_acc < 2e-3
     eng.close()
+
+
+def test_three_wave_kernel_variant_parity(model, clips, oracle_clips, torch_mod):
+    """Batches of >= 6144 envs run dm_step_kernel_w3 (the same body compiled for 3 waves/SIMD, 168 VGPRs): same parity
+    gates as the two-wave kernel, on 960 oracle states tiled to 6720 envs."""
+    res = _run_teacher_forced(model, clips, oracle_clips, torch_mod, 2.0, 3, tile=7)
+    assert len(res["qpos"]) == 6720
+    hard = [m for m in res["contact_mismatch"] if not m[3]]
+    assert len(hard) == 0
+    ok = np.ones(len(res["qpos"]), bool)
+    for m in res["contact_mismatch"]:
+        ok[m[0]] = False
+    ok[res["stage_flips"]] = False
+    assert len(res["stage_flips"]) <= 0.01 * len(ok)
+    assert res["qpos"][ok].max() < TOL_QPOS and res["qvel"][ok].max() < TOL_QVEL
+    assert res["obs"][ok].max() < TOL_OBS and res["rew"][ok].max() < TOL_REW
+    # identical inputs in every tile -> identical outputs (the variant is deterministic across slots)
+    q = res["qpos"].reshape(7, -1)
+    assert np.array_equal(q[0], q[3]) and np.array_equal(q[0], q[6])
