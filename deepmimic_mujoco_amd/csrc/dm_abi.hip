@@ -32,6 +32,7 @@ struct DmEngine {
   static constexpr int NEV = 512;              // ring of event pairs: one per dm_step while timing is on
   hipEvent_t ev0[NEV] = {}, ev1[NEV] = {};
   long nrec = 0;                               // launches recorded since dm_enable_timing(1)
+  int waves = 0;                               // 0: kernel variant from the batch size; 2 / 3: forced (env DM_WAVES, experiments)
   bool timing = false;
   float last_ms = 0;
   std::string err;
@@ -195,6 +196,7 @@ extern "C" int dm_create(const DmModel *model, const DmConfig *cfg, DmHandle *ou
   e->cfg = *cfg;
   e->model = *model;
   e->N = cfg->num_envs;
+  if (const char *w = getenv("DM_WAVES")) e->waves = atoi(w);
   int rc = check_model(e, *model);
   if (rc != DM_OK) { fprintf(stderr, "dm_create: %s\n", e->err.c_str()); delete e; return rc; }
   if (hipSetDevice(cfg->device) != hipSuccess) { delete e; return DM_ENODEV; }
@@ -357,7 +359,7 @@ static int launch(DmEngine *e, DmLaunch &P, int nslots, void *stream) {
   if (e->cfg.task == DM_TASK_COMBINED) {
     if (e->clipL[1] < 1 || e->clipL[2] < 2) return fail(e, DM_EINVAL, "combined task needs clips 0,1,2 = walk, run, getup");
     hipLaunchKernelGGL(dm_step_combined_kernel, grid, block, 0, s, P);
-  } else if (P.nslots >= 6144) {
+  } else if (e->waves == 3 || (e->waves == 0 && P.nslots >= 6144)) {
     hipLaunchKernelGGL(dm_step_kernel_w3, grid, block, 0, s, P);   // three waves per SIMD pay off from ~1.5 x 4096 envs
   } else {
     hipLaunchKernelGGL(dm_step_kernel, grid, block, 0, s, P);
