@@ -47,6 +47,7 @@
 #define PROF(i) do {} while (0)
 #endif
 typedef __attribute__((address_space(3))) const float *lds_cfloat_p;
+typedef float mfma_f16v __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(1))) DmDev GDev;          // model tables: global address space
 typedef const __attribute__((address_space(1))) DmPairDev GPair;
 #define MINVALF 1e-15f
@@ -1344,6 +1345,32 @@ __device__ __forceinline__ float fwd_constraint(GDev &T, const int lane, const i
       float ARd = R;
 #pragma unroll
       for (int k = 0; k < DMK_NV; k++) ARd += J[k] * J[k];
+      if (nefc <= DMK_REGROW) {
+        // All rows sit in lanes 0..31: A = B B^T is one 32 x 32 x 34 product on the matrix pipe.  v_mfma_f32_32x32x2f32
+        // wants lane l to supply B[l % 32][k0 + l / 32] for both operands: v_permlane32_swap puts the rows' k0 + 1
+        // entries into the upper half-wave.  17 MFMAs + 17 swaps instead of nefc x (34 v_readlane + 34 FMA).
+        mfma_f16v acc;
+#pragma unroll
+        for (int v = 0; v < 16; v++) acc[v] = 0.f;
+        StaticFor<0, DMK_NV / 2>::run([&](auto kc) {
+          constexpr int k0 = decltype(kc)::value * 2;
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(J[k0]), __float_as_uint(J[k0 + 1]), false, false);
+          const float x = __uint_as_float(sw[0]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, acc, 0, 0, 0);
+          return true;
+        });
+        // result fragment: lane (c, h) holds A[i][c] = A[c][i] for i = 8 (v / 4) + 4 h + v % 4; the upper half-wave's
+        // sixteen values move down with one more swap each, so that lane c < 32 owns its whole row
+        StaticFor<0, 16>::run([&](auto vc) {
+          constexpr int v = decltype(vc)::value;
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[v]), __float_as_uint(acc[v]), false, false);
+          constexpr int i0 = (v / 4) * 8 + (v % 4);
+          AR[i0] = lane_sel<(1ull << i0)>(acc[v] + R, acc[v]);
+          const float up = __uint_as_float(sw[1]);
+          AR[i0 + 4] = lane_sel<(1ull << (i0 + 4))>(up + R, up);
+          return true;
+        });
+      } else
       StaticFor<0, DMK_REGROW>::run([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         if (i >= nefc) {  // PGS walks the columns in blocks of four: zero the tail of the last block, stop after it
