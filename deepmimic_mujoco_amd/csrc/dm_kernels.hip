@@ -1091,6 +1091,7 @@ __device__ __forceinline__ int fwd_collide(GDev &T, const int lane) {
 
 // ---- one constraint row (limit or pyramid edge / frictionless contact) for the calling lane:
 // Jacobian row -> reference acceleration, regulariser -> B row = D^-1/2 L^-T J^T (returned in J)
+template <bool MF>   // MF: all rows live in lanes 0..31 (nefc <= 32): the dof-by-row products run on the matrix pipe
 __device__ __forceinline__ void build_row(GDev &T, EnvLds &S, const int r, const int nefc, const float (&com)[3],
                                           float (&J)[DMK_NV], float &R, float &Dd, float &aref, float &bb, float &jw) {
       float rpos = 0, rmargin = 0, rdiag = 1, mu = 0;
@@ -1142,11 +1143,39 @@ __device__ __forceinline__ void build_row(GDev &T, EnvLds &S, const int r, const
       }
       float vel = 0, jqs = 0;
       jw = 0;
+      float vals[32];
+      if (MF) {
+        // val[k][row] = cdof_k . (wa, wl) for 32 dofs x 32 rows: three v_mfma_f32_32x32x2f32 (K = 6).  Operand A: lane l
+        // reads cdof[l % 32][k0 + l / 32] from LDS; operand B: this lane's weights with the k0 + 1 component of the
+        // rows swapped into the upper half-wave.  The result fragment is completed with one swap per register.
+        const float wv[6] = {wa[0], wa[1], wa[2], wl[0], wl[1], wl[2]};
+        const int lane_ = (int)(threadIdx.x & 63);
+        const float *cdp = &S.cdof[lane_ & 31][lane_ >> 5];
+        mfma_f16v acc;
+#pragma unroll
+        for (int v = 0; v < 16; v++) acc[v] = 0.f;
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(wv[2 * p]), __float_as_uint(wv[2 * p + 1]), false, false);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cdp[2 * p], __uint_as_float(sw[0]), acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[v]), __float_as_uint(acc[v]), false, false);
+          vals[(v / 4) * 8 + (v % 4)] = acc[v];
+          vals[(v / 4) * 8 + (v % 4) + 4] = __uint_as_float(sw[1]);
+        }
+      }
 #pragma unroll
       for (int k = 0; k < DMK_NV; k++) {
-        const float4 ca = *reinterpret_cast<const float4 *>(&S.cdof[k][0]);
-        const float2 cb = *reinterpret_cast<const float2 *>(&S.cdof[k][4]);
-        float val = ca.x * wa[0] + ca.y * wa[1] + ca.z * wa[2] + ca.w * wl[0] + cb.x * wl[1] + cb.y * wl[2];
+        float val;
+        if (MF && k < 32) {
+          val = vals[k];
+        } else {
+          const float4 ca = *reinterpret_cast<const float4 *>(&S.cdof[k][0]);
+          const float2 cb = *reinterpret_cast<const float2 *>(&S.cdof[k][4]);
+          val = ca.x * wa[0] + ca.y * wa[1] + ca.z * wa[2] + ca.w * wl[0] + cb.x * wl[1] + cb.y * wl[2];
+        }
         float sg = (float)((int)((cm2 >> k) & 1ull) - (int)((cm1 >> k) & 1ull));   // 0 for limit / unused rows (no chains)
         float j = (k == ldof) ? lsign : sg * val;
         J[k] = j;
@@ -1194,8 +1223,8 @@ __device__ __noinline__ float fwd_constraint_wide(GDev &T, const int lane, const
   const float com[3] = {S.com[0], S.com[1], S.com[2]};
   float Ja[DMK_NV], Jb[DMK_NV];
   float Ra, Da, arefa, bba, jwa, Rb, Db, arefb, bbb, jwb;
-  build_row(T, S, lane, nefc, com, Ja, Ra, Da, arefa, bba, jwa);
-  build_row(T, S, lane + 64, nefc, com, Jb, Rb, Db, arefb, bbb, jwb);
+  build_row<false>(T, S, lane, nefc, com, Ja, Ra, Da, arefa, bba, jwa);
+  build_row<false>(T, S, lane + 64, nefc, com, Jb, Rb, Db, arefb, bbb, jwb);
   float ARda = Ra, ARdb = Rb;
 #pragma unroll
   for (int k = 0; k < DMK_NV; k++) { ARda += Ja[k] * Ja[k]; ARdb += Jb[k] * Jb[k]; }
@@ -1335,7 +1364,8 @@ __device__ __forceinline__ float fwd_constraint(GDev &T, const int lane, const i
       // ---- Jacobian row, reference acceleration, regulariser, B row (lane = row)
       float J[DMK_NV];
       float R, Dd, aref, bb, jw;
-      build_row(T, S, lane, nefc, com, J, R, Dd, aref, bb, jw);
+      if (nefc <= DMK_REGROW) build_row<true>(T, S, lane, nefc, com, J, R, Dd, aref, bb, jw);
+      else build_row<false>(T, S, lane, nefc, com, J, R, Dd, aref, bb, jw);
       PROF(6);
       // ---- A row: AR[i] = B_lane . B_i (+ R on the diagonal).  Columns 0..31 live in registers; the
       // rare columns 32..63 (nefc > 32: p99 of the benchmark workload is 16) go to a per-env global
