@@ -707,13 +707,38 @@ __device__ __forceinline__ void fwd_smooth(GDev &T, const int lane) {
     }
     SYNC();
     const float armv = isdof ? T.d_arm[lk] : 0.f;
+    // dots[k] = cdof_lane . buf_k.  k < 32 on the matrix pipe (32 x 32 x 6: operand A = buf from LDS, operand B = the
+    // lanes' cdof with the odd components swapped into the upper half-wave; dof lanes 32, 33 only own rows 32, 33);
+    // k = 32, 33 with FMAs.
+    float dots[DMK_NV];
+    {
+      const float *bufp = &S.u.v.mbuf[lane & 31][lane >> 5];
+      mfma_f16v acc;
+#pragma unroll
+      for (int v = 0; v < 16; v++) acc[v] = 0.f;
+#pragma unroll
+      for (int p = 0; p < 3; p++) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(cd[2 * p]), __float_as_uint(cd[2 * p + 1]), false, false);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bufp[2 * p], __uint_as_float(sw[0]), acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int v = 0; v < 16; v++) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[v]), __float_as_uint(acc[v]), false, false);
+        dots[(v / 4) * 8 + (v % 4)] = acc[v];
+        dots[(v / 4) * 8 + (v % 4) + 4] = __uint_as_float(sw[1]);
+      }
+#pragma unroll
+      for (int k = 32; k < DMK_NV; k++) {
+        float d = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) d = fmaf(cd[i], S.u.v.mbuf[k][i], d);
+        dots[k] = d;
+      }
+    }
     StaticFor<0, DMK_NV>::run([&](auto kc) {
       constexpr int k = decltype(kc)::value;
-      float dot = 0;
-#pragma unroll
-      for (int i = 0; i < 6; i++) dot = fmaf(cd[i], g_S.u.v.mbuf[k][i], dot);
-      const float off = lane_sel<topo::anc_mask(k)>(dot, 0.f);                 // strict ancestors of k keep M[k][j]
-      C[k] = lane_sel<(1ull << k)>(dot + armv, off);                           // lane k: diagonal + armature
+      const float off = lane_sel<topo::anc_mask(k)>(dots[k], 0.f);             // strict ancestors of k keep M[k][j]
+      C[k] = lane_sel<(1ull << k)>(dots[k] + armv, off);                       // lane k: diagonal + armature
       return true;
     });
   }
