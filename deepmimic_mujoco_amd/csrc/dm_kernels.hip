@@ -48,6 +48,9 @@
 #endif
 typedef __attribute__((address_space(3))) const float *lds_cfloat_p;
 typedef float mfma_f16v __attribute__((ext_vector_type(16)));
+#ifndef DMK_MFMA_MIN_ROWS
+#define DMK_MFMA_MIN_ROWS 8   // below this the 17-MFMA product (1088 cycles) loses to nefc x (34 v_readlane + 34 FMA)
+#endif
 typedef const __attribute__((address_space(1))) DmDev GDev;          // model tables: global address space
 typedef const __attribute__((address_space(1))) DmPairDev GPair;
 #define MINVALF 1e-15f
@@ -1400,7 +1403,7 @@ __device__ __forceinline__ float fwd_constraint(GDev &T, const int lane, const i
       float ARd = R;
 #pragma unroll
       for (int k = 0; k < DMK_NV; k++) ARd += J[k] * J[k];
-      if (nefc <= DMK_REGROW) {
+      if (nefc <= DMK_REGROW && nefc >= DMK_MFMA_MIN_ROWS) {
         // All rows sit in lanes 0..31: A = B B^T is one 32 x 32 x 34 product on the matrix pipe.  v_mfma_f32_32x32x2f32
         // wants lane l to supply B[l % 32][k0 + l / 32] for both operands: v_permlane32_swap puts the rows' k0 + 1
         // entries into the upper half-wave.  17 MFMAs + 17 swaps instead of nefc x (34 v_readlane + 34 FMA).
