@@ -25,7 +25,8 @@ EXPORTS = ["dm_default_config", "dm_create", "dm_destroy", "dm_last_error", "dm_
            "dm_load_clip", "dm_set_env_clips", "dm_reset", "dm_step", "dm_step_forced",
            "dm_set_state", "dm_get_state", "dm_get_counters", "dm_set_counters", "dm_set_debug",
            "dm_fill_random_actions", "dm_last_step_ms", "dm_enable_timing", "dm_get_work",
-           "dm_set_clip_flags", "dm_obs_dim", "dm_terms_dim", "dm_get_env_clips", "dm_mean_step_ms", "dm_ppo_loss", "dm_forward", "dm_linear_wgrad", "dm_ppo_gather", "dm_adam_clip_step"]
+           "dm_set_clip_flags", "dm_obs_dim", "dm_terms_dim", "dm_get_env_clips", "dm_mean_step_ms", "dm_ppo_loss", "dm_forward", "dm_linear_wgrad", "dm_ppo_gather", "dm_adam_clip_step", "dm_policy_sample",
+           "dm_rollout_store"]
 
 
 class DmConfig(C.Structure):
@@ -74,6 +75,8 @@ def load_library():
     L.dm_get_state.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
     L.dm_forward.argtypes = [vp, vp, i32, vp]
     L.dm_linear_wgrad.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
+    L.dm_policy_sample.argtypes = [vp, vp, i32, i32, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]
+    L.dm_rollout_store.argtypes = [i32, i32, i32] + [vp] * 16
     L.dm_adam_clip_step.argtypes = [vp, vp, vp, vp, i32] + [C.c_float] * 5 + [vp, vp]
     L.dm_ppo_gather.argtypes = [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.dm_get_counters.argtypes = [vp, vp, vp, vp, vp]

@@ -303,3 +303,86 @@ extern "C" int dm_adam_clip_step(float *p, const float *g, float *m, float *v, i
   hipLaunchKernelGGL(adam_update_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, max_norm, state2);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Rollout side of the PPO loop (reference: src/sb3_ppo.py:307-313 -> [EXT] SB3 collect_rollouts): per env step the
+// policy head output becomes a sampled action, its log-probability and the clipped action handed to the env, and the
+// step's data go into the rollout buffer.  Two launches instead of ~20 elementwise PyTorch kernels.
+namespace {
+
+__device__ __forceinline__ unsigned ppo_hash32(unsigned long long seed, unsigned a, unsigned b, unsigned c) {
+  unsigned long long x = seed ^ ((unsigned long long)a * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)b * 0xBF58476D1CE4E5B9ull) ^
+                         ((unsigned long long)c * 0x94D049BB133111EBull);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (unsigned)(x >> 32);
+}
+
+// act = mean + exp(log_std) * eps, eps ~ N(0,1) (Box-Muller on a counter-based hash: env, draw counter, action index);
+// logp = sum_j -0.5 eps_j^2 - log_std_j - 0.5 log(2 pi); act_env = clamp(act, lo, hi).  counter[0] is read here and
+// advanced by ppo_store_kernel, which runs later on the same stream.
+__global__ void ppo_sample_kernel(const float *mean, const float *log_std, int N, int A, unsigned long long seed,
+                                  const unsigned *counter, const float *lo, const float *hi, float *act, float *act_env,
+                                  float *logp) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  const unsigned ctr = counter[0];
+  float lp = 0.f;
+  for (int j = 0; j < A; j += 2) {
+    const float u1 = ((float)(ppo_hash32(seed, (unsigned)e, ctr, (unsigned)j) >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
+    const float u2 = (float)(ppo_hash32(seed, (unsigned)e, ctr, (unsigned)j + 1u) >> 8) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.283185307179586f * u2, &sn, &cs);
+    const float eps[2] = {rad * cs, rad * sn};
+    for (int q = 0; q < 2 && j + q < A; q++) {
+      const float ls = log_std[j + q];
+      const float a = mean[(size_t)e * A + j + q] + expf(ls) * eps[q];
+      act[(size_t)e * A + j + q] = a;
+      act_env[(size_t)e * A + j + q] = fminf(fmaxf(a, lo[j + q]), hi[j + q]);
+      lp += -0.5f * eps[q] * eps[q] - ls - 0.9189385332046727f;
+    }
+  }
+  logp[e] = lp;
+}
+
+// rollout buffer row t <- (obs the policy saw, action, value, logp, reward, done); last_obs <- the env's new obs
+__global__ void ppo_store_kernel(int N, int D, int A, const float *last_obs, const float *act, const float *val, const float *logp,
+                                 const float *rew, const unsigned char *done, const float *new_obs, float *b_obs, float *b_act,
+                                 float *b_val, float *b_logp, float *b_rew, float *b_done, float *last_obs_out, unsigned *counter) {
+  const int e = blockIdx.x;
+  if (e >= N) return;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    b_obs[(size_t)e * D + c] = last_obs[(size_t)e * D + c];
+    last_obs_out[(size_t)e * D + c] = new_obs[(size_t)e * D + c];
+  }
+  for (int c = threadIdx.x; c < A; c += blockDim.x) b_act[(size_t)e * A + c] = act[(size_t)e * A + c];
+  if (threadIdx.x == 0) {
+    b_val[e] = val[e]; b_logp[e] = logp[e]; b_rew[e] = rew[e]; b_done[e] = done[e] ? 1.f : 0.f;
+    if (e == 0 && counter) counter[0] += 1u;
+  }
+}
+
+}  // namespace
+
+extern "C" int dm_policy_sample(const float *mean, const float *log_std, int N, int A, unsigned long long seed,
+                                const unsigned *counter, const float *lo, const float *hi, float *act, float *act_env,
+                                float *logp, void *stream) {
+  if (!mean || !log_std || !counter || !lo || !hi || !act || !act_env || !logp || N < 1 || A < 1) return -22;
+  hipLaunchKernelGGL(ppo_sample_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, log_std, N, A, seed, counter,
+                     lo, hi, act, act_env, logp);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int dm_rollout_store(int N, int D, int A, const float *last_obs, const float *act, const float *val, const float *logp,
+                                const float *rew, const unsigned char *done, const float *new_obs, float *b_obs, float *b_act,
+                                float *b_val, float *b_logp, float *b_rew, float *b_done, float *last_obs_out, unsigned *counter,
+                                void *stream) {
+  if (N < 1 || !last_obs || !act || !val || !logp || !rew || !done || !new_obs || !b_obs || !b_act || !b_val || !b_logp || !b_rew ||
+      !b_done || !last_obs_out)
+    return -22;
+  hipLaunchKernelGGL(ppo_store_kernel, dim3(N), dim3(128), 0, (hipStream_t)stream, N, D, A, last_obs, act, val, logp, rew, done, new_obs,
+                     b_obs, b_act, b_val, b_logp, b_rew, b_done, last_obs_out, counter);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}

@@ -298,7 +298,7 @@ class PPO:
     def __init__(self, env, net_arch=(256, 128), n_steps=4096, batch_size=4096, n_epochs=20, learning_rate=4e-4,
                  gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5,
                  normalize_advantage=True, seed=0, device=None, buffer_dtype=torch.float32, policy=None,
-                 use_hip_graph=None, fused_loss=True, flat_adam=True, two_stream=True, rollout_graph=True):
+                 use_hip_graph=None, fused_loss=True, flat_adam=True, two_stream=True, rollout_graph=True, fused_rollout=True):
         # rollout_graph only takes effect for an env built with sub_batches > 1
         self.env = env
         self.device = device if device is not None else getattr(env, "device", torch.device("cpu"))
@@ -310,6 +310,8 @@ class PPO:
         self.fused_loss = fused_loss          # dm_ppo_loss (HIP) for the loss tail when the batch is on the GPU
         self.two_stream = two_stream          # value trunk on a second stream (parallel graph branches)
         self.rollout_graph = rollout_graph    # env with sub_batches > 1: the T-step rollout is one captured hipGraph
+        self.fused_rollout = fused_rollout    # dm_policy_sample + dm_rollout_store instead of ~20 small kernels per step
+        self._rollout_seed = 0x5EED0000 + seed
         self.buffer_dtype = buffer_dtype
         torch.manual_seed(seed)  # identical initial weights on every rank; no parameter broadcast needed
         self.obs_dim = int(env.observation_space.shape[0]) if env is not None else 67   # 67 DPEnv, 72 DPCombinedEnv
@@ -337,6 +339,52 @@ class PPO:
         self.stats = {}
 
     # ------------------------------------------------------------------ rollout
+    # ---- rollout-side fused kernels (csrc/dm_ppo.hip): policy head -> sampled / clamped action + logp, and the
+    # per-step stores into the rollout buffer, two launches instead of ~20 small PyTorch kernels per env step
+    def _fused_rollout_ok(self):
+        return (self.fused_rollout and self.device.type == "cuda" and self.buffer_dtype == torch.float32)
+
+    def _rollout_scratch(self, key):
+        sc = getattr(self, "_rsc", {})
+        if key not in sc:
+            n = key[0]
+            z = lambda *shape: torch.zeros(*shape, device=self.device)
+            sc[key] = dict(act=z(n, 28), act_env=z(n, 28), logp=z(n))
+            self._rsc = sc
+        if getattr(self, "_rctr", None) is None:
+            self._rctr = torch.zeros(1, dtype=torch.int32, device=self.device)      # draw counter, advanced on the device
+        return sc[key]
+
+    def _policy_step_fused(self, obs, env_index=0):
+        """mean/value by the MLP (library GEMMs), then one launch for sample + logp + clamp."""
+        import ctypes as C
+        from . import _lib
+        n = obs.shape[0]
+        sc = self._rollout_scratch((n, env_index))
+        mean = self.policy.action_net(self.policy.pi(obs))
+        val = self.policy.value_net(self.policy.vf(obs)).squeeze(-1).contiguous()
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rc = _lib.load_library().dm_policy_sample(p(mean.contiguous()), p(self.policy.log_std), n, 28,
+                                                  C.c_uint64(self._rollout_seed + 7919 * env_index), p(self._rctr), p(self.act_lo),
+                                                  p(self.act_hi), p(sc["act"]), p(sc["act_env"]), p(sc["logp"]),
+                                                  C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("dm_policy_sample failed (%d)" % rc)
+        return sc, val
+
+    def _store_fused(self, rb, t, sl, last, sc, val, out, bump):
+        import ctypes as C
+        from . import _lib
+        p = lambda x: C.c_void_p(x.data_ptr())
+        n = val.shape[0]
+        rc = _lib.load_library().dm_rollout_store(
+            n, self.obs_dim, 28, p(last[sl]), p(sc["act"]), p(val), p(sc["logp"]), p(out["rew"]), p(out["done"]), p(out["obs"]),
+            p(rb["obs"][t, sl]), p(rb["act"][t, sl]), p(rb["val"][t, sl]), p(rb["logp"][t, sl]), p(rb["rew"][t, sl]),
+            p(rb["done"][t, sl]), p(last[sl]), p(self._rctr) if bump else None,
+            C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("dm_rollout_store failed (%d)" % rc)
+
     def _rollout_graph_build(self):
         """Capture the whole T-step rollout as ONE hipGraph with one chain per env sub-batch (own stream each): the
         policy forward of one half overlaps the step kernel of the other, so the ramp-down of every launch is filled
@@ -352,6 +400,11 @@ class PPO:
             sl = env.sub_slices[k]
             for t in range(steps):
                 obs = last[sl]
+                if self._fused_rollout_ok():
+                    sc, val = self._policy_step_fused(obs, env_index=k)
+                    out = env.step_sub(k, sc["act_env"])
+                    self._store_fused(rb, t, sl, last, sc, val, out, bump=(k == K - 1))
+                    continue
                 act, val, logp = self.policy(obs)
                 rb["obs"][t, sl] = obs
                 rb["act"][t, sl] = act
@@ -386,7 +439,42 @@ class PPO:
         rb["adv"], rb["ret"] = adv, ret
         self._rollout = (g, rb, last)
 
+    def _rollout_pipelined_eager(self):
+        """sub_batches > 1 without graph capture: the host issues step t of every sub-batch on that sub-batch's stream,
+        so the policy kernels of one overlap the step kernel of the other (14 launches per sub-batch step)."""
+        env, T, N, dev = self.env, self.n_steps, self.n_envs, self.device
+        K = env.sub_batches
+        if getattr(self, "_pipe", None) is None:
+            z = lambda *shape: torch.zeros(*shape, device=dev)
+            rb = dict(obs=z(T, N, self.obs_dim), act=z(T, N, 28), rew=z(T, N), done=z(T, N), val=z(T, N), logp=z(T, N))
+            last = env.reset_tensor().clone() if self._last_obs is None else self._last_obs.clone()
+            self._pipe = (rb, last, [torch.cuda.Stream(device=dev) for _ in range(K)])
+        rb, last, streams = self._pipe
+        cur = torch.cuda.current_stream(dev)
+        with torch.no_grad():
+            for st in streams:
+                st.wait_stream(cur)
+            for t in range(T):
+                for k in range(K):
+                    with torch.cuda.stream(streams[k]):
+                        sl = env.sub_slices[k]
+                        sc, val = self._policy_step_fused(last[sl], env_index=k)
+                        out = env.step_sub(k, sc["act_env"])
+                        self._store_fused(rb, t, sl, last, sc, val, out, bump=(k == K - 1))
+            for st in streams:
+                cur.wait_stream(st)
+            last_val = self.policy.predict_values(last)
+            rb["adv"], rb["ret"] = compute_gae(rb["rew"], rb["val"], rb["done"], last_val, self.gamma, self.gae_lambda)
+        self._last_obs = last
+        self.num_timesteps += T * N
+        self.stats["mean_reward"] = float(rb["rew"].mean())
+        self.stats["done_rate"] = float(rb["done"].mean())
+        return rb
+
     def collect_rollouts(self):
+        if (not self.rollout_graph and self._fused_rollout_ok() and getattr(self.env, "sub_batches", 1) > 1
+                and hasattr(self.env, "step_sub")):
+            return self._rollout_pipelined_eager()
         if (self.rollout_graph and self.device.type == "cuda" and getattr(self.env, "sub_batches", 1) > 1
                 and hasattr(self.env, "step_sub")):
             if getattr(self, "_rollout", None) is None:
@@ -407,8 +495,15 @@ class PPO:
             self._last_obs = self.env.reset_tensor().clone()
         ep_done = 0
         with torch.no_grad():
+            fused = self._fused_rollout_ok() and self._last_obs.is_contiguous()
+            full = slice(0, N)
             for t in range(T):
                 obs = self._last_obs
+                if fused:
+                    sc, val = self._policy_step_fused(obs)
+                    out = self.env.step_tensor(sc["act_env"])
+                    self._store_fused(buf, t, full, self._last_obs, sc, val, out, bump=True)
+                    continue
                 act, val, logp = self.policy(obs)
                 out = self.env.step_tensor(torch.clamp(act, self.act_lo, self.act_hi))
                 buf["obs"][t] = obs

@@ -33,6 +33,7 @@ def main(argv=None):
     ap.add_argument("--sub-batches", type=int, default=1,
                     help="> 1: env sub-batches stepped as parallel chains of one captured rollout graph (measured slower "
                          "than the plain loop on ROCm 7.2: ~5 us per graph node x 2 200 nodes)")
+    ap.add_argument("--rollout-graph", action="store_true", help="with --sub-batches > 1: capture the rollout as one hipGraph")
     ap.add_argument("--json", action="store_true", help="print a JSON throughput summary on rank 0")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + several ranks on one GPU only rehearses the multi-rank path")
@@ -62,7 +63,7 @@ def main(argv=None):
                                  seed=1234 + 7919 * rank, sub_batches=args.sub_batches if args.envs % args.sub_batches == 0 else 1)
     ppo = PPO(env, net_arch=tuple(int(x) for x in args.arch.split(",")), n_steps=args.horizon,
               batch_size=args.minibatch, n_epochs=args.epochs, learning_rate=args.lr, seed=args.seed,
-              buffer_dtype=torch.bfloat16 if args.bf16_buffer else torch.float32)
+              buffer_dtype=torch.bfloat16 if args.bf16_buffer else torch.float32, rollout_graph=args.rollout_graph)
     hist = []
     t0 = time.perf_counter()
     ppo.learn(args.total, log_interval=0 if args.json else 1, callback=lambda p: hist.append(dict(p.stats)))

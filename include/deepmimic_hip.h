@@ -191,6 +191,17 @@ int dm_ppo_gather(const long long *idx, int B, const float *obs, int D, const fl
 int dm_adam_clip_step(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
                       float max_norm, float *state2, void *stream);
 
+/* Rollout side of SB3's collect_rollouts [EXT] (driven by src/sb3_ppo.py:307-313), two launches per env step:
+ * dm_policy_sample: act = mean + exp(log_std) * N(0,1) (counter-based generator: seed, env, counter[0], action index),
+ *   logp of the diagonal Gaussian, act_env = clamp(act, lo, hi) (what DPEnv.step receives);
+ * dm_rollout_store: rollout-buffer row <- (obs the policy saw, action, value, logp, reward, done), last_obs <- new obs,
+ *   counter[0] += 1.  All pointers are device pointers; b_* point at row t of the [T, N, ...] buffers. */
+int dm_policy_sample(const float *mean, const float *log_std, int N, int A, unsigned long long seed, const unsigned *counter,
+                     const float *lo, const float *hi, float *act, float *act_env, float *logp, void *stream);
+int dm_rollout_store(int N, int D, int A, const float *last_obs, const float *act, const float *val, const float *logp,
+                     const float *rew, const unsigned char *done, const float *new_obs, float *b_obs, float *b_act, float *b_val,
+                     float *b_logp, float *b_rew, float *b_done, float *last_obs_out, unsigned *counter, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

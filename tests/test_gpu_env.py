@@ -445,3 +445,42 @@ def test_sub_batched_vecenv_and_captured_rollout(model):
     ppo.train(ppo._rollout[1])
     assert np.isfinite(ppo.stats["loss"])
     venv.close()
+
+
+def test_fused_rollout_kernels(model):
+    """dm_policy_sample: standard-normal noise (moments, independence across draws), logp equal to the policy's own
+    formula for the sampled action, clamping; dm_rollout_store through a short rollout: buffers equal to what the
+    unfused loop stores (obs seen by the policy, its value, rewards / dones of the env)."""
+    import torch
+    from deepmimic_mujoco_amd.deepmimic_env import HipDeepMimicVecEnv
+    from deepmimic_mujoco_amd.ppo import PPO
+    N = 4096
+    venv = HipDeepMimicVecEnv(N, motion="walk", seed=9)
+    ppo = PPO(venv, net_arch=(64, 32), n_steps=4, batch_size=1024, n_epochs=1)
+    with torch.no_grad():
+        ppo.policy.log_std.copy_(torch.linspace(-1.0, 0.5, 28))
+        obs = venv.reset_tensor().clone()
+        sc, val = ppo._policy_step_fused(obs)
+        act1 = sc["act"].clone()
+        mean = ppo.policy.action_net(ppo.policy.pi(obs))
+        eps = (act1 - mean) / ppo.policy.log_std.exp()
+        assert abs(float(eps.mean())) < 0.01 and abs(float(eps.std()) - 1.0) < 0.01
+        assert abs(float((eps ** 3).mean())) < 0.03 and abs(float((eps ** 4).mean()) - 3.0) < 0.1
+        assert abs(float(torch.corrcoef(eps[:, :2].T)[0, 1])) < 0.05                 # pairs come from one Box-Muller draw
+        assert torch.allclose(sc["logp"], ppo.policy._logp(act1, mean), atol=2e-4)
+        assert torch.equal(sc["act_env"], torch.clamp(act1, ppo.act_lo, ppo.act_hi))
+        assert torch.allclose(val, ppo.policy.predict_values(obs), atol=1e-6)
+        sc2, _ = ppo._policy_step_fused(obs)                                          # same counter -> same draw
+        assert torch.equal(sc2["act"], act1)
+    buf = ppo.collect_rollouts()                                                       # counter advances once per step
+    with torch.no_grad():
+        for t in range(4):
+            m = ppo.policy.action_net(ppo.policy.pi(buf["obs"][t]))
+            assert torch.allclose(buf["logp"][t], ppo.policy._logp(buf["act"][t], m), atol=2e-4)
+            assert torch.allclose(buf["val"][t], ppo.policy.predict_values(buf["obs"][t]), atol=1e-5)
+        e0 = (buf["act"][0] - ppo.policy.action_net(ppo.policy.pi(buf["obs"][0]))) / ppo.policy.log_std.exp()
+        e1 = (buf["act"][1] - ppo.policy.action_net(ppo.policy.pi(buf["obs"][1]))) / ppo.policy.log_std.exp()
+        assert abs(float((e0 * e1).mean())) < 0.01                                     # fresh noise every step
+        cont = buf["done"][0] == 0
+        assert cont.float().mean() > 0.5 and torch.isfinite(buf["rew"]).all()
+    venv.close()
