@@ -33,7 +33,9 @@ def measured_traffic_bytes():
     import csv
     import glob
     try:
-        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dm_step_kernel.csv")))[-1]
+        import re
+        files = glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dm_step_kernel.csv"))
+        path = max(files, key=lambda f: tuple(int(x) for x in re.findall(r"\d+", os.path.basename(f))))   # newest round / version
         vals = {r["counter"]: float(r["mean_per_dispatch_over_last_10_dispatches"]) for r in csv.DictReader(open(path))}
         return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
     except Exception:
