@@ -14,6 +14,7 @@
 
 #include "dm_kernels.hip"
 #include "dm_ppo.hip"
+#include "dm_policy.hip"
 
 struct DmEngine {
   DmConfig cfg;

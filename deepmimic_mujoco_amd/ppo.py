@@ -121,6 +121,62 @@ class MlpPolicy(nn.Module):
         return self.value_net(self.vf(obs)).squeeze(-1)
 
 
+class FusedPolicyForward:
+    """``dm_policy_forward`` (csrc/dm_policy.hip) for an ``MlpPolicy`` with two hidden layers: both trunks, the sampling
+    head and the policy-side rollout-buffer writes as one launch.  ``pack()`` re-orders the weights into MFMA operand
+    order and must be called again after the weights changed (once per ``collect_rollouts``)."""
+
+    def __init__(self, policy, device):
+        from . import _lib
+        self.lib = _lib.load_library()
+        self.policy, self.device = policy, device
+        lin = lambda seq: [m for m in seq if isinstance(m, nn.Linear)]
+        self.pi, self.vf = lin(policy.pi) + [policy.action_net], lin(policy.vf) + [policy.value_net]
+        self.D, self.H1, self.H2, self.A = self.pi[0].in_features, self.pi[0].out_features, self.pi[1].out_features, self.pi[2].out_features
+        n = int(self.lib.dm_policy_packed_floats(self.D, self.H1, self.H2, self.A))
+        if n <= 0:
+            raise ValueError("dm_policy_forward does not support this net")
+        self.packed = [torch.zeros(n, device=device), torch.zeros(n, device=device)]
+
+    @staticmethod
+    def supported(policy, device):
+        if device.type != "cuda" or not isinstance(policy, MlpPolicy):
+            return False
+        lin = [m for m in policy.pi if isinstance(m, nn.Linear)]
+        if len(lin) != 2 or len([m for m in policy.vf if isinstance(m, nn.Linear)]) != 2:
+            return False
+        h1, h2, a, d = lin[0].out_features, lin[1].out_features, policy.action_net.out_features, lin[0].in_features
+        lds = 32 * (h1 + 4 + max(((d + 7) // 8) * 8 + 4, 132)) * 4
+        return h1 % 32 == 0 and h2 % 32 == 0 and a <= 32 and lds <= 160 * 1024 and all(
+            m.weight.dtype == torch.float32 and m.weight.is_contiguous() for m in lin)
+
+    def _stream(self):
+        import ctypes as C
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def pack(self):
+        import ctypes as C
+        p = lambda t: C.c_void_p(t.data_ptr())
+        for layers, out, a in ((self.pi, self.packed[0], self.A), (self.vf, self.packed[1], 1)):
+            rc = self.lib.dm_policy_pack(p(layers[0].weight), p(layers[1].weight), p(layers[2].weight), self.D, self.H1, self.H2, a,
+                                         p(out), self._stream())
+            if rc != 0:
+                raise RuntimeError("dm_policy_pack failed (%d)" % rc)
+
+    def __call__(self, obs, seed, counter, draw_offset, lo, hi, act, act_env, logp, val, obs_copy=None, mean_out=None,
+                 deterministic=False):
+        import ctypes as C
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        pi, vf = self.pi, self.vf
+        rc = self.lib.dm_policy_forward(
+            p(obs), obs.shape[0], self.D, self.H1, self.H2, self.A, p(self.packed[0]), p(pi[0].bias), p(pi[1].bias), p(pi[2].bias),
+            p(self.packed[1]), p(vf[0].bias), p(vf[1].bias), p(vf[2].bias), p(self.policy.log_std), C.c_uint64(seed), p(counter),
+            C.c_uint32(draw_offset), int(bool(deterministic)), p(lo), p(hi), p(mean_out), p(act), p(act_env), p(logp), p(val),
+            p(obs_copy), self._stream())
+        if rc != 0:
+            raise RuntimeError("dm_policy_forward failed (%d)" % rc)
+
+
 class ExtractedPolicy:
     """The reference's exported walk policy: a = tanh(tanh(o W0 + B0) W2 + B2) WA + BA
     (src/extracted_policy.py:471-478; used with obs[:66] and clip +-0.5, src/play_extracted.py:36-38)."""
@@ -298,7 +354,8 @@ class PPO:
     def __init__(self, env, net_arch=(256, 128), n_steps=4096, batch_size=4096, n_epochs=20, learning_rate=4e-4,
                  gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5,
                  normalize_advantage=True, seed=0, device=None, buffer_dtype=torch.float32, policy=None,
-                 use_hip_graph=None, fused_loss=True, flat_adam=True, two_stream=True, rollout_graph=True, fused_rollout=True):
+                 use_hip_graph=None, fused_loss=True, flat_adam=True, two_stream=True, rollout_graph=True, fused_rollout=True,
+                 fused_policy=True):
         # rollout_graph only takes effect for an env built with sub_batches > 1
         self.env = env
         self.device = device if device is not None else getattr(env, "device", torch.device("cpu"))
@@ -311,6 +368,7 @@ class PPO:
         self.two_stream = two_stream          # value trunk on a second stream (parallel graph branches)
         self.rollout_graph = rollout_graph    # env with sub_batches > 1: the T-step rollout is one captured hipGraph
         self.fused_rollout = fused_rollout    # dm_policy_sample + dm_rollout_store instead of ~20 small kernels per step
+        self.fused_policy = fused_policy      # dm_policy_forward: the whole policy side of a rollout step as one launch
         self._rollout_seed = 0x5EED0000 + seed
         self.buffer_dtype = buffer_dtype
         torch.manual_seed(seed)  # identical initial weights on every rank; no parameter broadcast needed
@@ -384,6 +442,84 @@ class PPO:
             C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         if rc != 0:
             raise RuntimeError("dm_rollout_store failed (%d)" % rc)
+
+    # ---- one-launch policy side (csrc/dm_policy.hip): per env step dm_policy_forward + dm_step, nothing else
+    def _fused_policy_ok(self):
+        return (self.fused_policy and self._fused_rollout_ok() and self.env is not None
+                and (hasattr(self.env, "engines") or hasattr(self.env, "engine"))
+                and FusedPolicyForward.supported(self.policy, self.device))
+
+    def _rollout_fused_policy(self):
+        """Rollout with two host calls per (sub-batch) step: ``dm_policy_forward`` reads the observations in place and
+        writes action / value / log-prob / observation copy straight into row t of the rollout buffer, ``dm_step``
+        writes reward and done flag into row t and the next observation over the one just consumed.  With
+        ``env.sub_batches`` > 1 every sub-batch runs on its own stream (the policy kernel of one fills the ramp-down of
+        the other's step kernel), host-driven or, with ``rollout_graph``, as one captured hipGraph of the T steps."""
+        env, T, N, dev = self.env, self.n_steps, self.n_envs, self.device
+        K = getattr(env, "sub_batches", 1)
+        engines = getattr(env, "engines", None) or [env.engine]
+        st = getattr(self, "_fp", None)
+        if st is None:
+            z = lambda *shape, dt=torch.float32: torch.zeros(*shape, device=dev, dtype=dt)
+            rb = dict(obs=z(T, N, self.obs_dim), act=z(T, N, 28), rew=z(T, N), done_u8=z(T, N, dt=torch.uint8), val=z(T, N),
+                      logp=z(T, N))
+            last = (env.reset_tensor() if self._last_obs is None else self._last_obs).clone()
+            self._rollout_scratch((N, 0))
+            st = self._fp = dict(rb=rb, last=last, fwd=FusedPolicyForward(self.policy, dev), act_env=z(N, 28),
+                                 streams=[torch.cuda.Stream(device=dev) for _ in range(K)] if K > 1 else None, graph=None)
+        rb, last, fwd = st["rb"], st["last"], st["fwd"]
+        if self._last_obs is not None and self._last_obs.data_ptr() != last.data_ptr():
+            last.copy_(self._last_obs)
+
+        def sub_step(k, t):
+            sl = env.sub_slices[k] if K > 1 else slice(0, N)
+            fwd(last[sl], self._rollout_seed + 7919 * k, self._rctr, t, self.act_lo, self.act_hi, rb["act"][t, sl], st["act_env"][sl],
+                rb["logp"][t, sl], rb["val"][t, sl], obs_copy=rb["obs"][t, sl])
+            engines[k].step(st["act_env"][sl], dict(obs=last[sl], rew=rb["rew"][t, sl], done=rb["done_u8"][t, sl]))
+
+        def whole():
+            cur = torch.cuda.current_stream(dev)
+            fwd.pack()
+            if K == 1:
+                for t in range(T):
+                    sub_step(0, t)
+            else:
+                for s_ in st["streams"]:
+                    s_.wait_stream(cur)
+                for t in range(T):
+                    for k in range(K):
+                        with torch.cuda.stream(st["streams"][k]):
+                            sub_step(k, t)
+                for s_ in st["streams"]:
+                    cur.wait_stream(s_)
+            self._rctr += T
+            rb["done"] = rb["done_u8"].float()
+            last_val = self.policy.predict_values(last)
+            rb["adv"], rb["ret"] = compute_gae(rb["rew"], rb["val"], rb["done"], last_val, self.gamma, self.gae_lambda)
+
+        with torch.no_grad():
+            if self.rollout_graph and K > 1:
+                if st["graph"] is None:
+                    side = torch.cuda.Stream(device=dev)        # warm-up off the default stream (real but uncounted env steps)
+                    side.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(side):
+                        fwd.pack()
+                        for k in range(K):
+                            sub_step(k, 0)
+                        self.policy.predict_values(last)
+                    torch.cuda.current_stream(dev).wait_stream(side)
+                    torch.cuda.synchronize(dev)
+                    st["graph"] = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(st["graph"]):
+                        whole()
+                st["graph"].replay()
+            else:
+                whole()
+        self._last_obs = last
+        self.num_timesteps += T * N
+        self.stats["mean_reward"] = float(rb["rew"].mean())
+        self.stats["done_rate"] = float(rb["done"].mean())
+        return {k: v for k, v in rb.items() if k != "done_u8"}
 
     def _rollout_graph_build(self):
         """Capture the whole T-step rollout as ONE hipGraph with one chain per env sub-batch (own stream each): the
@@ -472,6 +608,8 @@ class PPO:
         return rb
 
     def collect_rollouts(self):
+        if self._fused_policy_ok():
+            return self._rollout_fused_policy()
         if (not self.rollout_graph and self._fused_rollout_ok() and getattr(self.env, "sub_batches", 1) > 1
                 and hasattr(self.env, "step_sub")):
             return self._rollout_pipelined_eager()

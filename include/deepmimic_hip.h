@@ -202,6 +202,22 @@ int dm_rollout_store(int N, int D, int A, const float *last_obs, const float *ac
                      const float *rew, const unsigned char *done, const float *new_obs, float *b_obs, float *b_act, float *b_val,
                      float *b_logp, float *b_rew, float *b_done, float *last_obs_out, unsigned *counter, void *stream);
 
+/* The policy side of a rollout step as ONE launch (csrc/dm_policy.hip): both trunks of SB3's actor-critic MLP
+ * (obs -> H1 -> H2 -> A / 1, tanh; what [EXT] ActorCriticPolicy.forward computes for src/sb3_ppo.py:307-313), the
+ * sampling head of dm_policy_sample (same draws: seed, env, counter[0] + draw_offset, action index) and the
+ * rollout-buffer writes of the policy's outputs (pass row t of the [T, N, ...] buffers as act / logp / val / obs_copy).
+ * dm_policy_pack re-orders the three nn.Linear weights ([out, in] row-major) of ONE trunk into MFMA operand order
+ * (dm_policy_packed_floats floats, 16-byte aligned; A = 1 for the value trunk); call it again when the weights change.
+ * H1, H2 multiples of 32, A <= 32, 32 (H1 + 4 + max(D8 + 4, 132)) floats of LDS <= 160 KB.  mean_out and obs_copy may be
+ * NULL; deterministic != 0 returns act = mean (logp of the mean). */
+long long dm_policy_packed_floats(int D, int H1, int H2, int A);
+int dm_policy_pack(const float *W1, const float *W2, const float *W3, int D, int H1, int H2, int A, float *packed, void *stream);
+int dm_policy_forward(const float *obs, int N, int D, int H1, int H2, int A, const float *pi_packed, const float *pi_b1,
+                      const float *pi_b2, const float *pi_b3, const float *vf_packed, const float *vf_b1, const float *vf_b2,
+                      const float *vf_b3, const float *log_std, unsigned long long seed, const unsigned *counter,
+                      unsigned draw_offset, int deterministic, const float *lo, const float *hi, float *mean_out, float *act,
+                      float *act_env, float *logp, float *val, float *obs_copy, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

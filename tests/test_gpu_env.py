@@ -431,7 +431,7 @@ def test_sub_batched_vecenv_and_captured_rollout(model):
     assert obs.shape == (N, 67) and np.isfinite(obs).all()
     o2, r2, d2, infos = venv.step(np.zeros((N, 28), np.float32))
     assert o2.shape == (N, 67) and r2.shape == (N,) and (r2[:N // 2] != 0).any() and (r2[N // 2:] != 0).any()   # both halves stepped
-    ppo = PPO(venv, net_arch=(64, 32), n_steps=8, batch_size=512, n_epochs=1)
+    ppo = PPO(venv, net_arch=(64, 32), n_steps=8, batch_size=512, n_epochs=1, fused_policy=False)
     buf = ppo.collect_rollouts()
     assert buf["obs"].shape == (8, N, 67) and torch.isfinite(buf["obs"]).all() and torch.isfinite(buf["adv"]).all()
     assert torch.isfinite(buf["rew"]).all() and ppo.num_timesteps == 8 * N
@@ -456,7 +456,7 @@ def test_fused_rollout_kernels(model):
     from deepmimic_mujoco_amd.ppo import PPO
     N = 4096
     venv = HipDeepMimicVecEnv(N, motion="walk", seed=9)
-    ppo = PPO(venv, net_arch=(64, 32), n_steps=4, batch_size=1024, n_epochs=1)
+    ppo = PPO(venv, net_arch=(64, 32), n_steps=4, batch_size=1024, n_epochs=1, fused_policy=False)
     with torch.no_grad():
         ppo.policy.log_std.copy_(torch.linspace(-1.0, 0.5, 28))
         obs = venv.reset_tensor().clone()
@@ -484,3 +484,106 @@ def test_fused_rollout_kernels(model):
         cont = buf["done"][0] == 0
         assert cont.float().mean() > 0.5 and torch.isfinite(buf["rew"]).all()
     venv.close()
+
+
+@pytest.mark.parametrize("arch,N,D", [((256, 128), 4096, 67), ((64, 32), 1000, 72), ((1024, 512), 2048, 67), ((96, 160), 33, 67)])
+def test_policy_forward_kernel_matches_torch(arch, N, D):
+    """dm_policy_forward (one launch: both MLP trunks on fp32 MFMA, sampling head, buffer writes) against the PyTorch
+    fp32 modules: mean / value within fp32 GEMM reordering error (atol 2e-5 on O(1) outputs), the sampled action equal
+    to dm_policy_sample's for the same (seed, env, counter, index), logp of the policy's own formula, clamped env
+    action, verbatim observation copy; ragged batch (N not a multiple of 32), D = 72 (DPCombinedEnv), [1024,512]."""
+    import ctypes as C
+    import torch
+    from deepmimic_mujoco_amd import _lib
+    from deepmimic_mujoco_amd.ppo import MlpPolicy, FusedPolicyForward
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    pol = MlpPolicy(obs_dim=D, net_arch=arch).to(dev)
+    with torch.no_grad():
+        pol.log_std.copy_(torch.linspace(-1.0, 0.5, 28))
+        pol.action_net.weight.mul_(30.0)                  # O(1) means, so that the clamp at +-2 is exercised
+        for m in list(pol.pi) + list(pol.vf) + [pol.action_net, pol.value_net]:
+            if hasattr(m, "bias") and m.bias is not None:
+                m.bias.normal_(0, 0.1)
+    assert FusedPolicyForward.supported(pol, dev)
+    fwd = FusedPolicyForward(pol, dev)
+    fwd.pack()
+    obs = torch.randn(N, D, device=dev) * 0.7
+    z = lambda *s: torch.full(s, float("nan"), device=dev)
+    mean, act, act_env, logp, val, ocopy = z(N, 28), z(N, 28), z(N, 28), z(N), z(N), z(N, D)
+    ctr = torch.tensor([5], dtype=torch.int32, device=dev)
+    lo, hi = torch.full((28,), -2.0, device=dev), torch.full((28,), 2.0, device=dev)
+    fwd(obs, 1234, ctr, 3, lo, hi, act, act_env, logp, val, obs_copy=ocopy, mean_out=mean)
+    with torch.no_grad():
+        mean_t = pol.action_net(pol.pi(obs))
+        val_t = pol.value_net(pol.vf(obs)).squeeze(-1)
+    assert torch.isfinite(mean).all() and torch.isfinite(val).all()
+    assert float((mean - mean_t).abs().max()) < 2e-5 * max(1.0, float(mean_t.abs().max()))
+    assert float((val - val_t).abs().max()) < 2e-5 * max(1.0, float(val_t.abs().max()))
+    assert torch.equal(ocopy, obs)
+    assert torch.equal(act_env, torch.clamp(act, lo, hi)) and float((act_env != act).float().mean()) > 0.001
+    with torch.no_grad():
+        assert torch.allclose(logp, pol._logp(act, mean), atol=3e-4)
+    # same draws as the two-kernel path: counter[0] + draw_offset = 8
+    a2, e2, l2 = z(N, 28), z(N, 28), z(N)
+    ctr8 = torch.tensor([8], dtype=torch.int32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rc = _lib.load_library().dm_policy_sample(p(mean), p(pol.log_std), N, 28, C.c_uint64(1234), p(ctr8), p(lo), p(hi), p(a2), p(e2), p(l2),
+                                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    assert rc == 0
+    assert torch.allclose(a2, act, atol=1e-6) and torch.allclose(l2, logp, atol=3e-4)
+    # deterministic head: act = mean
+    fwd(obs, 1234, ctr, 0, lo, hi, act, act_env, logp, val, deterministic=True)
+    assert torch.allclose(act, mean_t, atol=2e-5 * max(1.0, float(mean_t.abs().max())))
+    # weights change -> pack() again
+    with torch.no_grad():
+        pol.pi[0].weight.mul_(0.5)
+    fwd.pack()
+    fwd(obs, 1234, ctr, 0, lo, hi, act, act_env, logp, val, mean_out=mean)
+    with torch.no_grad():
+        assert float((mean - pol.action_net(pol.pi(obs))).abs().max()) < 2e-5 * max(1.0, float(mean_t.abs().max()))
+
+
+@pytest.mark.parametrize("sub_batches,graph", [(1, False), (2, False), (2, True)])
+def test_one_launch_policy_rollout(model, sub_batches, graph):
+    """PPO.collect_rollouts on the dm_policy_forward path (two host calls per sub-batch step): the buffers are what the
+    unfused loop would store — obs the policy saw, its value / logp for the stored action, the env's reward / done, and
+    obs[t + 1] equal to the env's output for (state_t, clamp(act_t)) — checked by replaying the stored actions on a second
+    env with the same seed; then one PPO update on them."""
+    import torch
+    from deepmimic_mujoco_amd.deepmimic_env import HipDeepMimicVecEnv
+    from deepmimic_mujoco_amd.ppo import PPO
+    N, T = 512, 6
+    venv = HipDeepMimicVecEnv(N, motion="walk", sub_batches=sub_batches, seed=11)
+    twin = HipDeepMimicVecEnv(N, motion="walk", sub_batches=sub_batches, seed=11)
+    ppo = PPO(venv, net_arch=(64, 32), n_steps=T, batch_size=1024, n_epochs=1, rollout_graph=graph)
+    assert ppo._fused_policy_ok()
+    buf = ppo.collect_rollouts()
+    assert set(("obs", "act", "rew", "done", "val", "logp", "adv", "ret")) <= set(buf)
+    with torch.no_grad():
+        o = twin.reset_tensor().clone()
+        skip = 1 if graph else 0                     # graph mode: one uncounted warm-up step of every sub-batch precedes the capture
+        if skip == 0:
+            assert torch.equal(buf["obs"][0], o)
+        for t in range(T):
+            m = ppo.policy.action_net(ppo.policy.pi(buf["obs"][t]))
+            assert torch.allclose(buf["logp"][t], ppo.policy._logp(buf["act"][t], m), atol=3e-4)
+            assert torch.allclose(buf["val"][t], ppo.policy.predict_values(buf["obs"][t]), atol=2e-5)
+        if skip == 0:
+            for t in range(T):
+                out = twin.step_tensor(torch.clamp(buf["act"][t], ppo.act_lo, ppo.act_hi))
+                assert torch.equal(out["rew"], buf["rew"][t]) and torch.equal(out["done"].float(), buf["done"][t])
+                if t + 1 < T:
+                    assert torch.equal(out["obs"], buf["obs"][t + 1])
+            assert torch.equal(out["obs"], ppo._last_obs)
+        e0 = (buf["act"][0] - ppo.policy.action_net(ppo.policy.pi(buf["obs"][0]))) / ppo.policy.log_std.exp()
+        e1 = (buf["act"][1] - ppo.policy.action_net(ppo.policy.pi(buf["obs"][1]))) / ppo.policy.log_std.exp()
+        assert abs(float(e0.mean())) < 0.03 and abs(float(e0.std()) - 1) < 0.03 and abs(float((e0 * e1).mean())) < 0.03
+    first = buf["obs"].clone()
+    ppo.train(buf)
+    assert np.isfinite(ppo.stats["loss"])
+    buf = ppo.collect_rollouts()                     # second rollout: continues the episodes with the updated (re-packed) weights
+    assert not torch.equal(first, buf["obs"]) and ppo.num_timesteps == 2 * T * N
+    with torch.no_grad():
+        assert torch.allclose(buf["val"][2], ppo.policy.predict_values(buf["obs"][2]), atol=2e-5)
+    venv.close(); twin.close()
