@@ -26,7 +26,7 @@ EXPORTS = ["dm_default_config", "dm_create", "dm_destroy", "dm_last_error", "dm_
            "dm_set_state", "dm_get_state", "dm_get_counters", "dm_set_counters", "dm_set_debug",
            "dm_fill_random_actions", "dm_last_step_ms", "dm_enable_timing", "dm_get_work",
            "dm_set_clip_flags", "dm_obs_dim", "dm_terms_dim", "dm_get_env_clips", "dm_mean_step_ms", "dm_ppo_loss", "dm_forward", "dm_linear_wgrad", "dm_ppo_gather", "dm_adam_clip_step", "dm_policy_sample",
-           "dm_rollout_store", "dm_policy_pack", "dm_policy_forward", "dm_policy_packed_floats"]
+           "dm_rollout_store", "dm_policy_pack", "dm_policy_forward", "dm_policy_packed_floats", "dm_ppo_mlp_grad", "dm_ppo_mlp_workspace_floats"]
 
 
 class DmConfig(C.Structure):
@@ -37,6 +37,17 @@ class DmConfig(C.Structure):
                 ("seed", C.c_uint64), ("auto_reset", C.c_int32), ("device", C.c_int32),
                 ("lpt_schedule", C.c_int32), ("task", C.c_int32),
                 ("amnesty_steps", C.c_int32), ("to_getup_len", C.c_int32)]
+
+
+class DmPpoMlpStep(C.Structure):
+    """include/deepmimic_hip.h: DmPpoMlpStep"""
+    _fields_ = [("B", C.c_int32), ("D", C.c_int32), ("H1", C.c_int32), ("H2", C.c_int32), ("A", C.c_int32),
+                ("normalize_advantage", C.c_int32), ("clip_range", C.c_float), ("vf_coef", C.c_float), ("ent_coef", C.c_float),
+                ("reserved", C.c_int32),
+                ("obs", C.c_void_p), ("act", C.c_void_p), ("adv", C.c_void_p), ("ret", C.c_void_p), ("old_logp", C.c_void_p),
+                ("log_std", C.c_void_p),
+                ("W", (C.c_void_p * 3) * 2), ("b", (C.c_void_p * 3) * 2), ("gW", (C.c_void_p * 3) * 2), ("gb", (C.c_void_p * 3) * 2),
+                ("g_log_std", C.c_void_p), ("out8", C.c_void_p), ("workspace", C.c_void_p), ("workspace_floats", C.c_longlong)]
 
 
 _LIB = None
@@ -78,6 +89,8 @@ def load_library():
     L.dm_policy_sample.argtypes = [vp, vp, i32, i32, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]
     L.dm_rollout_store.argtypes = [i32, i32, i32] + [vp] * 16
     L.dm_policy_packed_floats.argtypes = [i32] * 4
+    L.dm_ppo_mlp_workspace_floats.argtypes = [i32] * 5
+    L.dm_ppo_mlp_grad.argtypes = [C.POINTER(DmPpoMlpStep), vp]
     L.dm_policy_pack.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
     L.dm_policy_forward.argtypes = [vp] + [i32] * 5 + [vp] * 9 + [C.c_uint64, vp, C.c_uint32, i32] + [vp] * 9
     L.dm_adam_clip_step.argtypes = [vp, vp, vp, vp, i32] + [C.c_float] * 5 + [vp, vp]
@@ -94,7 +107,7 @@ def load_library():
     L.dm_mean_step_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     for name in EXPORTS:
         if name not in ("dm_default_config", "dm_last_error"):
-            getattr(L, name).restype = C.c_longlong if name == "dm_policy_packed_floats" else C.c_int
+            getattr(L, name).restype = C.c_longlong if name in ("dm_policy_packed_floats", "dm_ppo_mlp_workspace_floats") else C.c_int
     _LIB = L
     return L
 

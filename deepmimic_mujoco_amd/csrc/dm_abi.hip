@@ -15,6 +15,7 @@
 #include "dm_kernels.hip"
 #include "dm_ppo.hip"
 #include "dm_policy.hip"
+#include "dm_ppo_mlp.hip"
 
 struct DmEngine {
   DmConfig cfg;

@@ -216,16 +216,19 @@ __global__ void __launch_bounds__(POL_THREADS) pol_forward_kernel(PolArgs a) {
   if (q == 0 && ok) a.logp[e] = lp;
 }
 
-// W [O x K] row-major (nn.Linear) -> P[tile][k-block][lane] float4 = W[32 tile + (lane & 31)][8 kb + 4 (lane >> 5) + 0..3]
-__global__ void pol_pack_kernel(const float *W, int O, int K, int tiles, int KB, float4 *P) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// W (element (o, k) at W[o so + k sk]; nn.Linear [O x K] row-major is so = K, sk = 1, its transpose so = 1, sk = O) ->
+// P[tile][k-block][lane] float4 = W(32 tile + (lane & 31), 8 kb + 4 (lane >> 5) + 0..3), zero outside O x K
+__device__ __forceinline__ void pol_pack_one(const float *W, int O, int K, int so, int sk, int tiles, int KB, float4 *P, int i) {
   if (i >= tiles * KB * 64) return;
   const int lane = i & 63, kb = (i >> 6) % KB, to = (i >> 6) / KB;
   const int o = to * 32 + (lane & 31), k = kb * 8 + 4 * (lane >> 5);
   float v[4];
 #pragma unroll
-  for (int c = 0; c < 4; c++) v[c] = (o < O && k + c < K) ? W[(size_t)o * K + k + c] : 0.f;
+  for (int c = 0; c < 4; c++) v[c] = (o < O && k + c < K) ? W[(size_t)o * so + (size_t)(k + c) * sk] : 0.f;
   P[i] = make_float4(v[0], v[1], v[2], v[3]);
+}
+__global__ void pol_pack_kernel(const float *W, int O, int K, int tiles, int KB, float4 *P) {
+  pol_pack_one(W, O, K, K, 1, tiles, KB, P, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 inline int pol_dp(int D) { return (D + 7) & ~7; }

@@ -38,7 +38,8 @@ __device__ __forceinline__ float ppo_block_sum(float v, float *red) {
 }
 
 // stats[0] = mean(adv), stats[1] = 1 / (std_unbiased(adv) + 1e-8); also clears the accumulators of the main kernel
-__global__ void ppo_prepare_kernel(const float *adv, int B, int normalize, float *stats, float *out8, float *grad_log_std, int A) {
+__device__ __forceinline__ void ppo_prepare_body(const float *adv, int B, int normalize, float *stats, float *out8, float *grad_log_std,
+                                                 int A) {
   __shared__ float red[16];
   float s = 0;
   for (int i = threadIdx.x; i < B; i += blockDim.x) s += adv[i];
@@ -55,7 +56,10 @@ __global__ void ppo_prepare_kernel(const float *adv, int B, int normalize, float
     else { stats[0] = 0.f; stats[1] = 1.f; }
   }
   if (threadIdx.x < 8) out8[threadIdx.x] = 0.f;
-  if ((int)threadIdx.x < A) grad_log_std[threadIdx.x] = 0.f;
+  if (grad_log_std && (int)threadIdx.x < A) grad_log_std[threadIdx.x] = 0.f;
+}
+__global__ void ppo_prepare_kernel(const float *adv, int B, int normalize, float *stats, float *out8, float *grad_log_std, int A) {
+  ppo_prepare_body(adv, B, normalize, stats, out8, grad_log_std, A);
 }
 
 __global__ void ppo_loss_kernel(const float *mean, const float *log_std, const float *value, const float *act,
@@ -178,10 +182,10 @@ namespace {
 
 typedef float ppo_f16v __attribute__((ext_vector_type(16)));
 
-__global__ void __launch_bounds__(64) ppo_wgrad_kernel(const float *dY, const float *X, float *dW, float *db, int B, int O, int I,
-                                                       int kchunk) {
+__device__ __forceinline__ void ppo_wgrad_body(const float *dY, const float *X, float *dW, float *db, int B, int O, int I, int kchunk,
+                                               int bx, int by, int bz) {
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
-  const int i0 = blockIdx.x * 32, o0 = blockIdx.y * 32, b0 = blockIdx.z * kchunk;
+  const int i0 = bx * 32, o0 = by * 32, b0 = bz * kchunk;
   const bool oa = (o0 + r) < O, ia = (i0 + r) < I;
   const float *pa = dY + (size_t)(b0 + h) * O + (o0 + r);
   const float *px = X + (size_t)(b0 + h) * I + (i0 + r);
@@ -208,10 +212,15 @@ __global__ void __launch_bounds__(64) ppo_wgrad_kernel(const float *dY, const fl
     const int row = (j >> 2) * 8 + h * 4 + (j & 3);
     if ((o0 + row) < O && ia) atomicAdd(&dW[(size_t)(o0 + row) * I + i0 + r], acc[j]);
   }
-  if (blockIdx.x == 0) {
+  if (bx == 0) {
     const float v = dbacc + __shfl_xor(dbacc, 32);
     if (h == 0 && oa) atomicAdd(&db[o0 + r], v);
   }
+}
+
+__global__ void __launch_bounds__(64) ppo_wgrad_kernel(const float *dY, const float *X, float *dW, float *db, int B, int O, int I,
+                                                       int kchunk) {
+  ppo_wgrad_body(dY, X, dW, db, B, O, I, kchunk, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 }  // namespace

@@ -1,0 +1,374 @@
+// One PPO minibatch gradient of the two-hidden-layer actor-critic MLP in THREE launches (gfx950).
+//
+// Reference: src/sb3_ppo.py:254-271,307-312 -> [EXT] SB3 PPO.train on MlpPolicy(net_arch=[256,128]): per minibatch
+// evaluate_actions (both trunks), the clipped-surrogate / value / entropy loss, backward through both trunks.  With
+// PyTorch this is ~40 graph nodes of ~5 us (library GEMMs of 4096 x 256 x 128, elementwise tanh backward, the loss
+// kernels): the optimizer step of the reference's net is launch-bound at 0.22 ms.  Here:
+//   1. mlp_pack_kernel   weights -> MFMA operand order (forward and transposed), advantage statistics      (1 launch)
+//   2. mlp_fwdbwd_kernel a workgroup of four waves carries 32 minibatch rows of one trunk through the forward, the
+//                        loss head (same arithmetic as ppo_loss_kernel) and the input-gradient chain; activations and
+//                        pre-activation gradients stay in LDS and are written once to HBM for step 3           (1 launch)
+//   3. mlp_wgrad_kernel  dW = dZ^T X, db = sum dZ for all six layers: one wave per 32 x 32 tile and batch slice
+//                        (split-K, float atomics), plus the loss scalar / entropy-gradient epilogue            (1 launch)
+// All products are v_mfma_f32_32x32x2f32 (fp32 in, fp32 accumulate).  Gradients are ACCUMULATED into caller-owned
+// buffers (zeroed by the caller on the same stream: the optimizer's flat gradient arena, one memset).
+// Included by dm_abi.hip after dm_ppo.hip and dm_policy.hip (uses their device helpers).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/deepmimic_hip.h"
+
+namespace {
+
+struct MlpPackJob { const float *W; float4 *P; int O, K, so, sk, tiles, KB, first; };
+struct MlpPackArgs {
+  MlpPackJob j[10];
+  int njobs, nblocks;               // block nblocks (the last one) computes the advantage statistics
+  const float *adv; int B, normalize; float *stats, *out8;
+};
+
+__global__ void __launch_bounds__(256) mlp_pack_kernel(MlpPackArgs a) {
+  const int blk = blockIdx.x;
+  if (blk == a.nblocks) { ppo_prepare_body(a.adv, a.B, a.normalize, a.stats, a.out8, nullptr, 0); return; }
+  int q = 0;
+  for (int i = 1; i < a.njobs; i++) if (blk >= a.j[i].first) q = i;
+  const MlpPackJob &J = a.j[q];
+  pol_pack_one(J.W, J.O, J.K, J.so, J.sk, J.tiles, J.KB, J.P, (blk - J.first) * 256 + (int)threadIdx.x);
+}
+
+struct MlpTrainArgs {
+  int B, D, Dp, H1, H2, A;
+  const float *obs, *act, *adv, *ret, *old_logp, *log_std;
+  const float4 *pkF[2], *pkW2T[2], *pkW3T[2];
+  const float *b1[2], *b2[2], *b3[2];
+  float *h1g[2], *h2g[2], *dz1g[2], *dz2g[2], *d3g[2];
+  const float *stats;
+  float *out8, *g_log_std;
+  float clip, vf_coef;
+};
+
+__global__ void __launch_bounds__(POL_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a) {
+  extern __shared__ __align__(16) float mlp_lds[];
+  const int trunk = blockIdx.y, b0 = blockIdx.x * POL_R;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int sx = a.Dp + POL_PAD, s1 = a.H1 + POL_PAD, s2 = a.H2 + POL_PAD, s3 = 32 + POL_PAD;
+  float *xs = mlp_lds;
+  float *h1 = xs + POL_R * sx;
+  float *h2 = h1 + POL_R * s1;
+  float *dz2 = h2 + POL_R * s2;
+  float *d3 = dz2 + POL_R * s2;
+  float *red = d3 + POL_R * s3;           // 4 x 32 x 32 layer-3 partial sums
+  float *accs = red + 4096;               // [0..3] pg, vl, kl, clip fraction; [4..35] d loss / d log_std partials
+  const int KB1 = a.Dp >> 3, T1 = a.H1 >> 5, KB2 = a.H1 >> 3, T2 = a.H2 >> 5, KB3 = a.H2 >> 3;
+  const float4 *P1 = a.pkF[trunk];
+  const float4 *P2 = P1 + (size_t)T1 * KB1 * 64;
+  const float4 *P3 = P2 + (size_t)T2 * KB2 * 64;
+  const int r = lane & 31, h = lane >> 5;
+
+  for (int i = tid; i < POL_R * a.D; i += POL_THREADS) {
+    const int row = i / a.D, c = i - row * a.D;
+    xs[row * sx + c] = a.obs[(size_t)b0 * a.D + i];
+  }
+  for (int i = tid; i < POL_R * (a.Dp - a.D); i += POL_THREADS) {
+    const int row = i / (a.Dp - a.D), c = a.D + i - row * (a.Dp - a.D);
+    xs[row * sx + c] = 0.f;
+  }
+  if (tid < 36) accs[tid] = 0.f;
+  __syncthreads();
+
+  // ---- forward: layer 1, layer 2 (activations to LDS and to HBM for the weight gradients), layer 3 split-K
+  for (int to = wave; to < T1; to += 4) {
+    pol_f16v acc;
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc[j] = 0.f;
+    pol_tile<3>(xs, sx, P1 + (size_t)to * KB1 * 64, lane, 0, KB1, acc);
+    const float b = a.b1[trunk][to * 32 + r];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const int row = (j >> 2) * 8 + h * 4 + (j & 3);
+      const float v = tanhf(acc[j] + b);
+      h1[row * s1 + to * 32 + r] = v;
+      a.h1g[trunk][(size_t)(b0 + row) * a.H1 + to * 32 + r] = v;
+    }
+  }
+  __syncthreads();
+  for (int to = wave; to < T2; to += 4) {
+    pol_f16v acc;
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc[j] = 0.f;
+    pol_tile<8>(h1, s1, P2 + (size_t)to * KB2 * 64, lane, 0, KB2, acc);
+    const float b = a.b2[trunk][to * 32 + r];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const int row = (j >> 2) * 8 + h * 4 + (j & 3);
+      const float v = tanhf(acc[j] + b);
+      h2[row * s2 + to * 32 + r] = v;
+      a.h2g[trunk][(size_t)(b0 + row) * a.H2 + to * 32 + r] = v;
+    }
+  }
+  __syncthreads();
+  {
+    pol_f16v acc3;
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc3[j] = 0.f;
+    const int per = KB3 >> 2;                       // KB3 = H2 / 8 is a multiple of 4
+    pol_tile<4>(h2, s2, P3, lane, wave * per, (wave + 1) * per, acc3);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const int row = (j >> 2) * 8 + h * 4 + (j & 3);
+      red[wave * 1024 + row * 32 + r] = acc3[j];
+    }
+  }
+  __syncthreads();
+
+  // ---- loss head: eight threads per row (same formulas as ppo_loss_kernel)
+  {
+    const int row = tid >> 3, q = tid & 7, b = b0 + row;
+    const float invB = 1.0f / (float)a.B;
+    if (trunk == 0) {
+      float dd[4], iv[4], z2[4];
+      float lp = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const int c = q + 8 * s;
+        dd[s] = 0.f; iv[s] = 0.f; z2[s] = 0.f;
+        if (c < a.A) {
+          const float m = red[row * 32 + c] + red[1024 + row * 32 + c] + red[2048 + row * 32 + c] + red[3072 + row * 32 + c] + a.b3[0][c];
+          const float ls = a.log_std[c];
+          dd[s] = a.act[(size_t)b * a.A + c] - m;
+          iv[s] = expf(-2.f * ls);
+          z2[s] = dd[s] * dd[s] * iv[s];
+          lp += -0.5f * z2[s] - ls - 0.9189385332046727f;
+        }
+      }
+      lp += __shfl_xor(lp, 1);
+      lp += __shfl_xor(lp, 2);
+      lp += __shfl_xor(lp, 4);
+      const float a_n = (a.adv[b] - a.stats[0]) * a.stats[1];
+      const float lr = lp - a.old_logp[b];
+      const float ratio = expf(lr);
+      const float rc = fminf(fmaxf(ratio, 1.f - a.clip), 1.f + a.clip);
+      const float p1 = a_n * ratio, p2 = a_n * rc;
+      const bool inside = (ratio >= 1.f - a.clip) && (ratio <= 1.f + a.clip);
+      const float dr = (inside || p1 < p2) ? a_n : 0.f;
+      const float dlogp = -invB * dr * ratio;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const int c = q + 8 * s;
+        const float g = dlogp * dd[s] * iv[s];               // 0 for c >= A
+        d3[row * s3 + c] = g;
+        if (c < a.A) {
+          a.d3g[0][(size_t)b * a.A + c] = g;
+          atomicAdd(&accs[4 + c], dlogp * (z2[s] - 1.f));
+        }
+      }
+      if (q == 0) {
+        atomicAdd(&accs[0], -fminf(p1, p2));
+        atomicAdd(&accs[2], (ratio - 1.f) - lr);
+        atomicAdd(&accs[3], (fabsf(ratio - 1.f) > a.clip) ? 1.f : 0.f);
+      }
+    } else {
+      const float v = red[row * 32] + red[1024 + row * 32] + red[2048 + row * 32] + red[3072 + row * 32] + a.b3[1][0];
+      const float dv = v - a.ret[b];
+      const float g = a.vf_coef * 2.f * invB * dv;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const int c = q + 8 * s;
+        d3[row * s3 + c] = (c == 0) ? g : 0.f;
+      }
+      if (q == 0) {
+        a.d3g[1][b] = g;
+        atomicAdd(&accs[1], dv * dv);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const float invB = 1.0f / (float)a.B;
+    if (trunk == 0) {
+      if (tid == 0) atomicAdd(&a.out8[1], accs[0] * invB);
+      else if (tid == 2) atomicAdd(&a.out8[4], accs[2] * invB);
+      else if (tid == 3) atomicAdd(&a.out8[5], accs[3] * invB);
+      else if (tid >= 4 && tid < 4 + a.A) atomicAdd(&a.g_log_std[tid - 4], accs[tid]);
+    } else if (tid == 1) {
+      atomicAdd(&a.out8[2], accs[1] * invB);
+    }
+  }
+
+  // ---- backward: dZ2 = (d3 W3) (1 - h2^2), dZ1 = (dZ2 W2) (1 - h1^2)
+  for (int to = wave; to < T2; to += 4) {
+    pol_f16v acc;
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc[j] = 0.f;
+    pol_tile<4>(d3, s3, a.pkW3T[trunk] + (size_t)to * 4 * 64, lane, 0, 4, acc);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const int row = (j >> 2) * 8 + h * 4 + (j & 3);
+      const float hv = h2[row * s2 + to * 32 + r];
+      const float g = acc[j] * (1.f - hv * hv);
+      dz2[row * s2 + to * 32 + r] = g;
+      a.dz2g[trunk][(size_t)(b0 + row) * a.H2 + to * 32 + r] = g;
+    }
+  }
+  __syncthreads();
+  for (int to = wave; to < T1; to += 4) {
+    pol_f16v acc;
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc[j] = 0.f;
+    pol_tile<8>(dz2, s2, a.pkW2T[trunk] + (size_t)to * KB3 * 64, lane, 0, KB3, acc);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const int row = (j >> 2) * 8 + h * 4 + (j & 3);
+      const float hv = h1[row * s1 + to * 32 + r];
+      a.dz1g[trunk][(size_t)(b0 + row) * a.H1 + to * 32 + r] = acc[j] * (1.f - hv * hv);
+    }
+  }
+}
+
+struct MlpWgradJob { const float *dY, *X; float *dW, *db; int O, I, ti, to, kchunk, first; };
+struct MlpWgradArgs {
+  MlpWgradJob j[6];
+  int B, nblocks;                   // block nblocks (the last one) finishes the loss scalar and the entropy gradient
+  const float *log_std, *stats; float *g_log_std, *out8; int A; float vf_coef, ent_coef;
+};
+
+__global__ void __launch_bounds__(64) mlp_wgrad_kernel(MlpWgradArgs a) {
+  const int blk = blockIdx.x;
+  if (blk == a.nblocks) {
+    if (threadIdx.x == 0) {
+      float ent = 0;
+      for (int j = 0; j < a.A; j++) ent += 0.5f + 0.5f * 1.8378770664093453f + a.log_std[j];
+      a.out8[3] = ent;
+      a.out8[0] = a.out8[1] + a.vf_coef * a.out8[2] - a.ent_coef * ent;
+      a.out8[6] = a.stats[0];
+      a.out8[7] = a.stats[1];
+    }
+    if ((int)threadIdx.x < a.A && a.ent_coef != 0.f) atomicAdd(&a.g_log_std[threadIdx.x], -a.ent_coef);
+    return;
+  }
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < 6; i++) if (blk >= a.j[i].first) q = i;
+  const MlpWgradJob &J = a.j[q];
+  const int local = blk - J.first;
+  const int bx = local % J.ti, rest = local / J.ti;
+  ppo_wgrad_body(J.dY, J.X, J.dW, J.db, a.B, J.O, J.I, J.kchunk, bx, rest % J.to, rest / J.to);
+}
+
+inline bool mlp_dims_ok(int B, int D, int H1, int H2, int A) {
+  return B >= 64 && (B % 64) == 0 && pol_dims_ok(D, H1, H2, A) && H1 <= 256 && H2 <= 256;
+}
+inline size_t mlp_lds_bytes(int D, int H1, int H2) {
+  return (size_t)(POL_R * (pol_dp(D) + POL_PAD + H1 + POL_PAD + 2 * (H2 + POL_PAD) + 32 + POL_PAD) + 4096 + 64) * sizeof(float);
+}
+// per-trunk workspace (floats): forward pack | W2^T pack | W3^T pack | h1 | h2 | dz1 | dz2 | d3
+struct MlpWsLayout { size_t pkF, pkW2T, pkW3T, h1, h2, dz1, dz2, d3, per_trunk, total; };
+inline MlpWsLayout mlp_layout(int B, int D, int H1, int H2, int A) {
+  MlpWsLayout L;
+  size_t o = 0;
+  L.pkF = o;   o += 256 * ((size_t)(H1 / 32) * (pol_dp(D) / 8) + (size_t)(H2 / 32) * (H1 / 8) + (size_t)(H2 / 8));
+  L.pkW2T = o; o += 256 * (size_t)(H1 / 32) * (H2 / 8);
+  L.pkW3T = o; o += 256 * (size_t)(H2 / 32) * 4;
+  L.h1 = o;    o += (size_t)B * H1;
+  L.h2 = o;    o += (size_t)B * H2;
+  L.dz1 = o;   o += (size_t)B * H1;
+  L.dz2 = o;   o += (size_t)B * H2;
+  L.d3 = o;    o += (size_t)B * 32;
+  L.per_trunk = (o + 3) & ~(size_t)3;
+  L.total = 2 * L.per_trunk + 8;     // + advantage statistics
+  return L;
+}
+
+}  // namespace
+
+extern "C" long long dm_ppo_mlp_workspace_floats(int B, int D, int H1, int H2, int A) {
+  if (!mlp_dims_ok(B, D, H1, H2, A)) return -22;
+  if (mlp_lds_bytes(D, H1, H2) > 160 * 1024) return -22;
+  return (long long)mlp_layout(B, D, H1, H2, A).total;
+}
+
+extern "C" int dm_ppo_mlp_grad(const DmPpoMlpStep *s, void *stream) {
+  if (!s) return -22;
+  const int B = s->B, D = s->D, H1 = s->H1, H2 = s->H2, A = s->A;
+  if (!mlp_dims_ok(B, D, H1, H2, A)) return -22;
+  if (!s->obs || !s->act || !s->adv || !s->ret || !s->old_logp || !s->log_std || !s->g_log_std || !s->out8 || !s->workspace) return -22;
+  for (int t = 0; t < 2; t++)
+    for (int l = 0; l < 3; l++)
+      if (!s->W[t][l] || !s->b[t][l] || !s->gW[t][l] || !s->gb[t][l]) return -22;
+  if (reinterpret_cast<uintptr_t>(s->workspace) & 15) return -22;
+  const MlpWsLayout L = mlp_layout(B, D, H1, H2, A);
+  if (s->workspace_floats < (long long)L.total) return -22;
+  const size_t lds = mlp_lds_bytes(D, H1, H2);
+  if (lds > 160 * 1024) return -22;
+  static size_t lds_allowed = 64 * 1024;
+  if (lds > lds_allowed) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_fwdbwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
+      return -5;
+    lds_allowed = lds;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float *stats = s->workspace + 2 * L.per_trunk;
+  const int Dp = pol_dp(D), T1 = H1 / 32, KB1 = Dp / 8, T2 = H2 / 32, KB2 = H1 / 8, KB3 = H2 / 8;
+
+  // ---- 1. pack + advantage statistics
+  MlpPackArgs pa;
+  int nb = 0, nj = 0;
+  auto add_pack = [&](const float *W, float *P, int O, int K, int so, int sk, int tiles, int KB) {
+    MlpPackJob &J = pa.j[nj++];
+    J.W = W; J.P = reinterpret_cast<float4 *>(P); J.O = O; J.K = K; J.so = so; J.sk = sk; J.tiles = tiles; J.KB = KB; J.first = nb;
+    nb += (tiles * KB * 64 + 255) / 256;
+  };
+  for (int t = 0; t < 2; t++) {
+    float *ws = s->workspace + t * L.per_trunk;
+    const int Aout = t == 0 ? A : 1;
+    float *P1 = ws + L.pkF, *P2 = P1 + (size_t)T1 * KB1 * 256, *P3 = P2 + (size_t)T2 * KB2 * 256;
+    add_pack(s->W[t][0], P1, H1, D, D, 1, T1, KB1);
+    add_pack(s->W[t][1], P2, H2, H1, H1, 1, T2, KB2);
+    add_pack(s->W[t][2], P3, Aout, H2, H2, 1, 1, KB3);
+    add_pack(s->W[t][1], ws + L.pkW2T, H1, H2, 1, H1, T1, KB3);      // W2^T: (i, o) -> W2[o][i]
+    add_pack(s->W[t][2], ws + L.pkW3T, H2, Aout, 1, H2, T2, 4);       // W3^T: (i, c) -> W3[c][i], c padded to 32
+  }
+  pa.njobs = nj; pa.nblocks = nb;
+  pa.adv = s->adv; pa.B = B; pa.normalize = (s->normalize_advantage && B > 1) ? 1 : 0; pa.stats = stats; pa.out8 = s->out8;
+  hipLaunchKernelGGL(mlp_pack_kernel, dim3(nb + 1), dim3(256), 0, st, pa);
+
+  // ---- 2. forward + loss head + input gradients
+  MlpTrainArgs ta;
+  ta.B = B; ta.D = D; ta.Dp = Dp; ta.H1 = H1; ta.H2 = H2; ta.A = A;
+  ta.obs = s->obs; ta.act = s->act; ta.adv = s->adv; ta.ret = s->ret; ta.old_logp = s->old_logp; ta.log_std = s->log_std;
+  for (int t = 0; t < 2; t++) {
+    float *ws = s->workspace + t * L.per_trunk;
+    ta.pkF[t] = reinterpret_cast<const float4 *>(ws + L.pkF);
+    ta.pkW2T[t] = reinterpret_cast<const float4 *>(ws + L.pkW2T);
+    ta.pkW3T[t] = reinterpret_cast<const float4 *>(ws + L.pkW3T);
+    ta.b1[t] = s->b[t][0]; ta.b2[t] = s->b[t][1]; ta.b3[t] = s->b[t][2];
+    ta.h1g[t] = ws + L.h1; ta.h2g[t] = ws + L.h2; ta.dz1g[t] = ws + L.dz1; ta.dz2g[t] = ws + L.dz2; ta.d3g[t] = ws + L.d3;
+  }
+  ta.stats = stats; ta.out8 = s->out8; ta.g_log_std = s->g_log_std; ta.clip = s->clip_range; ta.vf_coef = s->vf_coef;
+  hipLaunchKernelGGL(mlp_fwdbwd_kernel, dim3(B / POL_R, 2), dim3(POL_THREADS), lds, st, ta);
+
+  // ---- 3. weight / bias gradients of the six layers + loss epilogue
+  MlpWgradArgs wa;
+  int nw = 0, nq = 0;
+  auto add_wg = [&](const float *dY, const float *X, float *dW, float *db, int O, int I) {
+    MlpWgradJob &J = wa.j[nq++];
+    J.dY = dY; J.X = X; J.dW = dW; J.db = db; J.O = O; J.I = I; J.ti = (I + 31) / 32; J.to = (O + 31) / 32;
+    const int tiles = J.ti * J.to;
+    int splitk = 1;
+    while (splitk * 2 * tiles <= 256 && B / (splitk * 2) >= 64 && (B % (splitk * 2 * 64)) == 0) splitk *= 2;
+    J.kchunk = B / splitk; J.first = nw;
+    nw += tiles * splitk;
+  };
+  for (int t = 0; t < 2; t++) {
+    float *ws = s->workspace + t * L.per_trunk;
+    const int Aout = t == 0 ? A : 1;
+    add_wg(ws + L.dz1, s->obs, s->gW[t][0], s->gb[t][0], H1, D);
+    add_wg(ws + L.dz2, ws + L.h1, s->gW[t][1], s->gb[t][1], H2, H1);
+    add_wg(ws + L.d3, ws + L.h2, s->gW[t][2], s->gb[t][2], Aout, H2);
+  }
+  wa.B = B; wa.nblocks = nw; wa.log_std = s->log_std; wa.stats = stats; wa.g_log_std = s->g_log_std; wa.out8 = s->out8; wa.A = A;
+  wa.vf_coef = s->vf_coef; wa.ent_coef = s->ent_coef;
+  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(nw + 1), dim3(64), 0, st, wa);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}

@@ -177,6 +177,58 @@ class FusedPolicyForward:
             raise RuntimeError("dm_policy_forward failed (%d)" % rc)
 
 
+class FusedMlpGrad:
+    """``dm_ppo_mlp_grad`` (csrc/dm_ppo_mlp.hip): loss and every gradient of one PPO minibatch for an ``MlpPolicy`` with
+    two hidden layers of at most 256 units, in three launches, written into the flat gradient arena of ``FlatAdam``
+    (which the caller zeroes).  Returns the loss as a view of the device-side ``out8`` record."""
+
+    def __init__(self, policy, opt, B):
+        import ctypes as C
+        from . import _lib
+        self.lib, self.C, self.St = _lib.load_library(), C, _lib.DmPpoMlpStep
+        lin = lambda seq: [m for m in seq if isinstance(m, nn.Linear)]
+        pi, vf = lin(policy.pi) + [policy.action_net], lin(policy.vf) + [policy.value_net]
+        dev = policy.log_std.device
+        D, H1, H2, A = pi[0].in_features, pi[0].out_features, pi[1].out_features, pi[2].out_features
+        n = int(self.lib.dm_ppo_mlp_workspace_floats(B, D, H1, H2, A))
+        if n <= 0:
+            raise ValueError("dm_ppo_mlp_grad does not support this net / minibatch")
+        self.ws = torch.zeros(n, device=dev)
+        self.out8 = torch.zeros(8, device=dev)
+        grad = {id(p): g for p, g in zip(opt.params, opt.slices)}
+        st = self.St()
+        st.B, st.D, st.H1, st.H2, st.A = B, D, H1, H2, A
+        for t, layers in enumerate((pi, vf)):
+            for l, m in enumerate(layers):
+                st.W[t][l], st.b[t][l] = m.weight.data_ptr(), m.bias.data_ptr()
+                st.gW[t][l], st.gb[t][l] = grad[id(m.weight)].data_ptr(), grad[id(m.bias)].data_ptr()
+        st.log_std, st.g_log_std = policy.log_std.data_ptr(), grad[id(policy.log_std)].data_ptr()
+        st.out8, st.workspace, st.workspace_floats = self.out8.data_ptr(), self.ws.data_ptr(), n
+        self.st, self.B, self.dev = st, B, dev
+
+    @staticmethod
+    def supported(policy, B):
+        if not isinstance(policy, MlpPolicy) or policy.log_std.device.type != "cuda":
+            return False
+        lin = [m for m in policy.pi if isinstance(m, nn.Linear)]
+        if len(lin) != 2 or len([m for m in policy.vf if isinstance(m, nn.Linear)]) != 2:
+            return False
+        h1, h2 = lin[0].out_features, lin[1].out_features
+        return (B >= 64 and B % 64 == 0 and h1 % 32 == 0 and h2 % 32 == 0 and h1 <= 256 and h2 <= 256
+                and policy.action_net.out_features <= 32)
+
+    def __call__(self, obs, act, adv, ret, old_logp, clip_range, vf_coef, ent_coef, normalize):
+        st = self.st
+        for t in (obs, act, adv, ret, old_logp):
+            assert t.is_contiguous() and t.dtype == torch.float32 and t.shape[0] == self.B
+        st.obs, st.act, st.adv, st.ret, st.old_logp = (t.data_ptr() for t in (obs, act, adv, ret, old_logp))
+        st.clip_range, st.vf_coef, st.ent_coef, st.normalize_advantage = clip_range, vf_coef, ent_coef, int(bool(normalize))
+        rc = self.lib.dm_ppo_mlp_grad(self.C.byref(st), self.C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("dm_ppo_mlp_grad failed (%d)" % rc)
+        return self.out8[0]
+
+
 class ExtractedPolicy:
     """The reference's exported walk policy: a = tanh(tanh(o W0 + B0) W2 + B2) WA + BA
     (src/extracted_policy.py:471-478; used with obs[:66] and clip +-0.5, src/play_extracted.py:36-38)."""
@@ -355,7 +407,7 @@ class PPO:
                  gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5,
                  normalize_advantage=True, seed=0, device=None, buffer_dtype=torch.float32, policy=None,
                  use_hip_graph=None, fused_loss=True, flat_adam=True, two_stream=True, rollout_graph=True, fused_rollout=True,
-                 fused_policy=True):
+                 fused_policy=True, fused_mlp=True):
         # rollout_graph only takes effect for an env built with sub_batches > 1
         self.env = env
         self.device = device if device is not None else getattr(env, "device", torch.device("cpu"))
@@ -369,6 +421,7 @@ class PPO:
         self.rollout_graph = rollout_graph    # env with sub_batches > 1: the T-step rollout is one captured hipGraph
         self.fused_rollout = fused_rollout    # dm_policy_sample + dm_rollout_store instead of ~20 small kernels per step
         self.fused_policy = fused_policy      # dm_policy_forward: the whole policy side of a rollout step as one launch
+        self.fused_mlp = fused_mlp            # dm_ppo_mlp_grad: loss + all gradients of a minibatch in three launches
         self._rollout_seed = 0x5EED0000 + seed
         self.buffer_dtype = buffer_dtype
         torch.manual_seed(seed)  # identical initial weights on every rank; no parameter broadcast needed
@@ -710,6 +763,18 @@ class PPO:
                                   self.ent_coef, self.normalize_advantage and obs.shape[0] > 1)
 
     def _minibatch_step(self, obs, act, adv, ret, old_logp):
+        if (self.flat_adam and self.fused_mlp and self.fused_loss and obs.is_cuda
+                and FusedMlpGrad.supported(self.policy, obs.shape[0])):
+            # the whole minibatch gradient in three launches, written into the flat arena
+            mg = getattr(self, "_mlp_grad", None)
+            if mg is None or mg.B != obs.shape[0]:
+                mg = self._mlp_grad = FusedMlpGrad(self.policy, self.optimizer, obs.shape[0])
+            self.optimizer.zero_grad()
+            loss = mg(obs.contiguous(), act.contiguous(), adv.contiguous(), ret.contiguous(), old_logp.contiguous(), self.clip_range,
+                      self.vf_coef, self.ent_coef, self.normalize_advantage and obs.shape[0] > 1)
+            self.optimizer.all_reduce()
+            self.optimizer.step()
+            return loss
         if self.flat_adam:
             # every gradient lands in one flat buffer (one memset), clipping + Adam are one fused update on it, and
             # with several ranks that buffer is the operand of the ONE collective of the data-parallel learner

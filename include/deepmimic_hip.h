@@ -218,6 +218,30 @@ int dm_policy_forward(const float *obs, int N, int D, int H1, int H2, int A, con
                       unsigned draw_offset, int deterministic, const float *lo, const float *hi, float *mean_out, float *act,
                       float *act_env, float *logp, float *val, float *obs_copy, void *stream);
 
+/* One PPO minibatch gradient of SB3's MlpPolicy with two hidden layers (net_arch [H1, H2], tanh, separate policy / value
+ * trunks) in three launches (csrc/dm_ppo_mlp.hip): what zero_grad + evaluate_actions + the dm_ppo_loss loss + backward
+ * compute for src/sb3_ppo.py:254-271,307-312 -> [EXT] PPO.train.  Index 0 = policy trunk (layers D->H1, H1->H2, H2->A),
+ * 1 = value trunk (.., H2->1); W are nn.Linear weights [out, in] row-major.  Gradients are ACCUMULATED into gW / gb /
+ * g_log_std, which the caller zeroes on the same stream (the optimizer's flat arena); out8 as in dm_ppo_loss.
+ * B a multiple of 64, H1 / H2 multiples of 32 and <= 256, A <= 32; workspace >= dm_ppo_mlp_workspace_floats floats,
+ * 16-byte aligned. */
+typedef struct DmPpoMlpStep {
+  int32_t B, D, H1, H2, A, normalize_advantage;
+  float clip_range, vf_coef, ent_coef;
+  int32_t reserved;
+  const float *obs, *act, *adv, *ret, *old_logp, *log_std;
+  const float *W[2][3];
+  const float *b[2][3];
+  float *gW[2][3];
+  float *gb[2][3];
+  float *g_log_std;
+  float *out8;
+  float *workspace;
+  long long workspace_floats;
+} DmPpoMlpStep;
+long long dm_ppo_mlp_workspace_floats(int B, int D, int H1, int H2, int A);
+int dm_ppo_mlp_grad(const DmPpoMlpStep *step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -587,3 +587,69 @@ def test_one_launch_policy_rollout(model, sub_batches, graph):
     with torch.no_grad():
         assert torch.allclose(buf["val"][2], ppo.policy.predict_values(buf["obs"][2]), atol=2e-5)
     venv.close(); twin.close()
+
+
+@pytest.mark.parametrize("arch,B,D,ent", [((256, 128), 4096, 67, 0.0), ((64, 32), 256, 72, 0.01), ((96, 160), 128, 67, 0.0)])
+def test_fused_mlp_grad_matches_autograd(arch, B, D, ent):
+    """dm_ppo_mlp_grad (pack + fused forward / loss / input-gradient kernel + six-layer weight-gradient kernel) against
+    autograd on the PyTorch-op loss of SB3's PPO.train: loss terms and every parameter gradient, on a minibatch whose
+    ratios straddle the clip range; tolerance 3e-4 of the largest gradient entry (fp32, different summation order)."""
+    import torch
+    from deepmimic_mujoco_amd.ppo import PPO, MlpPolicy, FusedMlpGrad
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(7)
+    pol = MlpPolicy(obs_dim=D, net_arch=arch)
+    ppo = PPO(None, net_arch=arch, batch_size=B, device=dev, ent_coef=ent, policy=pol, use_hip_graph=False)
+    pol = ppo.policy
+    with torch.no_grad():
+        pol.log_std.copy_(torch.linspace(-0.5, 0.3, 28))
+        pol.action_net.weight.mul_(20.0)
+        for m in pol.modules():
+            if isinstance(m, torch.nn.Linear):
+                m.bias.normal_(0, 0.1)
+        obs = torch.randn(B, D, device=dev) * 0.7
+        mean = pol.action_net(pol.pi(obs))
+        act = mean + pol.log_std.exp() * torch.randn(B, 28, device=dev)
+        old_logp = pol._logp(act, mean) + 0.15 * torch.randn(B, device=dev)
+        adv = torch.randn(B, device=dev) * 2 + 0.3
+        ret = torch.randn(B, device=dev)
+    assert FusedMlpGrad.supported(pol, B)
+    F = torch.nn.functional
+    trunk = lambda seq, x: torch.tanh(F.linear(torch.tanh(F.linear(x, seq[0].weight, seq[0].bias)), seq[2].weight, seq[2].bias))
+    mean_r = F.linear(trunk(pol.pi, obs), pol.action_net.weight, pol.action_net.bias)           # plain PyTorch ops only
+    value_r = F.linear(trunk(pol.vf, obs), pol.value_net.weight, pol.value_net.bias).squeeze(-1)
+    a_n = (adv - adv.mean()) / (adv.std() + 1e-8)
+    rat = torch.exp(pol._logp(act, mean_r) - old_logp)
+    ent_r = (0.5 + 0.5 * np.log(2 * np.pi) + pol.log_std).sum()
+    loss_t = (-torch.min(a_n * rat, a_n * torch.clamp(rat, 1 - ppo.clip_range, 1 + ppo.clip_range)).mean()
+              + ppo.vf_coef * F.mse_loss(value_r, ret) - ppo.ent_coef * ent_r)
+    for p in pol.parameters():
+        p.grad = None
+    loss_t.backward()
+    ref = {id(p): p.grad.clone() for p in pol.parameters()}
+    opt = ppo.optimizer
+    opt.zero_grad()
+    mg = FusedMlpGrad(pol, opt, B)
+    loss_f = mg(obs, act, adv, ret, old_logp, ppo.clip_range, ppo.vf_coef, ppo.ent_coef, True)
+    torch.cuda.synchronize()
+    assert abs(float(loss_f) - float(loss_t.detach())) < 2e-5 * max(1.0, abs(float(loss_t.detach())))
+    with torch.no_grad():
+        ratio = torch.exp(pol._logp(act, mean) - old_logp)
+        clipfrac = float(((ratio - 1).abs() > ppo.clip_range).float().mean())
+    assert 0.05 < clipfrac < 0.95 and abs(float(mg.out8[5]) - clipfrac) < 1e-6
+    names = {id(p): n for n, p in pol.named_parameters()}
+    for p, g in zip(opt.params, opt.slices):
+        r = ref[id(p)]
+        scale = float(r.abs().max())
+        assert scale > 0, names[id(p)]
+        assert float((g - r).abs().max()) < 3e-4 * scale + 1e-8, (names[id(p)], float((g - r).abs().max()), scale)
+    # the optimizer step on top of it: same parameters as the autograd path after three minibatch steps
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(7)
+        q = PPO(None, net_arch=arch, batch_size=B, device=dev, ent_coef=ent, policy=MlpPolicy(obs_dim=D, net_arch=arch),
+                use_hip_graph=False, fused_mlp=fused)
+        for _ in range(3):
+            q._minibatch_step(obs, act, adv, ret, old_logp)
+        res.append(torch.cat([p.detach().reshape(-1) for p in q.policy.parameters()]))
+    assert torch.allclose(res[0], res[1], rtol=1e-4, atol=2e-6), float((res[0] - res[1]).abs().max())
