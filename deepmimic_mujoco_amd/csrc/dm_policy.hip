@@ -53,25 +53,40 @@ __device__ __forceinline__ unsigned pol_hash32(unsigned long long seed, unsigned
 // acc += X[32 x 8 (kb1 - kb0)] W^T for one 32-neuron tile; xs = LDS activations (row stride sx), P = the tile's packed
 // weights (64 float4 per k-block of 8).
 template <int U>
+__device__ __forceinline__ void pol_load(const float4 *p, const float *xrow, int kb, float4 (&w)[U], float4 (&a)[U]) {
+#pragma unroll
+  for (int u = 0; u < U; u++) w[u] = p[(size_t)(kb + u) * 64];
+#pragma unroll
+  for (int u = 0; u < U; u++) a[u] = *reinterpret_cast<const float4 *>(xrow + (kb + u) * 8);
+}
+template <int U>
+__device__ __forceinline__ void pol_mfma(const float4 (&w)[U], const float4 (&a)[U], pol_f16v &acc) {
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, w[u].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, w[u].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, w[u].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, w[u].w, acc, 0, 0, 0);
+  }
+}
+template <int U>
 __device__ __forceinline__ void pol_tile(const float *xs, int sx, const float4 *P, int lane, int kb0, int kb1, pol_f16v &acc) {
   const float *xrow = xs + (lane & 31) * sx + 4 * (lane >> 5);
   const float4 *p = P + lane;
-  int kb = kb0;
-  for (; kb + U <= kb1; kb += U) {
-    float4 w[U], a[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) w[u] = p[(size_t)(kb + u) * 64];
-#pragma unroll
-    for (int u = 0; u < U; u++) a[u] = *reinterpret_cast<const float4 *>(xrow + (kb + u) * 8);
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, w[u].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, w[u].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, w[u].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, w[u].w, acc, 0, 0, 0);
-    }
+  const int nb = (kb1 - kb0) / U;
+  // ping-pong over two register sets (no copies): the loads of batch it + 1 are in flight under the 4 U MFMAs of batch
+  // it, and the MFMAs wait only for their own batch (s_waitcnt vmcnt(U))
+  float4 wA[U], aA[U], wB[U], aB[U];
+  if (nb > 0) pol_load<U>(p, xrow, kb0, wA, aA);
+  int it = 0;
+  for (; it + 2 <= nb; it += 2) {
+    pol_load<U>(p, xrow, kb0 + (it + 1) * U, wB, aB);
+    pol_mfma<U>(wA, aA, acc);
+    if (it + 2 < nb) pol_load<U>(p, xrow, kb0 + (it + 2) * U, wA, aA);
+    pol_mfma<U>(wB, aB, acc);
   }
-  for (; kb < kb1; kb++) {
+  if (it < nb) pol_mfma<U>(wA, aA, acc);
+  for (int kb = kb0 + nb * U; kb < kb1; kb++) {
     const float4 w = p[(size_t)kb * 64];
     const float4 a = *reinterpret_cast<const float4 *>(xrow + kb * 8);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc, 0, 0, 0);

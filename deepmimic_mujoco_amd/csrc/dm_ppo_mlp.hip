@@ -15,6 +15,7 @@
 // Included by dm_abi.hip after dm_ppo.hip and dm_policy.hip (uses their device helpers).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/deepmimic_hip.h"
 
@@ -36,6 +37,10 @@ __global__ void __launch_bounds__(256) mlp_pack_kernel(MlpPackArgs a) {
   pol_pack_one(J.W, J.O, J.K, J.so, J.sk, J.tiles, J.KB, J.P, (blk - J.first) * 256 + (int)threadIdx.x);
 }
 
+// tanh(x) = 1 - 2 / (1 + e^{2x}) on the hardware exp / rcp: absolute error ~1e-7 (the accurate tanhf costs ~40 instructions
+// and the forward evaluates 12 k of them per workgroup)
+__device__ __forceinline__ float mlp_tanh(float x) { return 1.f - __fdividef(2.f, 1.f + __expf(2.f * x)); }
+
 struct MlpTrainArgs {
   int B, D, Dp, H1, H2, A;
   const float *obs, *act, *adv, *ret, *old_logp, *log_std;
@@ -47,7 +52,11 @@ struct MlpTrainArgs {
   float clip, vf_coef;
 };
 
-__global__ void __launch_bounds__(POL_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a) {
+// Eight waves per workgroup (two per SIMD): one wave's weight-stream latency, tanh and stores run under the other's
+// MFMAs (with four waves the kernel spent a third of its time in MFMA and as much waiting on loads, nothing overlapping).
+constexpr int MLP_NW = 8, MLP_THREADS = 64 * MLP_NW;
+
+__global__ void __launch_bounds__(MLP_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a) {
   extern __shared__ __align__(16) float mlp_lds[];
   const int trunk = blockIdx.y, b0 = blockIdx.x * POL_R;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -57,27 +66,27 @@ __global__ void __launch_bounds__(POL_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
   float *h2 = h1 + POL_R * s1;
   float *dz2 = h2 + POL_R * s2;
   float *d3 = dz2 + POL_R * s2;
-  float *red = d3 + POL_R * s3;           // 4 x 32 x 32 layer-3 partial sums
-  float *accs = red + 4096;               // [0..3] pg, vl, kl, clip fraction; [4..35] d loss / d log_std partials
+  float *red = d3 + POL_R * s3;           // MLP_NW x 32 x 32 layer-3 partial sums; before that the layer-2 K-half partials
+  float *accs = red + MLP_NW * 1024;      // [0..3] pg, vl, kl, clip fraction; [4..35] d loss / d log_std partials
   const int KB1 = a.Dp >> 3, T1 = a.H1 >> 5, KB2 = a.H1 >> 3, T2 = a.H2 >> 5, KB3 = a.H2 >> 3;
   const float4 *P1 = a.pkF[trunk];
   const float4 *P2 = P1 + (size_t)T1 * KB1 * 64;
   const float4 *P3 = P2 + (size_t)T2 * KB2 * 64;
   const int r = lane & 31, h = lane >> 5;
 
-  for (int i = tid; i < POL_R * a.D; i += POL_THREADS) {
+  for (int i = tid; i < POL_R * a.D; i += MLP_THREADS) {
     const int row = i / a.D, c = i - row * a.D;
     xs[row * sx + c] = a.obs[(size_t)b0 * a.D + i];
   }
-  for (int i = tid; i < POL_R * (a.Dp - a.D); i += POL_THREADS) {
+  for (int i = tid; i < POL_R * (a.Dp - a.D); i += MLP_THREADS) {
     const int row = i / (a.Dp - a.D), c = a.D + i - row * (a.Dp - a.D);
     xs[row * sx + c] = 0.f;
   }
   if (tid < 36) accs[tid] = 0.f;
   __syncthreads();
 
-  // ---- forward: layer 1, layer 2 (activations to LDS and to HBM for the weight gradients), layer 3 split-K
-  for (int to = wave; to < T1; to += 4) {
+  // ---- forward layer 1: one tile per wave (activations to LDS, and to HBM for the weight gradients)
+  for (int to = wave; to < T1; to += MLP_NW) {
     pol_f16v acc;
 #pragma unroll
     for (int j = 0; j < 16; j++) acc[j] = 0.f;
@@ -86,33 +95,49 @@ __global__ void __launch_bounds__(POL_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const int row = (j >> 2) * 8 + h * 4 + (j & 3);
-      const float v = tanhf(acc[j] + b);
+      const float v = mlp_tanh(acc[j] + b);
       h1[row * s1 + to * 32 + r] = v;
       a.h1g[trunk][(size_t)(b0 + row) * a.H1 + to * 32 + r] = v;
     }
   }
   __syncthreads();
-  for (int to = wave; to < T2; to += 4) {
+  // ---- forward layer 2: a tile is shared by two waves (K halves; KB2 = H1 / 8 is even), the odd wave hands its partial
+  // sums over through LDS
+  for (int base = 0; base < 2 * T2; base += MLP_NW) {
+    const int u = base + wave, tile = u >> 1, half = u & 1;
+    const bool on = u < 2 * T2;
     pol_f16v acc;
 #pragma unroll
     for (int j = 0; j < 16; j++) acc[j] = 0.f;
-    pol_tile<8>(h1, s1, P2 + (size_t)to * KB2 * 64, lane, 0, KB2, acc);
-    const float b = a.b2[trunk][to * 32 + r];
+    if (on) {
+      const int kh = KB2 >> 1;
+      pol_tile<8>(h1, s1, P2 + (size_t)tile * KB2 * 64, lane, half * kh, (half + 1) * kh, acc);
+      if (half) {
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const int row = (j >> 2) * 8 + h * 4 + (j & 3);
-      const float v = tanhf(acc[j] + b);
-      h2[row * s2 + to * 32 + r] = v;
-      a.h2g[trunk][(size_t)(b0 + row) * a.H2 + to * 32 + r] = v;
+        for (int j = 0; j < 16; j++) red[tile * 1024 + j * 64 + lane] = acc[j];
+      }
+    }
+    __syncthreads();
+    if (on && !half) {
+      const float b = a.b2[trunk][tile * 32 + r];
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const int row = (j >> 2) * 8 + h * 4 + (j & 3);
+        const float v = mlp_tanh(acc[j] + red[tile * 1024 + j * 64 + lane] + b);
+        h2[row * s2 + tile * 32 + r] = v;
+        a.h2g[trunk][(size_t)(b0 + row) * a.H2 + tile * 32 + r] = v;
+      }
     }
   }
   __syncthreads();
+  // ---- forward layer 3: split-K over the waves
   {
     pol_f16v acc3;
 #pragma unroll
     for (int j = 0; j < 16; j++) acc3[j] = 0.f;
-    const int per = KB3 >> 2;                       // KB3 = H2 / 8 is a multiple of 4
-    pol_tile<4>(h2, s2, P3, lane, wave * per, (wave + 1) * per, acc3);
+    const int nsp = (KB3 % MLP_NW) == 0 ? MLP_NW : 4;      // KB3 = H2 / 8 is a multiple of 4
+    const int per = KB3 / nsp;
+    if (wave < nsp) pol_tile<4>(h2, s2, P3, lane, wave * per, (wave + 1) * per, acc3);
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const int row = (j >> 2) * 8 + h * 4 + (j & 3);
@@ -121,8 +146,8 @@ __global__ void __launch_bounds__(POL_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
   }
   __syncthreads();
 
-  // ---- loss head: eight threads per row (same formulas as ppo_loss_kernel)
-  {
+  // ---- loss head: eight threads per row (same formulas as ppo_loss_kernel), waves 0..3
+  if (tid < 256) {
     const int row = tid >> 3, q = tid & 7, b = b0 + row;
     const float invB = 1.0f / (float)a.B;
     if (trunk == 0) {
@@ -133,7 +158,9 @@ __global__ void __launch_bounds__(POL_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
         const int c = q + 8 * s;
         dd[s] = 0.f; iv[s] = 0.f; z2[s] = 0.f;
         if (c < a.A) {
-          const float m = red[row * 32 + c] + red[1024 + row * 32 + c] + red[2048 + row * 32 + c] + red[3072 + row * 32 + c] + a.b3[0][c];
+          float m = a.b3[0][c];
+#pragma unroll
+          for (int w = 0; w < MLP_NW; w++) m += red[w * 1024 + row * 32 + c];
           const float ls = a.log_std[c];
           dd[s] = a.act[(size_t)b * a.A + c] - m;
           iv[s] = expf(-2.f * ls);
@@ -168,7 +195,9 @@ __global__ void __launch_bounds__(POL_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
         atomicAdd(&accs[3], (fabsf(ratio - 1.f) > a.clip) ? 1.f : 0.f);
       }
     } else {
-      const float v = red[row * 32] + red[1024 + row * 32] + red[2048 + row * 32] + red[3072 + row * 32] + a.b3[1][0];
+      float v = a.b3[1][0];
+#pragma unroll
+      for (int w = 0; w < MLP_NW; w++) v += red[w * 1024 + row * 32];
       const float dv = v - a.ret[b];
       const float g = a.vf_coef * 2.f * invB * dv;
 #pragma unroll
@@ -196,7 +225,7 @@ __global__ void __launch_bounds__(POL_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
   }
 
   // ---- backward: dZ2 = (d3 W3) (1 - h2^2), dZ1 = (dZ2 W2) (1 - h1^2)
-  for (int to = wave; to < T2; to += 4) {
+  for (int to = wave; to < T2; to += MLP_NW) {
     pol_f16v acc;
 #pragma unroll
     for (int j = 0; j < 16; j++) acc[j] = 0.f;
@@ -211,7 +240,7 @@ __global__ void __launch_bounds__(POL_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
     }
   }
   __syncthreads();
-  for (int to = wave; to < T1; to += 4) {
+  for (int to = wave; to < T1; to += MLP_NW) {
     pol_f16v acc;
 #pragma unroll
     for (int j = 0; j < 16; j++) acc[j] = 0.f;
@@ -225,14 +254,21 @@ __global__ void __launch_bounds__(POL_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
   }
 }
 
-struct MlpWgradJob { const float *dY, *X; float *dW, *db; int O, I, ti, to, kchunk, first; };
+// Weight / bias gradients of all six layers in one launch.  A workgroup of four waves owns a rectangle of 2 x 2 output
+// tiles (64 x 64 of dW) of one layer and one slice of `kchunk` minibatch rows; the waves split the slice four ways,
+// each accumulating the four 32 x 32 tiles from operands read straight from global memory (128-byte row segments per
+// half-wave, every operand feeding two MFMAs, next batch of loads in flight under the current MFMAs), then the partial
+// tiles are summed through LDS and each wave adds one tile to dW with float atomics (split-K over workgroups: 8).
+constexpr int WG3_U = 8;            // k-pairs per load batch: 4 U loads per lane in flight, twice that with the prefetch
+struct MlpWgradJob { const float *dY, *X; float *dW, *db; int O, I, nro, nri, kchunk, first; };
 struct MlpWgradArgs {
   MlpWgradJob j[6];
   int B, nblocks;                   // block nblocks (the last one) finishes the loss scalar and the entropy gradient
   const float *log_std, *stats; float *g_log_std, *out8; int A; float vf_coef, ent_coef;
 };
 
-__global__ void __launch_bounds__(64) mlp_wgrad_kernel(MlpWgradArgs a) {
+__global__ void __launch_bounds__(256, 2) mlp_wgrad_kernel(MlpWgradArgs a) {
+  __shared__ __align__(16) float part[4][4][1024];       // [wave][tile][32 x 32]
   const int blk = blockIdx.x;
   if (blk == a.nblocks) {
     if (threadIdx.x == 0) {
@@ -250,16 +286,90 @@ __global__ void __launch_bounds__(64) mlp_wgrad_kernel(MlpWgradArgs a) {
 #pragma unroll
   for (int i = 1; i < 6; i++) if (blk >= a.j[i].first) q = i;
   const MlpWgradJob &J = a.j[q];
-  const int local = blk - J.first;
-  const int bx = local % J.ti, rest = local / J.ti;
-  ppo_wgrad_body(J.dY, J.X, J.dW, J.db, a.B, J.O, J.I, J.kchunk, bx, rest % J.to, rest / J.to);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int O = J.O, I = J.I;
+  const int local = blk - J.first, nrect = J.nro * J.nri;
+  const int rect = local % nrect, slice = local / nrect;
+  const int o0 = (rect / J.nri) * 64, i0 = (rect % J.nri) * 64;
+  const int kq = J.kchunk >> 2;                               // rows per wave, a multiple of 2 WG3_U
+  const int k0 = slice * J.kchunk + wave * kq;
+  const bool vo1 = o0 + 32 < O, vi1 = i0 + 32 < I;            // second tile row / column exists (wave-uniform)
+  const bool la0 = (o0 + r) < O, la1 = (o0 + 32 + r) < O;
+  // out-of-range rows / columns of a tile are never stored, so their operand lanes only need a valid address: clamp
+  const float *pa = J.dY + (size_t)(k0 + h) * O, *px = J.X + (size_t)(k0 + h) * I;
+  const int ca0 = min(o0 + r, O - 1), ca1 = min(o0 + 32 + r, O - 1), cx0 = min(i0 + r, I - 1), cx1 = min(i0 + 32 + r, I - 1);
+  pol_f16v acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int j = 0; j < 16; j++) { acc00[j] = 0.f; acc01[j] = 0.f; acc10[j] = 0.f; acc11[j] = 0.f; }
+  float db0 = 0.f, db1 = 0.f;
+  // ping-pong over two register sets: the 4 U loads of batch it + 1 are in flight under the MFMAs of batch it
+  struct Ops { float a0[WG3_U], a1[WG3_U], x0[WG3_U], x1[WG3_U]; };
+  auto load = [&](Ops &o, int k) {
+#pragma unroll
+    for (int u = 0; u < WG3_U; u++) {
+      const size_t kk = (size_t)(k + 2 * u);
+      o.a0[u] = pa[kk * O + ca0];
+      o.a1[u] = pa[kk * O + ca1];
+      o.x0[u] = px[kk * I + cx0];
+      o.x1[u] = px[kk * I + cx1];
+    }
+  };
+  auto mfma = [&](const Ops &o) {
+#pragma unroll
+    for (int u = 0; u < WG3_U; u++) {
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a0[u], o.x0[u], acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a0[u], o.x1[u], acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a1[u], o.x0[u], acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a1[u], o.x1[u], acc11, 0, 0, 0);
+      db0 += o.a0[u];
+      db1 += o.a1[u];
+    }
+  };
+  Ops A, Bq;
+  const int nb = kq / (2 * WG3_U);
+  load(A, 0);
+  int it = 0;
+  for (; it + 2 <= nb; it += 2) {
+    load(Bq, (it + 1) * 2 * WG3_U);
+    mfma(A);
+    if (it + 2 < nb) load(A, (it + 2) * 2 * WG3_U);
+    mfma(Bq);
+  }
+  if (it < nb) mfma(A);
+  // partial tiles -> LDS in accumulator order (lane-major: conflict-free), then wave w sums tile w and adds it to dW
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    part[wave][0][j * 64 + lane] = acc00[j];
+    part[wave][1][j * 64 + lane] = acc01[j];
+    part[wave][2][j * 64 + lane] = acc10[j];
+    part[wave][3][j * 64 + lane] = acc11[j];
+  }
+  __syncthreads();
+  {
+    const int t = wave, to = t >> 1, ti = t & 1;
+    const bool valid = (to == 0 || vo1) && (ti == 0 || vi1);
+    if (valid) {
+      const int col = i0 + ti * 32 + r;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const float v = part[0][t][j * 64 + lane] + part[1][t][j * 64 + lane] + part[2][t][j * 64 + lane] + part[3][t][j * 64 + lane];
+        const int row = o0 + to * 32 + (j >> 2) * 8 + h * 4 + (j & 3);
+        if (row < O && col < I) atomicAdd(&J.dW[(size_t)row * I + col], v);
+      }
+    }
+  }
+  if (i0 == 0) {            // bias gradient: every wave adds its K quarter (two rows of 32 outputs)
+    const float v0 = db0 + __shfl_xor(db0, 32), v1 = db1 + __shfl_xor(db1, 32);
+    if (h == 0 && la0) atomicAdd(&J.db[o0 + r], v0);
+    if (h == 0 && la1) atomicAdd(&J.db[o0 + 32 + r], v1);
+  }
 }
 
 inline bool mlp_dims_ok(int B, int D, int H1, int H2, int A) {
-  return B >= 64 && (B % 64) == 0 && pol_dims_ok(D, H1, H2, A) && H1 <= 256 && H2 <= 256;
+  return B >= 64 && (B % (8 * WG3_U)) == 0 && pol_dims_ok(D, H1, H2, A) && H1 <= 256 && H2 <= 256;
 }
 inline size_t mlp_lds_bytes(int D, int H1, int H2) {
-  return (size_t)(POL_R * (pol_dp(D) + POL_PAD + H1 + POL_PAD + 2 * (H2 + POL_PAD) + 32 + POL_PAD) + 4096 + 64) * sizeof(float);
+  return (size_t)(POL_R * (pol_dp(D) + POL_PAD + H1 + POL_PAD + 2 * (H2 + POL_PAD) + 32 + POL_PAD) + MLP_NW * 1024 + 64) * sizeof(float);
 }
 // per-trunk workspace (floats): forward pack | W2^T pack | W3^T pack | h1 | h2 | dz1 | dz2 | d3
 struct MlpWsLayout { size_t pkF, pkW2T, pkW3T, h1, h2, dz1, dz2, d3, per_trunk, total; };
@@ -346,19 +456,20 @@ extern "C" int dm_ppo_mlp_grad(const DmPpoMlpStep *s, void *stream) {
     ta.h1g[t] = ws + L.h1; ta.h2g[t] = ws + L.h2; ta.dz1g[t] = ws + L.dz1; ta.dz2g[t] = ws + L.dz2; ta.d3g[t] = ws + L.d3;
   }
   ta.stats = stats; ta.out8 = s->out8; ta.g_log_std = s->g_log_std; ta.clip = s->clip_range; ta.vf_coef = s->vf_coef;
-  hipLaunchKernelGGL(mlp_fwdbwd_kernel, dim3(B / POL_R, 2), dim3(POL_THREADS), lds, st, ta);
+  hipLaunchKernelGGL(mlp_fwdbwd_kernel, dim3(B / POL_R, 2), dim3(MLP_THREADS), lds, st, ta);
 
   // ---- 3. weight / bias gradients of the six layers + loss epilogue
   MlpWgradArgs wa;
   int nw = 0, nq = 0;
+  static const int sk_env = getenv("DM_WGRAD_SPLITK") ? atoi(getenv("DM_WGRAD_SPLITK")) : 8;   // workgroup-level split-K (experiments)
+  int splitk = s->reserved > 0 ? s->reserved : (sk_env > 0 ? sk_env : 8);
+  while (splitk > 1 && (B % (splitk * 8 * WG3_U)) != 0) splitk >>= 1;                         // kchunk / 4 a multiple of 2 WG3_U
+  if ((B % (splitk * 8 * WG3_U)) != 0) return -22;
   auto add_wg = [&](const float *dY, const float *X, float *dW, float *db, int O, int I) {
     MlpWgradJob &J = wa.j[nq++];
-    J.dY = dY; J.X = X; J.dW = dW; J.db = db; J.O = O; J.I = I; J.ti = (I + 31) / 32; J.to = (O + 31) / 32;
-    const int tiles = J.ti * J.to;
-    int splitk = 1;
-    while (splitk * 2 * tiles <= 256 && B / (splitk * 2) >= 64 && (B % (splitk * 2 * 64)) == 0) splitk *= 2;
+    J.dY = dY; J.X = X; J.dW = dW; J.db = db; J.O = O; J.I = I; J.nro = (O + 63) / 64; J.nri = (I + 63) / 64;
     J.kchunk = B / splitk; J.first = nw;
-    nw += tiles * splitk;
+    nw += J.nro * J.nri * splitk;
   };
   for (int t = 0; t < 2; t++) {
     float *ws = s->workspace + t * L.per_trunk;
@@ -369,6 +480,6 @@ extern "C" int dm_ppo_mlp_grad(const DmPpoMlpStep *s, void *stream) {
   }
   wa.B = B; wa.nblocks = nw; wa.log_std = s->log_std; wa.stats = stats; wa.g_log_std = s->g_log_std; wa.out8 = s->out8; wa.A = A;
   wa.vf_coef = s->vf_coef; wa.ent_coef = s->ent_coef;
-  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(nw + 1), dim3(64), 0, st, wa);
+  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(nw + 1), dim3(256), 0, st, wa);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

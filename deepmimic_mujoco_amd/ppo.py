@@ -204,6 +204,7 @@ class FusedMlpGrad:
                 st.gW[t][l], st.gb[t][l] = grad[id(m.weight)].data_ptr(), grad[id(m.bias)].data_ptr()
         st.log_std, st.g_log_std = policy.log_std.data_ptr(), grad[id(policy.log_std)].data_ptr()
         st.out8, st.workspace, st.workspace_floats = self.out8.data_ptr(), self.ws.data_ptr(), n
+        st.reserved = int(__import__("os").environ.get("DM_WGRAD_SPLITK", "0"))      # 0: library default (experiments)
         self.st, self.B, self.dev = st, B, dev
 
     @staticmethod
