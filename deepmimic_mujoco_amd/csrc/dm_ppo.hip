@@ -313,6 +313,17 @@ extern "C" int dm_adam_clip_step(float *p, const float *g, float *m, float *v, i
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
+extern "C" int dm_adam_clip_update(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
+                                   float max_norm, float *state2, void *stream) {
+  if (!p || !g || !m || !v || !state2 || n < 1) return -22;
+  hipStream_t s = (hipStream_t)stream;
+  int blocks = (n + 256 * 8 - 1) / (256 * 8);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(adam_sumsq_kernel, dim3(blocks), dim3(256), 0, s, g, n, state2);
+  hipLaunchKernelGGL(adam_update_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, max_norm, state2);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Rollout side of the PPO loop (reference: src/sb3_ppo.py:307-313 -> [EXT] SB3 collect_rollouts): per env step the
 // policy head output becomes a sampled action, its log-probability and the clipped action handed to the env, and the

@@ -24,13 +24,24 @@ namespace {
 struct MlpPackJob { const float *W; float4 *P; int O, K, so, sk, tiles, KB, first; };
 struct MlpPackArgs {
   MlpPackJob j[10];
-  int njobs, nblocks;               // block nblocks (the last one) computes the advantage statistics
+  int njobs, nblocks;               // block nblocks computes the advantage statistics, the blocks after it clear zero_ptr
   const float *adv; int B, normalize; float *stats, *out8;
+  float *zero_ptr; long long zero_floats; float *adam_state2;
 };
 
 __global__ void __launch_bounds__(256) mlp_pack_kernel(MlpPackArgs a) {
   const int blk = blockIdx.x;
-  if (blk == a.nblocks) { ppo_prepare_body(a.adv, a.B, a.normalize, a.stats, a.out8, nullptr, 0); return; }
+  if (blk == a.nblocks) {
+    ppo_prepare_body(a.adv, a.B, a.normalize, a.stats, a.out8, nullptr, 0);
+    if (a.adam_state2 && threadIdx.x == 0) { a.adam_state2[0] = 0.f; a.adam_state2[1] += 1.f; }     // adam_begin_kernel
+    return;
+  }
+  if (blk > a.nblocks) {
+    const long long i = ((long long)(blk - a.nblocks - 1) * 256 + threadIdx.x) * 4;
+#pragma unroll
+    for (int c = 0; c < 4; c++) if (i + c < a.zero_floats) a.zero_ptr[i + c] = 0.f;
+    return;
+  }
   int q = 0;
   for (int i = 1; i < a.njobs; i++) if (blk >= a.j[i].first) q = i;
   const MlpPackJob &J = a.j[q];
@@ -264,7 +275,7 @@ struct MlpWgradJob { const float *dY, *X; float *dW, *db; int O, I, nro, nri, kc
 struct MlpWgradArgs {
   MlpWgradJob j[6];
   int B, nblocks;                   // block nblocks (the last one) finishes the loss scalar and the entropy gradient
-  const float *log_std, *stats; float *g_log_std, *out8; int A; float vf_coef, ent_coef;
+  const float *log_std, *stats; float *g_log_std, *out8, *loss_acc; int A; float vf_coef, ent_coef;
 };
 
 __global__ void __launch_bounds__(256, 2) mlp_wgrad_kernel(MlpWgradArgs a) {
@@ -278,6 +289,7 @@ __global__ void __launch_bounds__(256, 2) mlp_wgrad_kernel(MlpWgradArgs a) {
       a.out8[0] = a.out8[1] + a.vf_coef * a.out8[2] - a.ent_coef * ent;
       a.out8[6] = a.stats[0];
       a.out8[7] = a.stats[1];
+      if (a.loss_acc) { a.loss_acc[0] += a.out8[0]; a.loss_acc[1] += 1.f; }
     }
     if ((int)threadIdx.x < a.A && a.ent_coef != 0.f) atomicAdd(&a.g_log_std[threadIdx.x], -a.ent_coef);
     return;
@@ -441,7 +453,9 @@ extern "C" int dm_ppo_mlp_grad(const DmPpoMlpStep *s, void *stream) {
   }
   pa.njobs = nj; pa.nblocks = nb;
   pa.adv = s->adv; pa.B = B; pa.normalize = (s->normalize_advantage && B > 1) ? 1 : 0; pa.stats = stats; pa.out8 = s->out8;
-  hipLaunchKernelGGL(mlp_pack_kernel, dim3(nb + 1), dim3(256), 0, st, pa);
+  pa.zero_ptr = s->zero_ptr; pa.zero_floats = s->zero_ptr ? s->zero_floats : 0; pa.adam_state2 = s->adam_state2;
+  const int nzero = (int)((pa.zero_floats + 1023) / 1024);
+  hipLaunchKernelGGL(mlp_pack_kernel, dim3(nb + 1 + nzero), dim3(256), 0, st, pa);
 
   // ---- 2. forward + loss head + input gradients
   MlpTrainArgs ta;
@@ -478,7 +492,7 @@ extern "C" int dm_ppo_mlp_grad(const DmPpoMlpStep *s, void *stream) {
     add_wg(ws + L.dz2, ws + L.h1, s->gW[t][1], s->gb[t][1], H2, H1);
     add_wg(ws + L.d3, ws + L.h2, s->gW[t][2], s->gb[t][2], Aout, H2);
   }
-  wa.B = B; wa.nblocks = nw; wa.log_std = s->log_std; wa.stats = stats; wa.g_log_std = s->g_log_std; wa.out8 = s->out8; wa.A = A;
+  wa.B = B; wa.nblocks = nw; wa.log_std = s->log_std; wa.stats = stats; wa.g_log_std = s->g_log_std; wa.out8 = s->out8; wa.loss_acc = s->loss_acc; wa.A = A;
   wa.vf_coef = s->vf_coef; wa.ent_coef = s->ent_coef;
   hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(nw + 1), dim3(256), 0, st, wa);
   return hipGetLastError() == hipSuccess ? 0 : -5;

@@ -182,7 +182,7 @@ class FusedMlpGrad:
     two hidden layers of at most 256 units, in three launches, written into the flat gradient arena of ``FlatAdam``
     (which the caller zeroes).  Returns the loss as a view of the device-side ``out8`` record."""
 
-    def __init__(self, policy, opt, B):
+    def __init__(self, policy, opt, B, loss_acc=None, fold=True):
         import ctypes as C
         from . import _lib
         self.lib, self.C, self.St = _lib.load_library(), C, _lib.DmPpoMlpStep
@@ -205,6 +205,11 @@ class FusedMlpGrad:
         st.log_std, st.g_log_std = policy.log_std.data_ptr(), grad[id(policy.log_std)].data_ptr()
         st.out8, st.workspace, st.workspace_floats = self.out8.data_ptr(), self.ws.data_ptr(), n
         st.reserved = int(__import__("os").environ.get("DM_WGRAD_SPLITK", "0"))      # 0: library default (experiments)
+        self.folded = bool(fold)
+        if fold:    # the launch also clears the gradient arena, does Adam's begin and keeps the running loss sum
+            self.loss_acc = loss_acc if loss_acc is not None else torch.zeros(2, device=dev)
+            st.zero_ptr, st.zero_floats = opt.flat_g.data_ptr(), opt.n
+            st.adam_state2, st.loss_acc = opt.state2.data_ptr(), self.loss_acc.data_ptr()
         self.st, self.B, self.dev = st, B, dev
 
     @staticmethod
@@ -384,11 +389,13 @@ class FlatAdam:
             self.flat_g.div_(dist.get_world_size())
             self.calls += 1
 
-    def step(self):
+    def step(self, begin=True):
+        """begin=False: state2 was prepared by dm_ppo_mlp_grad (adam_state2 fold) — two launches instead of three."""
         import ctypes as C
         from . import _lib
         p = lambda t: C.c_void_p(t.data_ptr())
-        rc = _lib.load_library().dm_adam_clip_step(p(self.flat_p), p(self.flat_g), p(self.m), p(self.v), self.n, self.lr,
+        L = _lib.load_library()
+        rc = (L.dm_adam_clip_step if begin else L.dm_adam_clip_update)(p(self.flat_p), p(self.flat_g), p(self.m), p(self.v), self.n, self.lr,
                                                    self.betas[0], self.betas[1], self.eps, self.max_grad_norm, p(self.state2),
                                                    C.c_void_p(torch.cuda.current_stream(self.flat_p.device).cuda_stream))
         if rc != 0:
@@ -408,7 +415,7 @@ class PPO:
                  gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5,
                  normalize_advantage=True, seed=0, device=None, buffer_dtype=torch.float32, policy=None,
                  use_hip_graph=None, fused_loss=True, flat_adam=True, two_stream=True, rollout_graph=True, fused_rollout=True,
-                 fused_policy=True, fused_mlp=True):
+                 fused_policy=True, fused_mlp=True, epoch_graph=True):
         # rollout_graph only takes effect for an env built with sub_batches > 1
         self.env = env
         self.device = device if device is not None else getattr(env, "device", torch.device("cpu"))
@@ -422,6 +429,7 @@ class PPO:
         self.rollout_graph = rollout_graph    # env with sub_batches > 1: the T-step rollout is one captured hipGraph
         self.fused_rollout = fused_rollout    # dm_policy_sample + dm_rollout_store instead of ~20 small kernels per step
         self.fused_policy = fused_policy      # dm_policy_forward: the whole policy side of a rollout step as one launch
+        self.epoch_graph = epoch_graph        # one hipGraph replay per epoch (gathers + optimizer steps) instead of one per minibatch
         self.fused_mlp = fused_mlp            # dm_ppo_mlp_grad: loss + all gradients of a minibatch in three launches
         self._rollout_seed = 0x5EED0000 + seed
         self.buffer_dtype = buffer_dtype
@@ -439,6 +447,8 @@ class PPO:
             self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5, fused=on_gpu,
                                               capturable=on_gpu and self.use_hip_graph)
         self._graph = None
+        self._mlp_grads = {}                                                        # FusedMlpGrad per minibatch size
+        self._loss_acc = torch.zeros(2, device=self.device) if on_gpu else None     # device-side (sum of losses, count)
         self.grad_sync = self.optimizer if self.flat_adam else FlatGradAllReduce(self.policy.parameters())
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         if dist.is_initialized():  # decorrelate action noise across ranks after the common init
@@ -720,6 +730,25 @@ class PPO:
         n = flat["obs"].shape[0]
         loss_sum = torch.zeros((), device=self.device)
         nsteps = 0
+        on_dev = (self.flat_adam and self.fused_mlp and self.fused_loss and self.device.type == "cuda"
+                  and FusedMlpGrad.supported(self.policy, self.batch_size) and n % self.batch_size == 0)
+        self._on_dev = on_dev
+        if on_dev:
+            self._loss_acc.zero_()
+        if self._epoch_graph_ok(flat, n):
+            # one replay per epoch: the 32 x (gather + optimizer step) of an epoch are one captured hipGraph reading the
+            # permutation from a static buffer, so the host issues two calls per epoch instead of two per minibatch
+            eg = self._epoch_graph(flat, n)
+            for k in eg["flat"]:
+                eg["flat"][k].copy_(flat[k])
+            eg["loss"].zero_()
+            for _ in range(self.n_epochs):
+                torch.randperm(n, device=self.device, generator=generator, out=eg["perm"])
+                eg["graph"].replay()
+            nsteps = self.n_epochs * (n // self.batch_size)
+            acc = self._loss_acc if on_dev else torch.stack([eg["loss"], torch.full((), float(nsteps), device=self.device)])
+            self.stats["loss"] = float(acc[0] / torch.clamp(acc[1], min=1.0))
+            return self.stats["loss"]
         for _ in range(self.n_epochs):
             perm = torch.randperm(n, device=self.device, generator=generator)
             for s in range(0, n, self.batch_size):
@@ -729,9 +758,13 @@ class PPO:
                 else:
                     loss = self._minibatch_step(flat["obs"][idx].float(), flat["act"][idx].float(), flat["adv"][idx],
                                                 flat["ret"][idx], flat["logp"][idx])
-                loss_sum += loss
+                if not on_dev:
+                    loss_sum += loss
                 nsteps += 1
-        self.stats["loss"] = float(loss_sum / max(nsteps, 1))   # one host sync per train() call
+        if on_dev:      # dm_ppo_mlp_grad kept the sum on the device (loss_acc fold)
+            self.stats["loss"] = float(self._loss_acc[0] / torch.clamp(self._loss_acc[1], min=1.0))
+        else:
+            self.stats["loss"] = float(loss_sum / max(nsteps, 1))   # one host sync per train() call
         return self.stats["loss"]
 
     def _loss_torch(self, obs, act, adv, ret, old_logp):
@@ -767,14 +800,14 @@ class PPO:
         if (self.flat_adam and self.fused_mlp and self.fused_loss and obs.is_cuda
                 and FusedMlpGrad.supported(self.policy, obs.shape[0])):
             # the whole minibatch gradient in three launches, written into the flat arena
-            mg = getattr(self, "_mlp_grad", None)
-            if mg is None or mg.B != obs.shape[0]:
-                mg = self._mlp_grad = FusedMlpGrad(self.policy, self.optimizer, obs.shape[0])
-            self.optimizer.zero_grad()
+            # (that launch sequence also clears the arena, performs Adam's begin and adds the loss to a device-side sum)
+            mg = self._mlp_grads.get(obs.shape[0])
+            if mg is None:
+                mg = self._mlp_grads[obs.shape[0]] = FusedMlpGrad(self.policy, self.optimizer, obs.shape[0], loss_acc=self._loss_acc)
             loss = mg(obs.contiguous(), act.contiguous(), adv.contiguous(), ret.contiguous(), old_logp.contiguous(), self.clip_range,
                       self.vf_coef, self.ent_coef, self.normalize_advantage and obs.shape[0] > 1)
             self.optimizer.all_reduce()
-            self.optimizer.step()
+            self.optimizer.step(begin=False)
             return loss
         if self.flat_adam:
             # every gradient lands in one flat buffer (one memset), clipping + Adam are one fused update on it, and
@@ -800,45 +833,88 @@ class PPO:
         self.optimizer.step()
         return loss.detach()
 
+    def _gather_minibatch(self, flat, idx, g):
+        import ctypes as C
+        from . import _lib
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rc = _lib.load_library().dm_ppo_gather(
+            p(idx), int(idx.numel()), p(flat["obs"]), self.obs_dim, p(flat["act"]), flat["act"].shape[1], p(flat["adv"]),
+            p(flat["ret"]), p(flat["logp"]), p(g["obs"]), p(g["act"]), p(g["adv"]), p(g["ret"]), p(g["logp"]),
+            C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("dm_ppo_gather failed (%d)" % rc)
+
+    def _capture_with_restore(self, warm, body):
+        """Run ``warm`` three times on a side stream, capture ``body`` into a hipGraph, then put parameters and optimizer
+        state back: warm-up and capture must not change the model."""
+        dev = self.device
+        snap_p = [p.detach().clone() for p in self.policy.parameters()]
+        snap_o = {k: {kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in st.items()}
+                  for k, st in self.optimizer.state.items()}
+        had_state = len(self.optimizer.state) > 0
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                warm()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = body()
+        with torch.no_grad():
+            for p, q in zip(self.policy.parameters(), snap_p):
+                p.copy_(q)
+            for k, st in self.optimizer.state.items():
+                for kk, vv in st.items():
+                    if torch.is_tensor(vv):
+                        vv.copy_(snap_o[k][kk]) if had_state and k in snap_o else vv.zero_()
+            if self._loss_acc is not None:
+                self._loss_acc.zero_()          # the warm-up steps are not part of the statistics
+        return graph, out
+
+    def _static_minibatch(self):
+        B, dev = self.batch_size, self.device
+        return dict(obs=torch.zeros(B, self.obs_dim, device=dev), act=torch.zeros(B, 28, device=dev), adv=torch.zeros(B, device=dev),
+                    ret=torch.zeros(B, device=dev), logp=torch.zeros(B, device=dev))
+
+    def _epoch_graph_ok(self, flat, n):
+        return (self.use_hip_graph and self.device.type == "cuda" and n % self.batch_size == 0 and self.epoch_graph
+                and all(flat[k].dtype == torch.float32 for k in ("obs", "act", "adv", "ret", "logp")))
+
+    def _epoch_graph(self, flat, n):
+        eg = getattr(self, "_eg", None)
+        if eg is not None and eg["n"] == n:
+            return eg
+        dev, B = self.device, self.batch_size
+        eg = dict(n=n, perm=torch.arange(n, device=dev), loss=torch.zeros((), device=dev),
+                  flat={k: torch.zeros_like(flat[k]) for k in ("obs", "act", "adv", "ret", "logp")})
+        gin = self._static_minibatch()
+        kw = {("old_logp" if k == "logp" else k): v for k, v in gin.items()}
+
+        def warm():
+            self._gather_minibatch(eg["flat"], eg["perm"][:B], gin)
+            self._minibatch_step(**kw)
+
+        def body():
+            for s in range(0, n, B):
+                self._gather_minibatch(eg["flat"], eg["perm"][s:s + B], gin)
+                loss = self._minibatch_step(**kw)
+                if not self._on_dev:
+                    eg["loss"].add_(loss)
+
+        eg["graph"], _ = self._capture_with_restore(warm, body)
+        self._eg = eg
+        return eg
+
     def _graph_step(self, flat, idx):
         """Replay the captured optimizer step on static input buffers (capture on first use)."""
         if self._graph is None:
-            B, dev = self.batch_size, self.device
-            self._gin = dict(obs=torch.zeros(B, self.obs_dim, device=dev), act=torch.zeros(B, 28, device=dev),
-                             adv=torch.zeros(B, device=dev), ret=torch.zeros(B, device=dev),
-                             logp=torch.zeros(B, device=dev))
-            # warm-up iterations must not change the model: snapshot parameters and optimizer state
-            snap_p = [p.detach().clone() for p in self.policy.parameters()]
-            snap_o = {k: {kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in st.items()}
-                      for k, st in self.optimizer.state.items()}
-            had_state = len(self.optimizer.state) > 0
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    self._minibatch_step(**{("old_logp" if k == "logp" else k): v for k, v in self._gin.items()})
-            torch.cuda.current_stream(dev).wait_stream(side)
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
-                self._gloss = self._minibatch_step(**{("old_logp" if k == "logp" else k): v for k, v in self._gin.items()})
-            with torch.no_grad():
-                for p, q in zip(self.policy.parameters(), snap_p):
-                    p.copy_(q)
-                for k, st in self.optimizer.state.items():
-                    for kk, vv in st.items():
-                        if torch.is_tensor(vv):
-                            vv.copy_(snap_o[k][kk]) if had_state and k in snap_o else vv.zero_()
+            self._gin = self._static_minibatch()
+            kw = {("old_logp" if k == "logp" else k): v for k, v in self._gin.items()}
+            self._graph, self._gloss = self._capture_with_restore(lambda: self._minibatch_step(**kw), lambda: self._minibatch_step(**kw))
         g = self._gin
         if flat["obs"].dtype == torch.float32 and flat["act"].dtype == torch.float32 and idx.dtype == torch.int64:
-            import ctypes as C
-            from . import _lib
-            p = lambda t: C.c_void_p(t.data_ptr())
-            rc = _lib.load_library().dm_ppo_gather(
-                p(idx), int(idx.numel()), p(flat["obs"]), self.obs_dim, p(flat["act"]), flat["act"].shape[1], p(flat["adv"]),
-                p(flat["ret"]), p(flat["logp"]), p(g["obs"]), p(g["act"]), p(g["adv"]), p(g["ret"]), p(g["logp"]),
-                C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
-            if rc != 0:
-                raise RuntimeError("dm_ppo_gather failed (%d)" % rc)
+            self._gather_minibatch(flat, idx, g)
         else:  # bf16 rollout buffers (config 5): gather + widen with PyTorch ops
             g["obs"].copy_(flat["obs"][idx]); g["act"].copy_(flat["act"][idx])
             torch.index_select(flat["adv"], 0, idx, out=g["adv"])

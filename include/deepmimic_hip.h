@@ -190,6 +190,9 @@ int dm_ppo_gather(const long long *idx, int B, const float *obs, int D, const fl
  * the caller once); no weight decay, no amsgrad. */
 int dm_adam_clip_step(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
                       float max_norm, float *state2, void *stream);
+/* the same without the begin launch (state2 prepared by dm_ppo_mlp_grad's adam_state2 fold): two launches */
+int dm_adam_clip_update(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
+                        float max_norm, float *state2, void *stream);
 
 /* Rollout side of SB3's collect_rollouts [EXT] (driven by src/sb3_ppo.py:307-313), two launches per env step:
  * dm_policy_sample: act = mean + exp(log_std) * N(0,1) (counter-based generator: seed, env, counter[0], action index),
@@ -238,6 +241,11 @@ typedef struct DmPpoMlpStep {
   float *out8;
   float *workspace;
   long long workspace_floats;
+  /* optional folds (NULL / 0 to skip), each saving one launch of the optimizer step: */
+  float *zero_ptr;              /* zero_floats floats cleared by the first launch (the flat gradient arena that holds gW / gb / g_log_std) */
+  long long zero_floats;
+  float *adam_state2;           /* dm_adam_clip_step's begin (state2[0] = 0, state2[1] += 1): follow with dm_adam_clip_update */
+  float *loss_acc;              /* loss_acc[0] += loss, loss_acc[1] += 1 (running mean of the loss without a host-side add) */
 } DmPpoMlpStep;
 long long dm_ppo_mlp_workspace_floats(int B, int D, int H1, int H2, int A);
 int dm_ppo_mlp_grad(const DmPpoMlpStep *step, void *stream);

@@ -8,20 +8,19 @@ from deepmimic_mujoco_amd.ppo import PPO
 arch = tuple(int(x) for x in (sys.argv[1] if len(sys.argv) > 1 and "," in sys.argv[1] else "256,128").split(","))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 640
 dev = torch.device("cuda", 0)
-T, N = 8, 4096
+T, N = 32, 4096
 g = torch.Generator(device="cpu").manual_seed(0)
 buf = dict(obs=torch.randn(T, N, 67, generator=g), act=torch.randn(T, N, 28, generator=g), adv=torch.randn(T, N, generator=g),
            ret=torch.randn(T, N, generator=g), logp=-40 + torch.randn(T, N, generator=g))
 buf = {k: v.to(dev) for k, v in buf.items()}
-ppo = PPO(None, net_arch=arch, n_epochs=1, batch_size=4096, device=dev, fused_mlp="--no-fused-mlp" not in sys.argv)
-flat = {k: v.reshape(-1, *v.shape[2:]) for k, v in buf.items()}
-idx = torch.randperm(T * N, device=dev)[:4096]
-for _ in range(5):
-    ppo._graph_step(flat, idx)
+epochs = max(1, steps // T)
+ppo = PPO(None, net_arch=arch, n_epochs=epochs, batch_size=4096, device=dev, fused_mlp="--no-fused-mlp" not in sys.argv,
+          epoch_graph="--no-epoch-graph" not in sys.argv)
+ppo.train(buf)                       # capture
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(steps):
-    ppo._graph_step(flat, idx)
+ppo.train(buf)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print("arch %s: %.1f us per optimizer step (%d steps), loss %.5f" % (arch, dt / steps * 1e6, steps, float(ppo._gloss)))
+print("arch %s: %.1f us per optimizer step (%d steps, PPO.train of %d epochs x %d minibatches), loss %.5f" % (
+    arch, dt / (epochs * T) * 1e6, epochs * T, epochs, T, ppo.stats["loss"]))
