@@ -352,16 +352,23 @@ class HipDeepMimicVecEnv(_SB3VecEnv):
 
     def step_async(self, actions):
         t = self._torch
-        self._actions.copy_(t.as_tensor(np.asarray(actions), dtype=t.float32))
+        self._actions.copy_(t.as_tensor(np.ascontiguousarray(actions, dtype=np.float32)).reshape(self._actions.shape))
 
     def step_wait(self):
+        """numpy surface: the six outputs are packed into one [N, 2 obs + terms + 3] float32 device tensor (one small
+        kernel) and cross PCIe as ONE download + synchronisation (2.3 MB at 4 096 envs); CPU reads of ROCm's pinned
+        staging memory are uncached, so the download targets ordinary pageable memory."""
+        t = self._torch
         out = self.step_tensor(self._actions)
-        obs = out["obs"].cpu().numpy()
-        rew = out["rew"].cpu().numpy()
-        done = out["done"].cpu().numpy().astype(bool)
-        infos = LazyInfos(out["terms"].cpu().numpy(), out["reason"].cpu().numpy(), done,
-                          out["terminal_obs"].cpu().numpy())
-        return obs, rew, done, infos
+        packed = t.cat([out["obs"], out["terminal_obs"], out["terms"], out["rew"][:, None], out["done"][:, None].float(),
+                        out["reason"][:, None].float()], dim=1).cpu().numpy()
+        d, k = out["obs"].shape[1], out["terms"].shape[1]
+        obs, tobs, terms = (np.ascontiguousarray(packed[:, 0:d]), np.ascontiguousarray(packed[:, d:2 * d]),
+                            np.ascontiguousarray(packed[:, 2 * d:2 * d + k]))
+        rew = packed[:, 2 * d + k].copy()
+        done = packed[:, 2 * d + k + 1] != 0
+        reason = packed[:, 2 * d + k + 2].astype(np.int32)
+        return obs, rew, done, LazyInfos(terms, reason, done, tobs)
 
     def step(self, actions):
         self.step_async(actions)
