@@ -339,11 +339,16 @@ class HipCombinedVecEnv(_SB3VecEnv):
         self._actions.copy_(t.as_tensor(np.asarray(actions), dtype=t.float32))
 
     def step_wait(self):
+        # one packed download per step, as HipDeepMimicVecEnv.step_wait
+        t = self._torch
         out = self.step_tensor(self._actions)
-        done = out["done"].cpu().numpy().astype(bool)
-        infos = _LazyCombinedInfos(out["terms"].cpu().numpy(), out["reason"].cpu().numpy(), done,
-                                   out["terminal_obs"].cpu().numpy())
-        return out["obs"].cpu().numpy(), out["rew"].cpu().numpy(), done, infos
+        packed = t.cat([out["obs"], out["terminal_obs"], out["terms"], out["rew"][:, None], out["done"][:, None].float(),
+                        out["reason"][:, None].float()], dim=1).cpu().numpy()
+        d, k = out["obs"].shape[1], out["terms"].shape[1]
+        done = packed[:, 2 * d + k + 1] != 0
+        infos = _LazyCombinedInfos(np.ascontiguousarray(packed[:, 2 * d:2 * d + k]), packed[:, 2 * d + k + 2].astype(np.int32), done,
+                                   np.ascontiguousarray(packed[:, d:2 * d]))
+        return np.ascontiguousarray(packed[:, 0:d]), packed[:, 2 * d + k].copy(), done, infos
 
     def step(self, actions):
         self.step_async(actions)
