@@ -124,7 +124,6 @@ __global__ void __launch_bounds__(POL_THREADS) pol_forward_kernel(PolArgs a) {
     const bool ok = (b0 + row) < a.N;
     const float v = ok ? a.obs[(size_t)b0 * a.D + i] : 0.f;
     xs[row * sx + c] = v;
-    if (trunk == 0 && a.obs_copy && ok) a.obs_copy[(size_t)b0 * a.D + i] = v;
   }
   for (int i = tid; i < POL_R * (a.Dp - a.D); i += POL_THREADS) {
     const int row = i / (a.Dp - a.D), c = a.D + i - row * (a.Dp - a.D);
@@ -190,6 +189,12 @@ __global__ void __launch_bounds__(POL_THREADS) pol_forward_kernel(PolArgs a) {
   if (trunk == 1) {
     if (tid < POL_R && (b0 + tid) < a.N)
       a.val[b0 + tid] = red[tid * 32] + red[1024 + tid * 32] + red[2048 + tid * 32] + red[3072 + tid * 32] + a.b3[1][0];
+    // the observation copy for the rollout buffer, at the very end of the (lighter) value workgroup: a global store followed by
+    // loads makes the compiler wait for the write acknowledgement (possible alias), which at the top of the kernel would
+    // sit in front of the first weight loads
+    if (a.obs_copy)
+      for (int i = tid; i < POL_R * a.D; i += POL_THREADS)
+        if ((b0 + i / a.D) < a.N) a.obs_copy[(size_t)b0 * a.D + i] = a.obs[(size_t)b0 * a.D + i];
     return;
   }
   // eight threads per row, two action pairs each (A <= 32): same draws as ppo_sample_kernel (seed, env, counter, index)

@@ -58,6 +58,7 @@ struct MlpTrainArgs {
   const float4 *pkF[2], *pkW2T[2], *pkW3T[2];
   const float *b1[2], *b2[2], *b3[2];
   float *h1g[2], *h2g[2], *dz1g[2], *dz2g[2], *d3g[2];
+  float *part;                      // [2][B / 32][36] per-workgroup loss / log-std partial sums (summed by mlp_wgrad_kernel's epilogue)
   const float *stats;
   float *out8, *g_log_std;
   float clip, vf_coef;
@@ -66,6 +67,14 @@ struct MlpTrainArgs {
 // Eight waves per workgroup (two per SIMD): one wave's weight-stream latency, tanh and stores run under the other's
 // MFMAs (with four waves the kernel spent a third of its time in MFMA and as much waiting on loads, nothing overlapping).
 constexpr int MLP_NW = 8, MLP_THREADS = 64 * MLP_NW;
+
+// -DMLP_PROFILE (diagnostic build only, scripts/phase_profile_learner.py): s_memtime stamps of workgroup (0, 0) per wave and phase
+#ifdef MLP_PROFILE
+__device__ long long mlp_prof_buf[MLP_NW * 16];
+#define MLP_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) mlp_prof_buf[wave * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MLP_STAMP(i) do { } while (0)
+#endif
 
 __global__ void __launch_bounds__(MLP_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a) {
   extern __shared__ __align__(16) float mlp_lds[];
@@ -84,7 +93,7 @@ __global__ void __launch_bounds__(MLP_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
   const float4 *P2 = P1 + (size_t)T1 * KB1 * 64;
   const float4 *P3 = P2 + (size_t)T2 * KB2 * 64;
   const int r = lane & 31, h = lane >> 5;
-
+  MLP_STAMP(0);
   for (int i = tid; i < POL_R * a.D; i += MLP_THREADS) {
     const int row = i / a.D, c = i - row * a.D;
     xs[row * sx + c] = a.obs[(size_t)b0 * a.D + i];
@@ -94,7 +103,9 @@ __global__ void __launch_bounds__(MLP_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
     xs[row * sx + c] = 0.f;
   }
   if (tid < 36) accs[tid] = 0.f;
+  MLP_STAMP(1);
   __syncthreads();
+  MLP_STAMP(2);
 
   // ---- forward layer 1: one tile per wave (activations to LDS, and to HBM for the weight gradients)
   for (int to = wave; to < T1; to += MLP_NW) {
@@ -108,10 +119,11 @@ __global__ void __launch_bounds__(MLP_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
       const int row = (j >> 2) * 8 + h * 4 + (j & 3);
       const float v = mlp_tanh(acc[j] + b);
       h1[row * s1 + to * 32 + r] = v;
-      a.h1g[trunk][(size_t)(b0 + row) * a.H1 + to * 32 + r] = v;
     }
   }
+  MLP_STAMP(3);
   __syncthreads();
+  MLP_STAMP(4);
   // ---- forward layer 2: a tile is shared by two waves (K halves; KB2 = H1 / 8 is even), the odd wave hands its partial
   // sums over through LDS
   for (int base = 0; base < 2 * T2; base += MLP_NW) {
@@ -136,11 +148,12 @@ __global__ void __launch_bounds__(MLP_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
         const int row = (j >> 2) * 8 + h * 4 + (j & 3);
         const float v = mlp_tanh(acc[j] + red[tile * 1024 + j * 64 + lane] + b);
         h2[row * s2 + tile * 32 + r] = v;
-        a.h2g[trunk][(size_t)(b0 + row) * a.H2 + tile * 32 + r] = v;
       }
     }
   }
+  MLP_STAMP(5);
   __syncthreads();
+  MLP_STAMP(6);
   // ---- forward layer 3: split-K over the waves
   {
     pol_f16v acc3;
@@ -155,7 +168,9 @@ __global__ void __launch_bounds__(MLP_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
       red[wave * 1024 + row * 32 + r] = acc3[j];
     }
   }
+  MLP_STAMP(7);
   __syncthreads();
+  MLP_STAMP(8);
 
   // ---- loss head: eight threads per row (same formulas as ppo_loss_kernel), waves 0..3
   if (tid < 256) {
@@ -195,10 +210,7 @@ __global__ void __launch_bounds__(MLP_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
         const int c = q + 8 * s;
         const float g = dlogp * dd[s] * iv[s];               // 0 for c >= A
         d3[row * s3 + c] = g;
-        if (c < a.A) {
-          a.d3g[0][(size_t)b * a.A + c] = g;
-          atomicAdd(&accs[4 + c], dlogp * (z2[s] - 1.f));
-        }
+        if (c < a.A) atomicAdd(&accs[4 + c], dlogp * (z2[s] - 1.f));
       }
       if (q == 0) {
         atomicAdd(&accs[0], -fminf(p1, p2));
@@ -216,24 +228,12 @@ __global__ void __launch_bounds__(MLP_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
         const int c = q + 8 * s;
         d3[row * s3 + c] = (c == 0) ? g : 0.f;
       }
-      if (q == 0) {
-        a.d3g[1][b] = g;
-        atomicAdd(&accs[1], dv * dv);
-      }
+      if (q == 0) atomicAdd(&accs[1], dv * dv);
     }
   }
+  MLP_STAMP(9);
   __syncthreads();
-  {
-    const float invB = 1.0f / (float)a.B;
-    if (trunk == 0) {
-      if (tid == 0) atomicAdd(&a.out8[1], accs[0] * invB);
-      else if (tid == 2) atomicAdd(&a.out8[4], accs[2] * invB);
-      else if (tid == 3) atomicAdd(&a.out8[5], accs[3] * invB);
-      else if (tid >= 4 && tid < 4 + a.A) atomicAdd(&a.g_log_std[tid - 4], accs[tid]);
-    } else if (tid == 1) {
-      atomicAdd(&a.out8[2], accs[1] * invB);
-    }
-  }
+  MLP_STAMP(10);
 
   // ---- backward: dZ2 = (d3 W3) (1 - h2^2), dZ1 = (dZ2 W2) (1 - h1^2)
   for (int to = wave; to < T2; to += MLP_NW) {
@@ -241,28 +241,58 @@ __global__ void __launch_bounds__(MLP_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
 #pragma unroll
     for (int j = 0; j < 16; j++) acc[j] = 0.f;
     pol_tile<4>(d3, s3, a.pkW3T[trunk] + (size_t)to * 4 * 64, lane, 0, 4, acc);
+    float hv[16];                       // all sixteen LDS reads in flight before the first use
+#pragma unroll
+    for (int j = 0; j < 16; j++) hv[j] = h2[((j >> 2) * 8 + h * 4 + (j & 3)) * s2 + to * 32 + r];
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const int row = (j >> 2) * 8 + h * 4 + (j & 3);
-      const float hv = h2[row * s2 + to * 32 + r];
-      const float g = acc[j] * (1.f - hv * hv);
+      const float g = acc[j] * (1.f - hv[j] * hv[j]);
       dz2[row * s2 + to * 32 + r] = g;
-      a.dz2g[trunk][(size_t)(b0 + row) * a.H2 + to * 32 + r] = g;
     }
   }
+  MLP_STAMP(11);
   __syncthreads();
+  MLP_STAMP(12);
   for (int to = wave; to < T1; to += MLP_NW) {
     pol_f16v acc;
 #pragma unroll
     for (int j = 0; j < 16; j++) acc[j] = 0.f;
     pol_tile<8>(dz2, s2, a.pkW2T[trunk] + (size_t)to * KB3 * 64, lane, 0, KB3, acc);
+    float hv[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) hv[j] = h1[((j >> 2) * 8 + h * 4 + (j & 3)) * s1 + to * 32 + r];
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const int row = (j >> 2) * 8 + h * 4 + (j & 3);
-      const float hv = h1[row * s1 + to * 32 + r];
-      a.dz1g[trunk][(size_t)(b0 + row) * a.H1 + to * 32 + r] = acc[j] * (1.f - hv * hv);
+      a.dz1g[trunk][(size_t)(b0 + row) * a.H1 + to * 32 + r] = acc[j] * (1.f - hv[j] * hv[j]);
     }
   }
+  // ---- everything that writes global memory besides dZ1 comes last.  A global store or atomic followed by a load makes the
+  // compiler wait for the write's acknowledgement (s_waitcnt vmcnt(0): the addresses might alias), and the loss / log-std
+  // sums are written as per-workgroup partials: in the middle of the kernel (as atomics) that wait was 10 k cycles
+  // in front of the backward weight loads, and 1-2 k at the head of every other phase (stamps of -DMLP_PROFILE).
+  {
+    const int q1 = a.H1 >> 2, q2 = a.H2 >> 2;
+    for (int i = tid; i < POL_R * q1; i += MLP_THREADS) {
+      const int row = i / q1, c = (i - row * q1) * 4;
+      *reinterpret_cast<float4 *>(a.h1g[trunk] + (size_t)(b0 + row) * a.H1 + c) = *reinterpret_cast<const float4 *>(h1 + row * s1 + c);
+    }
+    for (int i = tid; i < POL_R * q2; i += MLP_THREADS) {
+      const int row = i / q2, c = (i - row * q2) * 4;
+      *reinterpret_cast<float4 *>(a.h2g[trunk] + (size_t)(b0 + row) * a.H2 + c) = *reinterpret_cast<const float4 *>(h2 + row * s2 + c);
+      *reinterpret_cast<float4 *>(a.dz2g[trunk] + (size_t)(b0 + row) * a.H2 + c) = *reinterpret_cast<const float4 *>(dz2 + row * s2 + c);
+    }
+    const int A3 = trunk == 0 ? a.A : 1;
+    for (int i = tid; i < POL_R * A3; i += MLP_THREADS) {
+      const int row = i / A3, c = i - row * A3;
+      a.d3g[trunk][(size_t)(b0 + row) * A3 + c] = d3[row * s3 + c];
+    }
+    // per-workgroup partial sums, plain stores: 256 workgroups adding to the same two cache lines with atomics queued for
+    // ~10 k cycles at the L2 (and a wave cannot retire before its atomics are acknowledged)
+    if (tid < 36) a.part[((size_t)trunk * gridDim.x + blockIdx.x) * 36 + tid] = accs[tid];
+  }
+  MLP_STAMP(13);
 }
 
 // Weight / bias gradients of all six layers in one launch.  A workgroup of four waves owns a rectangle of 2 x 2 output
@@ -275,23 +305,50 @@ struct MlpWgradJob { const float *dY, *X; float *dW, *db; int O, I, nro, nri, kc
 struct MlpWgradArgs {
   MlpWgradJob j[6];
   int B, nblocks;                   // block nblocks (the last one) finishes the loss scalar and the entropy gradient
-  const float *log_std, *stats; float *g_log_std, *out8, *loss_acc; int A; float vf_coef, ent_coef;
+  const float *log_std, *stats, *part; float *g_log_std, *out8, *loss_acc; int A, nwg; float vf_coef, ent_coef;
 };
 
 __global__ void __launch_bounds__(256, 2) mlp_wgrad_kernel(MlpWgradArgs a) {
   __shared__ __align__(16) float part[4][4][1024];       // [wave][tile][32 x 32]
   const int blk = blockIdx.x;
   if (blk == a.nblocks) {
-    if (threadIdx.x == 0) {
+    // loss epilogue: sum the per-workgroup partials of mlp_fwdbwd_kernel (thread q < 36 owns quantity q: 0 pg (pi), 1 vl (vf),
+    // 2 kl, 3 clip fraction, 4.. d loss / d log_std), then the loss scalar and the entropy term
+    float *tot = &part[0][0][0];
+    const int q = threadIdx.x;
+    {
+      // 252 = 7 x 36 threads: thread t sums quantity t % 36 over the workgroups w = t / 36, t / 36 + 7, ... (independent loads)
+      const int col = q % 36, grp = q / 36;
+      float t = 0.f;
+      if (q < 252) {
+        const float *p = a.part + (size_t)(col == 1 ? a.nwg : 0) * 36 + col;
+        for (int w = grp; w < a.nwg; w += 7) t += p[(size_t)w * 36];
+        tot[64 + q] = t;
+      }
+      __syncthreads();
+      if (q < 36) {
+        float u = 0.f;
+#pragma unroll
+        for (int g = 0; g < 7; g++) u += tot[64 + g * 36 + q];
+        tot[q] = u;
+      }
+    }
+    __syncthreads();
+    const float invB = 1.0f / (float)a.B;
+    if (q >= 4 && q < 4 + a.A) atomicAdd(&a.g_log_std[q - 4], tot[q] - a.ent_coef);
+    if (q == 0) {
       float ent = 0;
       for (int j = 0; j < a.A; j++) ent += 0.5f + 0.5f * 1.8378770664093453f + a.log_std[j];
+      a.out8[1] = tot[0] * invB;
+      a.out8[2] = tot[1] * invB;
+      a.out8[4] = tot[2] * invB;
+      a.out8[5] = tot[3] * invB;
       a.out8[3] = ent;
       a.out8[0] = a.out8[1] + a.vf_coef * a.out8[2] - a.ent_coef * ent;
       a.out8[6] = a.stats[0];
       a.out8[7] = a.stats[1];
       if (a.loss_acc) { a.loss_acc[0] += a.out8[0]; a.loss_acc[1] += 1.f; }
     }
-    if ((int)threadIdx.x < a.A && a.ent_coef != 0.f) atomicAdd(&a.g_log_std[threadIdx.x], -a.ent_coef);
     return;
   }
   int q = 0;
@@ -397,7 +454,7 @@ inline MlpWsLayout mlp_layout(int B, int D, int H1, int H2, int A) {
   L.dz2 = o;   o += (size_t)B * H2;
   L.d3 = o;    o += (size_t)B * 32;
   L.per_trunk = (o + 3) & ~(size_t)3;
-  L.total = 2 * L.per_trunk + 8;     // + advantage statistics
+  L.total = 2 * L.per_trunk + 8 + 2 * (size_t)(B / 32) * 36;     // + advantage statistics + per-workgroup loss partials
   return L;
 }
 
@@ -469,6 +526,7 @@ extern "C" int dm_ppo_mlp_grad(const DmPpoMlpStep *s, void *stream) {
     ta.b1[t] = s->b[t][0]; ta.b2[t] = s->b[t][1]; ta.b3[t] = s->b[t][2];
     ta.h1g[t] = ws + L.h1; ta.h2g[t] = ws + L.h2; ta.dz1g[t] = ws + L.dz1; ta.dz2g[t] = ws + L.dz2; ta.d3g[t] = ws + L.d3;
   }
+  ta.part = stats + 8;
   ta.stats = stats; ta.out8 = s->out8; ta.g_log_std = s->g_log_std; ta.clip = s->clip_range; ta.vf_coef = s->vf_coef;
   hipLaunchKernelGGL(mlp_fwdbwd_kernel, dim3(B / POL_R, 2), dim3(MLP_THREADS), lds, st, ta);
 
@@ -492,8 +550,14 @@ extern "C" int dm_ppo_mlp_grad(const DmPpoMlpStep *s, void *stream) {
     add_wg(ws + L.dz2, ws + L.h1, s->gW[t][1], s->gb[t][1], H2, H1);
     add_wg(ws + L.d3, ws + L.h2, s->gW[t][2], s->gb[t][2], Aout, H2);
   }
-  wa.B = B; wa.nblocks = nw; wa.log_std = s->log_std; wa.stats = stats; wa.g_log_std = s->g_log_std; wa.out8 = s->out8; wa.loss_acc = s->loss_acc; wa.A = A;
+  wa.B = B; wa.nblocks = nw; wa.log_std = s->log_std; wa.stats = stats; wa.g_log_std = s->g_log_std; wa.out8 = s->out8; wa.loss_acc = s->loss_acc; wa.A = A; wa.part = stats + 8; wa.nwg = B / POL_R;
   wa.vf_coef = s->vf_coef; wa.ent_coef = s->ent_coef;
   hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(nw + 1), dim3(256), 0, st, wa);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
+
+#ifdef MLP_PROFILE
+extern "C" int dm_ppo_mlp_prof(long long *host128) {
+  return hipMemcpyFromSymbol(host128, HIP_SYMBOL(mlp_prof_buf), sizeof(long long) * MLP_NW * 16) == hipSuccess ? 0 : -5;
+}
+#endif

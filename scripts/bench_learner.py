@@ -1,5 +1,5 @@
-"""Optimizer step of the PPO learner alone (captured hipGraph, replayed): us per 4096-row minibatch step.
-usage: python scripts/bench_learner.py [H1,H2] [steps] [--no-fused-mlp]"""
+"""Optimizer step of the PPO learner alone (captured hipGraph, replayed): us per minibatch step.
+usage: python scripts/bench_learner.py [H1,H2] [steps] [--no-fused-mlp] [--no-epoch-graph] [--mb=4096]"""
 import sys, time
 import torch
 sys.path.insert(0, ".")
@@ -8,13 +8,14 @@ from deepmimic_mujoco_amd.ppo import PPO
 arch = tuple(int(x) for x in (sys.argv[1] if len(sys.argv) > 1 and "," in sys.argv[1] else "256,128").split(","))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 640
 dev = torch.device("cuda", 0)
-T, N = 32, 4096
+MB = int([a for a in sys.argv if a.startswith("--mb=")][0][5:]) if any(a.startswith("--mb=") for a in sys.argv) else 4096
+T, N = 32, MB
 g = torch.Generator(device="cpu").manual_seed(0)
 buf = dict(obs=torch.randn(T, N, 67, generator=g), act=torch.randn(T, N, 28, generator=g), adv=torch.randn(T, N, generator=g),
            ret=torch.randn(T, N, generator=g), logp=-40 + torch.randn(T, N, generator=g))
 buf = {k: v.to(dev) for k, v in buf.items()}
 epochs = max(1, steps // T)
-ppo = PPO(None, net_arch=arch, n_epochs=epochs, batch_size=4096, device=dev, fused_mlp="--no-fused-mlp" not in sys.argv,
+ppo = PPO(None, net_arch=arch, n_epochs=epochs, batch_size=MB, device=dev, fused_mlp="--no-fused-mlp" not in sys.argv,
           epoch_graph="--no-epoch-graph" not in sys.argv)
 ppo.train(buf)                       # capture
 torch.cuda.synchronize()
