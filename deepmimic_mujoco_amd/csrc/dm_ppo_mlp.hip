@@ -4,14 +4,17 @@
 // evaluate_actions (both trunks), the clipped-surrogate / value / entropy loss, backward through both trunks.  With
 // PyTorch this is ~40 graph nodes of ~5 us (library GEMMs of 4096 x 256 x 128, elementwise tanh backward, the loss
 // kernels): the optimizer step of the reference's net is launch-bound at 0.22 ms.  Here:
-//   1. mlp_pack_kernel   weights -> MFMA operand order (forward and transposed), advantage statistics      (1 launch)
-//   2. mlp_fwdbwd_kernel a workgroup of four waves carries 32 minibatch rows of one trunk through the forward, the
+//   1. mlp_pack_kernel   weights -> MFMA operand order (forward and transposed), advantage statistics; optional folds:
+//                        clearing the gradient arena, Adam's begin                                             (1 launch)
+//   2. mlp_fwdbwd_kernel a workgroup of eight waves carries 32 minibatch rows of one trunk through the forward, the
 //                        loss head (same arithmetic as ppo_loss_kernel) and the input-gradient chain; activations and
-//                        pre-activation gradients stay in LDS and are written once to HBM for step 3           (1 launch)
-//   3. mlp_wgrad_kernel  dW = dZ^T X, db = sum dZ for all six layers: one wave per 32 x 32 tile and batch slice
-//                        (split-K, float atomics), plus the loss scalar / entropy-gradient epilogue            (1 launch)
+//                        pre-activation gradients stay in LDS and go to HBM in one copy-out at the very end, with the
+//                        workgroup's loss / log-std partial sums (no global write before the last load)        (1 launch)
+//   3. mlp_wgrad_kernel  dW = dZ^T X, db = sum dZ for all six layers: a workgroup per 64 x 64 rectangle of dW and batch
+//                        slice, four waves splitting the slice, LDS reduction, split-K 8 over workgroups with float
+//                        atomics; one extra block sums the loss partials (loss scalar, entropy gradient)        (1 launch)
 // All products are v_mfma_f32_32x32x2f32 (fp32 in, fp32 accumulate).  Gradients are ACCUMULATED into caller-owned
-// buffers (zeroed by the caller on the same stream: the optimizer's flat gradient arena, one memset).
+// buffers that must be zero on entry (the optimizer's flat gradient arena: pass it as zero_ptr, or clear it on the stream).
 // Included by dm_abi.hip after dm_ppo.hip and dm_policy.hip (uses their device helpers).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
