@@ -43,14 +43,28 @@ class _HipLinearFn(torch.autograd.Function):
         gx = gy @ w if ctx.needs_input_grad[0] else None
         gy = gy.contiguous()
         arena = getattr(ctx.mod, "_grad_arena", None)    # (gw, gb) views of one flat buffer zeroed once per step
+        p = lambda t: C.c_void_p(t.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        L = _lib.load_library()
+        if max(w.shape) > 256:
+            # layers beyond 256 units: dW on the library GEMM, written straight into the arena (no autograd-owned gradient, so
+            # no copy into the flat buffer afterwards), db by dm_colsum
+            if arena is not None:
+                gw, gb = arena
+                torch.mm(gy.t(), x, out=gw)
+            else:
+                gw = gy.t() @ x
+                gb = torch.zeros(w.shape[0], device=w.device, dtype=w.dtype)
+            rc = L.dm_colsum(p(gy), x.shape[0], w.shape[0], p(gb), stream)
+            if rc != 0:
+                raise RuntimeError("dm_colsum failed (%d)" % rc)
+            return (gx, None, None, None) if arena is not None else (gx, gw, gb, None)
         if arena is not None:
             gw, gb = arena
         else:
             gw = torch.zeros_like(w)
             gb = torch.zeros(w.shape[0], device=w.device, dtype=w.dtype)
-        p = lambda t: C.c_void_p(t.data_ptr())
-        rc = _lib.load_library().dm_linear_wgrad(p(gy), p(x), p(gw), p(gb), x.shape[0], w.shape[0], w.shape[1],
-                                                 C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        rc = L.dm_linear_wgrad(p(gy), p(x), p(gw), p(gb), x.shape[0], w.shape[0], w.shape[1], stream)
         if rc != 0:
             raise RuntimeError("dm_linear_wgrad failed (%d)" % rc)
         if arena is not None:
@@ -61,12 +75,13 @@ class _HipLinearFn(torch.autograd.Function):
 
 
 class HipLinear(nn.Linear):
-    """nn.Linear whose weight / bias gradients come from the hand-written kernel when the batch is a large CUDA
-    minibatch (the optimizer step of the reference's [256,128] net is bound by the library's K = 4096 GEMMs)."""
+    """nn.Linear whose weight / bias gradients bypass autograd's generic kernels when the batch is a large CUDA minibatch:
+    layers up to 256 x 256 on `dm_linear_wgrad` (the library's K = 4096 GEMMs into tiny outputs take 25 us each), larger ones
+    on the library GEMM + `dm_colsum`, all written straight into the optimizer's flat gradient arena."""
 
     def forward(self, x):
         if (x.is_cuda and x.dim() == 2 and x.shape[0] >= 1024 and x.shape[0] % 64 == 0 and x.dtype == torch.float32
-                and x.is_contiguous() and torch.is_grad_enabled() and max(self.weight.shape) <= 256):
+                and x.is_contiguous() and torch.is_grad_enabled()):
             return _HipLinearFn.apply(x, self.weight, self.bias, self)
         return super().forward(x)
 

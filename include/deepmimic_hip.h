@@ -194,6 +194,10 @@ int dm_adam_clip_step(float *p, const float *g, float *m, float *v, int n, float
 int dm_adam_clip_update(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
                         float max_norm, float *state2, void *stream);
 
+/* out[o] += sum_b Y[b][o] for a row-major [B x O] matrix (out zeroed by the caller, stream-ordered): the bias gradient of the
+ * nn.Linear layers of PPO.train [EXT] whose weight gradient stays on the library GEMM (layers beyond 256 units). */
+int dm_colsum(const float *Y, int B, int O, float *out, void *stream);
+
 /* Rollout side of SB3's collect_rollouts [EXT] (driven by src/sb3_ppo.py:307-313), two launches per env step:
  * dm_policy_sample: act = mean + exp(log_std) * N(0,1) (counter-based generator: seed, env, counter[0], action index),
  *   logp of the diagonal Gaussian, act_env = clamp(act, lo, hi) (what DPEnv.step receives);

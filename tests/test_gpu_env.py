@@ -375,7 +375,8 @@ def test_hip_linear_wgrad_matches_torch():
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     for B in (4096, 2048, 1024):
-        for (I, O) in ((67, 256), (256, 128), (128, 28), (128, 1), (72, 256), (200, 96)):
+        # the last three shapes are beyond 256 units: library GEMM for dW, dm_colsum for db
+        for (I, O) in ((67, 256), (256, 128), (128, 28), (128, 1), (72, 256), (200, 96), (67, 1024), (1024, 512), (512, 28)):
             lin = HipLinear(I, O).to(dev)
             x = torch.randn(B, I, device=dev, requires_grad=True)
             gy = torch.randn(B, O, device=dev)
@@ -387,6 +388,28 @@ def test_hip_linear_wgrad_matches_torch():
             assert float((gw - ref_w).abs().max()) < 2e-4 * sw, (B, I, O)
             assert float((gb - ref_b).abs().max()) < 2e-4 * float(ref_b.abs().max() + 1), (B, I, O)
             assert torch.allclose(gx, ref_x, rtol=1e-4, atol=1e-4)
+
+
+def test_big_net_learner_step_matches_plain_autograd():
+    """[1024,512]: the arena path (library GEMM written into the flat gradient buffer + dm_colsum, fused loss, flat Adam,
+    value trunk on a second stream) gives the same parameters after three optimizer steps as plain autograd + torch Adam."""
+    import torch
+    from deepmimic_mujoco_amd.ppo import PPO
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    B = 4096
+    obs, act = torch.randn(B, 67, generator=g).to(dev), torch.randn(B, 28, generator=g).to(dev)
+    adv, ret, lp = torch.randn(B, generator=g).to(dev), torch.randn(B, generator=g).to(dev), (-40 + torch.randn(B, generator=g)).to(dev)
+    res = []
+    for fast in (True, False):
+        q = PPO(None, net_arch=(1024, 512), batch_size=B, device=dev, use_hip_graph=False, seed=4, fused_loss=fast, flat_adam=fast,
+                two_stream=fast)
+        for _ in range(3):
+            q._minibatch_step(obs, act, adv, ret, lp)
+        torch.cuda.synchronize()
+        res.append(torch.cat([p.detach().reshape(-1) for p in q.policy.parameters()]))
+    assert torch.isfinite(res[0]).all()
+    assert torch.allclose(res[0], res[1], rtol=2e-4, atol=5e-6), float((res[0] - res[1]).abs().max())
 
 
 def test_flat_adam_matches_clip_grad_norm_plus_torch_adam():
