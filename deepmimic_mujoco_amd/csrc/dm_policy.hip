@@ -69,15 +69,30 @@ __device__ __forceinline__ void pol_mfma(const float4 (&w)[U], const float4 (&a)
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, w[u].w, acc, 0, 0, 0);
   }
 }
+// first weight batch of a tile, issued early (before the barrier that publishes the tile's activations: the weight
+// stream does not depend on them), consumed by pol_tile_pre
 template <int U>
-__device__ __forceinline__ void pol_tile(const float *xs, int sx, const float4 *P, int lane, int kb0, int kb1, pol_f16v &acc) {
+__device__ __forceinline__ void pol_prefetch(const float4 *P, int lane, int kb0, float4 (&w)[U]) {
+#pragma unroll
+  for (int u = 0; u < U; u++) w[u] = P[(size_t)(kb0 + u) * 64 + lane];
+}
+template <int U, bool PRE>
+__device__ __forceinline__ void pol_tile_impl(const float *xs, int sx, const float4 *P, int lane, int kb0, int kb1, pol_f16v &acc,
+                                              float4 (&wA)[U]) {
   const float *xrow = xs + (lane & 31) * sx + 4 * (lane >> 5);
   const float4 *p = P + lane;
   const int nb = (kb1 - kb0) / U;
   // ping-pong over two register sets (no copies): the loads of batch it + 1 are in flight under the 4 U MFMAs of batch
   // it, and the MFMAs wait only for their own batch (s_waitcnt vmcnt(U))
-  float4 wA[U], aA[U], wB[U], aB[U];
-  if (nb > 0) pol_load<U>(p, xrow, kb0, wA, aA);
+  float4 aA[U], wB[U], aB[U];
+  if (nb > 0) {
+    if (PRE) {
+#pragma unroll
+      for (int u = 0; u < U; u++) aA[u] = *reinterpret_cast<const float4 *>(xrow + (kb0 + u) * 8);
+    } else {
+      pol_load<U>(p, xrow, kb0, wA, aA);
+    }
+  }
   int it = 0;
   for (; it + 2 <= nb; it += 2) {
     pol_load<U>(p, xrow, kb0 + (it + 1) * U, wB, aB);
@@ -94,6 +109,17 @@ __device__ __forceinline__ void pol_tile(const float *xs, int sx, const float4 *
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc, 0, 0, 0);
   }
+}
+template <int U>
+__device__ __forceinline__ void pol_tile(const float *xs, int sx, const float4 *P, int lane, int kb0, int kb1, pol_f16v &acc) {
+  float4 wA[U];
+  pol_tile_impl<U, false>(xs, sx, P, lane, kb0, kb1, acc, wA);
+}
+// the first batch's weights (kb0 .. kb0 + U - 1; requires kb1 - kb0 >= U) were fetched by pol_prefetch<U>
+template <int U>
+__device__ __forceinline__ void pol_tile_pre(const float *xs, int sx, const float4 *P, int lane, int kb0, int kb1, pol_f16v &acc,
+                                             float4 (&wpre)[U]) {
+  pol_tile_impl<U, true>(xs, sx, P, lane, kb0, kb1, acc, wpre);
 }
 
 // hs[row][o0 + r] = tanh(acc + bias)

@@ -97,6 +97,14 @@ __global__ void __launch_bounds__(MLP_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
   const float4 *P3 = P2 + (size_t)T2 * KB2 * 64;
   const int r = lane & 31, h = lane >> 5;
   MLP_STAMP(0);
+  // every phase's first weight batch is requested before the barrier / staging work that precedes the phase (no global
+  // write precedes it any more, so nothing holds the request back)
+  float4 w1pre[9];                          // D = 67 / 72: the nine k-blocks are the whole layer-1 tile
+  const bool pre1 = wave < T1 && KB1 >= 9;
+  if (pre1) pol_prefetch<9>(P1 + (size_t)wave * KB1 * 64, lane, 0, w1pre);
+  // the biases of this wave's first tiles too (a load at the top of an epilogue is one more exposed round trip)
+  const float b1pre = wave < T1 ? a.b1[trunk][wave * 32 + r] : 0.f;
+  const float b2pre = (wave >> 1) < T2 ? a.b2[trunk][(wave >> 1) * 32 + r] : 0.f;
   for (int i = tid; i < POL_R * a.D; i += MLP_THREADS) {
     const int row = i / a.D, c = i - row * a.D;
     xs[row * sx + c] = a.obs[(size_t)b0 * a.D + i];
@@ -115,8 +123,9 @@ __global__ void __launch_bounds__(MLP_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
     pol_f16v acc;
 #pragma unroll
     for (int j = 0; j < 16; j++) acc[j] = 0.f;
-    pol_tile<3>(xs, sx, P1 + (size_t)to * KB1 * 64, lane, 0, KB1, acc);
-    const float b = a.b1[trunk][to * 32 + r];
+    if (pre1 && to == wave) pol_tile_pre<9>(xs, sx, P1 + (size_t)to * KB1 * 64, lane, 0, KB1, acc, w1pre);
+    else pol_tile<3>(xs, sx, P1 + (size_t)to * KB1 * 64, lane, 0, KB1, acc);
+    const float b = to == wave ? b1pre : a.b1[trunk][to * 32 + r];
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const int row = (j >> 2) * 8 + h * 4 + (j & 3);
@@ -124,6 +133,9 @@ __global__ void __launch_bounds__(MLP_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
       h1[row * s1 + to * 32 + r] = v;
     }
   }
+  float4 w2pre[8];
+  const bool pre2 = wave < 2 * T2 && (KB2 >> 1) >= 8;
+  if (pre2) pol_prefetch<8>(P2 + (size_t)(wave >> 1) * KB2 * 64, lane, (wave & 1) * (KB2 >> 1), w2pre);
   MLP_STAMP(3);
   __syncthreads();
   MLP_STAMP(4);
@@ -137,7 +149,8 @@ __global__ void __launch_bounds__(MLP_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
     for (int j = 0; j < 16; j++) acc[j] = 0.f;
     if (on) {
       const int kh = KB2 >> 1;
-      pol_tile<8>(h1, s1, P2 + (size_t)tile * KB2 * 64, lane, half * kh, (half + 1) * kh, acc);
+      if (pre2 && base == 0) pol_tile_pre<8>(h1, s1, P2 + (size_t)tile * KB2 * 64, lane, half * kh, (half + 1) * kh, acc, w2pre);
+      else pol_tile<8>(h1, s1, P2 + (size_t)tile * KB2 * 64, lane, half * kh, (half + 1) * kh, acc);
       if (half) {
 #pragma unroll
         for (int j = 0; j < 16; j++) red[tile * 1024 + j * 64 + lane] = acc[j];
@@ -145,7 +158,7 @@ __global__ void __launch_bounds__(MLP_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
     }
     __syncthreads();
     if (on && !half) {
-      const float b = a.b2[trunk][tile * 32 + r];
+      const float b = base == 0 ? b2pre : a.b2[trunk][tile * 32 + r];
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         const int row = (j >> 2) * 8 + h * 4 + (j & 3);
@@ -254,6 +267,9 @@ __global__ void __launch_bounds__(MLP_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
       dz2[row * s2 + to * 32 + r] = g;
     }
   }
+  float4 w2tpre[8];
+  const bool pre2t = wave < T1 && KB3 >= 8;
+  if (pre2t) pol_prefetch<8>(a.pkW2T[trunk] + (size_t)wave * KB3 * 64, lane, 0, w2tpre);
   MLP_STAMP(11);
   __syncthreads();
   MLP_STAMP(12);
@@ -261,7 +277,8 @@ __global__ void __launch_bounds__(MLP_THREADS) mlp_fwdbwd_kernel(MlpTrainArgs a)
     pol_f16v acc;
 #pragma unroll
     for (int j = 0; j < 16; j++) acc[j] = 0.f;
-    pol_tile<8>(dz2, s2, a.pkW2T[trunk] + (size_t)to * KB3 * 64, lane, 0, KB3, acc);
+    if (pre2t && to == wave) pol_tile_pre<8>(dz2, s2, a.pkW2T[trunk] + (size_t)to * KB3 * 64, lane, 0, KB3, acc, w2tpre);
+    else pol_tile<8>(dz2, s2, a.pkW2T[trunk] + (size_t)to * KB3 * 64, lane, 0, KB3, acc);
     float hv[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) hv[j] = h1[((j >> 2) * 8 + h * 4 + (j & 3)) * s1 + to * 32 + r];
