@@ -32,10 +32,42 @@ struct MlpPackArgs {
   float *zero_ptr; long long zero_floats; float *adam_state2;
 };
 
+// Advantage statistics of the minibatch by ONE block of 256 threads (stats[0] = mean, stats[1] = 1 / (std_unbiased + 1e-8)), as
+// ppo_prepare_body, but with every load of the block in flight at once: the values are read into registers by independent
+// loads instead of 2 x B / 256 dependent round trips — this block is the critical path of the launch.  B <= 8192.
+__device__ __forceinline__ void mlp_adv_stats(const float *adv, int B, int normalize, float *stats, float *out8) {
+  __shared__ float red[16];
+  __shared__ float mean_s;
+  constexpr int ITEMS = 32;
+  float v[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) {
+    const int i = threadIdx.x + k * 256;
+    v[k] = (i < B) ? adv[i] : 0.f;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) s += v[k];
+  const float tot = ppo_block_sum(s, red);
+  if (threadIdx.x == 0) mean_s = tot / (float)B;
+  __syncthreads();
+  const float mean = mean_s;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) { const float d = v[k] - mean; q += ((int)threadIdx.x + k * 256 < B) ? d * d : 0.f; }
+  const float qq = ppo_block_sum(q, red);
+  if (threadIdx.x == 0) {
+    if (normalize && B > 1) { stats[0] = mean; stats[1] = 1.0f / (sqrtf(qq / (float)(B - 1)) + 1e-8f); }
+    else { stats[0] = 0.f; stats[1] = 1.f; }
+  }
+  if (threadIdx.x < 8) out8[threadIdx.x] = 0.f;
+}
+
 __global__ void __launch_bounds__(256) mlp_pack_kernel(MlpPackArgs a) {
   const int blk = blockIdx.x;
   if (blk == a.nblocks) {
-    ppo_prepare_body(a.adv, a.B, a.normalize, a.stats, a.out8, nullptr, 0);
+    if (a.B <= 8192) mlp_adv_stats(a.adv, a.B, a.normalize, a.stats, a.out8);
+    else ppo_prepare_body(a.adv, a.B, a.normalize, a.stats, a.out8, nullptr, 0);
     if (a.adam_state2 && threadIdx.x == 0) { a.adam_state2[0] = 0.f; a.adam_state2[1] += 1.f; }     // adam_begin_kernel
     return;
   }
