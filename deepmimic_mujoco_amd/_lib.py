@@ -259,8 +259,9 @@ class HipEngine:
         self._chk(self.L.dm_get_work(self.h, _ptr(w), self._stream()), "dm_get_work")
         return w
 
-    def enable_timing(self, on=True):
-        self._chk(self.L.dm_enable_timing(self.h, 1 if on else 0), "dm_enable_timing")
+    def enable_timing(self, on=True, stride=1):
+        """HIP event pair around every ``stride``-th step-kernel launch (ring of 512 pairs, read by mean_step_ms)."""
+        self._chk(self.L.dm_enable_timing(self.h, max(1, int(stride)) if on else 0), "dm_enable_timing")
 
     def mean_step_ms(self):
         """(mean kernel ms, launches) over the steps since enable_timing(True); synchronises."""

@@ -34,6 +34,8 @@ struct DmEngine {
   static constexpr int NEV = 512;              // ring of event pairs: one per dm_step while timing is on
   hipEvent_t ev0[NEV] = {}, ev1[NEV] = {};
   long nrec = 0;                               // launches recorded since dm_enable_timing(1)
+  long nlaunch = 0;                            // launches since dm_enable_timing
+  int stride = 1;                              // every stride-th launch carries an event pair
   int waves = 0;                               // 0: kernel variant from the batch size; 2 / 3: forced (env DM_WAVES, experiments)
   bool timing = false;
   float last_ms = 0;
@@ -356,7 +358,8 @@ static int launch(DmEngine *e, DmLaunch &P, int nslots, void *stream) {
   HIPCHK(e, hipSetDevice(e->cfg.device));
   hipStream_t s = (hipStream_t)stream;
   const int evi = (int)(e->nrec % DmEngine::NEV);
-  if (e->timing) hipEventRecord(e->ev0[evi], s);
+  const bool rec = e->timing && (e->nlaunch++ % e->stride) == 0;
+  if (rec) hipEventRecord(e->ev0[evi], s);
   const dim3 grid((P.nslots + DMK_ENVS_PER_BLOCK - 1) / DMK_ENVS_PER_BLOCK), block(64 * DMK_ENVS_PER_BLOCK);
   if (e->cfg.task == DM_TASK_COMBINED) {
     if (e->clipL[1] < 1 || e->clipL[2] < 2) return fail(e, DM_EINVAL, "combined task needs clips 0,1,2 = walk, run, getup");
@@ -366,7 +369,7 @@ static int launch(DmEngine *e, DmLaunch &P, int nslots, void *stream) {
   } else {
     hipLaunchKernelGGL(dm_step_kernel, grid, block, 0, s, P);
   }
-  if (e->timing) { hipEventRecord(e->ev1[evi], s); e->nrec++; }
+  if (rec) { hipEventRecord(e->ev1[evi], s); e->nrec++; }
   HIPCHK(e, hipGetLastError());
   return DM_OK;
 }
@@ -497,7 +500,9 @@ extern "C" int dm_fill_random_actions(DmHandle e, float *actions, uint32_t step_
 extern "C" int dm_enable_timing(DmHandle e, int enable) {
   if (!e) return DM_EINVAL;
   e->timing = enable != 0;
+  e->stride = enable > 1 ? enable : 1;
   e->nrec = 0;
+  e->nlaunch = 0;
   return DM_OK;
 }
 extern "C" int dm_last_step_ms(DmHandle e, float *ms) {

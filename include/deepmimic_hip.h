@@ -156,8 +156,9 @@ int dm_fill_random_actions(DmHandle h, float *actions, uint32_t step_index, void
 
 /* Timing of the step kernel on the engine's stream with HIP events (ms of the last dm_step). */
 int dm_last_step_ms(DmHandle h, float *ms);
-/* Mean kernel duration over the launches recorded since dm_enable_timing(h, 1) (ring of 512 event pairs, read
- * without a host sync in between: the caller synchronises once, after its timed region). */
+/* Mean kernel duration over the launches recorded since dm_enable_timing(h, n) (ring of 512 event pairs, read
+ * without a host sync in between: the caller synchronises once, after its timed region).  n = 1: every launch carries an
+ * event pair; n > 1: every n-th launch (two event records cost ~4 us of stream time each); 0: off. */
 int dm_mean_step_ms(DmHandle h, float *ms, int32_t *count);
 int dm_enable_timing(DmHandle h, int enable);
 
