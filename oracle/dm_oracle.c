@@ -24,6 +24,31 @@
 #define MINVAL 1e-15
 #define MAXVAL 1e10
 
+/* ------------------------------------------------------------------ sensitivity-study switches
+ * Defaults = the MuJoCo behaviour restated from SURVEY App. B.  tests/sensitivity_extracted_policy.py flips ONE of
+ * them at a time to see how the reference's MuJoCo-trained policy reacts.  Nothing else sets them. */
+static struct {
+  double refsafe;        /* 1: solref time constant clamped to >= 2h (mjDSBL_REFSAFE off) */
+  double redge;          /* pyramid edge regulariser Rpy = redge * mu^2 * R(first edge); MuJoCo: 2 */
+  double warmstart;      /* 0: MuJoCo rule (keep qacc_warmstart forces if their dual cost < 0); 1: always zero; 2: always warm */
+  double pgs_early_exit; /* 1: stop when scaled improvement < tolerance */
+  double planebox_all;   /* 1: plane-box also keeps corners with ldist > 0 (MuJoCo skips them) */
+  double diag_scale;     /* multiplies diagApprox (invweight0) of every row */
+  double solref_limit;   /* > 0: time constant of joint-limit rows only (solreflimit) */
+  double mu_scale;       /* multiplies the contact friction coefficient */
+  double stale_ws;       /* 1: RK stages 2..4 warm-start from what the step found (later MuJoCo saves qacc_warmstart in mj_advance) */
+} TW = {1, 2, 0, 1, 0, 1, 0, 1, 0};
+
+int dmo_set_tweak(const char *name, double v) {
+  if (!strcmp(name, "reset")) { TW.refsafe = 1; TW.redge = 2; TW.warmstart = 0; TW.pgs_early_exit = 1; TW.planebox_all = 0;
+                                TW.diag_scale = 1; TW.solref_limit = 0; TW.mu_scale = 1; TW.stale_ws = 0; return 0; }
+#define TWK(nm) if (!strcmp(name, #nm)) { TW.nm = v; return 0; }
+  TWK(refsafe) TWK(redge) TWK(warmstart) TWK(pgs_early_exit) TWK(planebox_all) TWK(diag_scale) TWK(solref_limit)
+  TWK(mu_scale) TWK(stale_ws)
+#undef TWK
+  return -1;
+}
+
 /* ------------------------------------------------------------------ small math */
 static double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 static void cross3(double *r, const double *a, const double *b) {
@@ -337,7 +362,7 @@ static int c_plane_box(RawCon *c, double margin, const double *ppos, const doubl
     double corner[3];
     rot_vec(corner, bmat, v);
     double ld = dot3(n, corner);
-    if (dist + ld > margin || ld > 0) continue;
+    if (dist + ld > margin || (ld > 0 && !TW.planebox_all)) continue;
     c[cnt].dist = dist + ld;
     memcpy(c[cnt].normal, n, sizeof n);
     memset(c[cnt].tangent, 0, sizeof c[cnt].tangent);
@@ -699,7 +724,7 @@ static void collision(const DmModel *m, DmoData *d) { /* [EXT] mj_collision */
       make_frame(c->frame);
       c->geom1 = g1; c->geom2 = g2; c->pair = p;
       c->dim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
-      c->mu = fmax(m->geom_friction[g1][0], m->geom_friction[g2][0]);
+      c->mu = TW.mu_scale * fmax(m->geom_friction[g1][0], m->geom_friction[g2][0]);
       c->includemargin = margin; /* gap = 0 */
     }
   }
@@ -786,13 +811,14 @@ static void make_constraint(const DmModel *m, DmoData *d) { /* [EXT] mj_makeCons
     }
   }
   /* impedance, regulariser, reference acceleration [EXT mj_makeImpedance, mj_referenceConstraint] */
-  double tc = fmax(m->solref[0], 2 * m->timestep); /* refsafe */
   double dr = m->solref[1], dmax = m->solimp[1];
-  double K = 1.0 / fmax(MINVAL, dmax * dmax * tc * tc * dr * dr);
-  double B = 2.0 / fmax(MINVAL, dmax * tc);
   for (int r = 0; r < d->nefc; r++) {
+    double tc = (d->efc_type[r] == 0 && TW.solref_limit > 0) ? TW.solref_limit : m->solref[0];
+    if (TW.refsafe) tc = fmax(tc, 2 * m->timestep); /* refsafe */
+    double K = 1.0 / fmax(MINVAL, dmax * dmax * tc * tc * dr * dr);
+    double B = 2.0 / fmax(MINVAL, dmax * tc);
     double imp = impedance(m->solimp, d->efc_pos[r], d->efc_margin[r]);
-    d->efc_R[r] = fmax(MINVAL, (1 - imp) * d->efc_diagApprox[r] / imp);
+    d->efc_R[r] = fmax(MINVAL, (1 - imp) * TW.diag_scale * d->efc_diagApprox[r] / imp);
     double vel = 0;
     for (int k = 0; k < NV; k++) vel += d->efc_J[(size_t)r * NV + k] * d->qvel[k];
     d->efc_vel[r] = vel;
@@ -804,7 +830,7 @@ static void make_constraint(const DmModel *m, DmoData *d) { /* [EXT] mj_makeCons
     if (c->dim <= 1) continue;
     int a = c->efc_address, n = 2 * (c->dim - 1);
     if (a + n > d->nefc) continue; /* dropped by the row cap */
-    double Rpy = 2 * c->mu * c->mu * d->efc_R[a];
+    double Rpy = TW.redge * c->mu * c->mu * d->efc_R[a];
     for (int k = 0; k < n; k++) d->efc_R[a + k] = Rpy;
   }
   for (int r = 0; r < d->nefc; r++) d->efc_D[r] = 1.0 / d->efc_R[r];
@@ -919,7 +945,7 @@ static void fwd_constraint(const DmModel *m, DmoData *d) { /* [EXT] mj_fwdConstr
     for (int c = 0; c < n; c++) s += AR[(size_t)r * n + c] * f[c];
     cost += f[r] * (0.5 * s + b[r]);
   }
-  if (cost > 0) memset(f, 0, sizeof(double) * n);
+  if ((cost > 0 && TW.warmstart != 2) || TW.warmstart == 1) memset(f, 0, sizeof(double) * n);
   /* projected Gauss-Seidel on the dual, all rows scalar and unilateral */
   double scale = 1.0 / (m->meaninertia * (NV > 1 ? NV : 1));
   int iter = 0;
@@ -935,7 +961,7 @@ static void fwd_constraint(const DmModel *m, DmoData *d) { /* [EXT] mj_fwdConstr
       improvement -= 0.5 * dl * dl * aii + dl * res;
     }
     iter++;
-    if (improvement * scale < m->tolerance) break;
+    if (TW.pgs_early_exit && improvement * scale < m->tolerance) break;
   }
   d->solver_iter = iter;
   for (int k = 0; k < NV; k++) {
@@ -993,6 +1019,8 @@ static void integrate_pos(const DmModel *m, double *qpos, const double *qvel, do
 
 int dmo_step(const DmModel *m, DmoData *d) { /* [EXT] mj_step with mj_RungeKutta(4) */
   if (bad(d->qpos, NQ) || bad(d->qvel, NV)) return 1;
+  double ws0[NV];
+  memcpy(ws0, d->qacc_warmstart, sizeof ws0); /* warm start as the step found it (TW.stale_ws only) */
   forward_nocheck(m, d);
   if (bad(d->qacc, NV)) return 1;
   d->stage_ncon[0] = d->ncon; d->stage_nefc[0] = d->nefc;
@@ -1017,6 +1045,7 @@ int dmo_step(const DmModel *m, DmoData *d) { /* [EXT] mj_step with mj_RungeKutta
       for (int k = 0; k < NV; k++) d->qvel[k] = X0v[k] + h * dv[k];
       memcpy(Xv[i], d->qvel, sizeof X0v);
       d->time = t0 + Ct[i - 1] * h;
+      if (TW.stale_ws) memcpy(d->qacc_warmstart, ws0, sizeof ws0);
       forward_nocheck(m, d);
       d->stage_ncon[i] = d->ncon; d->stage_nefc[i] = d->nefc;
       memcpy(F[i], d->qacc, sizeof X0v);

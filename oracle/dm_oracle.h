@@ -142,6 +142,10 @@ int dmo_combined_reset(const DmModel *m, DmoData *d, DmoCombEnv *e, const DmoCli
 int dmo_narrowphase(int t1, const double *x1, const double *M1, const double *z1, int t2, const double *x2,
                     const double *M2, const double *z2, double margin, double *out_n_x_10);
 
+/* Sensitivity-study switches (tests/sensitivity_extracted_policy.py only): names in dm_oracle.c; "reset" restores the
+ * MuJoCo defaults.  Returns 0, or -1 for an unknown name. */
+int dmo_set_tweak(const char *name, double value);
+
 /* rotation helpers exposed for tests */
 void dmo_quat_to_rpy(const double *wxyz, double *rpy);
 

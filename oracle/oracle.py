@@ -71,6 +71,7 @@ def lib():
         L.dmo_quat_to_rpy.argtypes = [C.c_void_p, C.c_void_p]
         L.dmo_bench_steps.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64]
         L.dmo_bench_steps.restype = C.c_double
+        L.dmo_set_tweak.argtypes = [C.c_char_p, C.c_double]
         _LIB = L
     return _LIB
 
@@ -229,6 +230,12 @@ def narrowphase(t1, x1, M1, z1, t2, x2, M2, z2, margin=0.001):
         raise ValueError("unsupported geom type pair")
     return [(out[10 * k], out[10 * k + 1:10 * k + 4].copy(), out[10 * k + 4:10 * k + 7].copy(), out[10 * k + 7:10 * k + 10].copy())
             for k in range(n)]
+
+
+def set_tweak(name, value):
+    """Sensitivity-study switch of the oracle (dm_oracle.c TW); "reset" restores the MuJoCo defaults."""
+    if lib().dmo_set_tweak(name.encode(), float(value)) != 0:
+        raise KeyError(name)
 
 
 def quat_to_rpy(q):
