@@ -26,7 +26,7 @@ EXPORTS = ["dm_default_config", "dm_create", "dm_destroy", "dm_last_error", "dm_
            "dm_set_state", "dm_get_state", "dm_get_counters", "dm_set_counters", "dm_set_debug",
            "dm_fill_random_actions", "dm_last_step_ms", "dm_enable_timing", "dm_get_work",
            "dm_set_clip_flags", "dm_obs_dim", "dm_terms_dim", "dm_get_env_clips", "dm_mean_step_ms", "dm_ppo_loss", "dm_forward", "dm_linear_wgrad", "dm_ppo_gather", "dm_adam_clip_step", "dm_policy_sample",
-           "dm_rollout_store", "dm_policy_pack", "dm_policy_forward", "dm_policy_packed_floats", "dm_ppo_mlp_grad", "dm_ppo_mlp_workspace_floats", "dm_adam_clip_update", "dm_colsum"]
+           "dm_rollout_store", "dm_policy_pack", "dm_policy_forward", "dm_policy_packed_floats", "dm_ppo_mlp_grad", "dm_ppo_mlp_workspace_floats", "dm_adam_clip_update", "dm_colsum", "dm_set_seed"]
 
 
 class DmConfig(C.Structure):
@@ -36,7 +36,11 @@ class DmConfig(C.Structure):
                 ("w_com", C.c_float), ("w_joint_limit", C.c_float), ("obs_bound", C.c_float),
                 ("seed", C.c_uint64), ("auto_reset", C.c_int32), ("device", C.c_int32),
                 ("lpt_schedule", C.c_int32), ("task", C.c_int32),
-                ("amnesty_steps", C.c_int32), ("to_getup_len", C.c_int32)]
+                ("amnesty_steps", C.c_int32), ("to_getup_len", C.c_int32),
+                ("integrator", C.c_int32), ("reserved0", C.c_int32)]
+
+
+INTEGRATORS = {None: 0, "model": 0, "Euler": 1, "euler": 1, "RK4": 2, "rk4": 2}   # DM_CFG_INT_*
 
 
 class DmPpoMlpStep(C.Structure):
@@ -101,6 +105,7 @@ def load_library():
     L.dm_get_counters.argtypes = [vp, vp, vp, vp, vp]
     L.dm_set_counters.argtypes = [vp, vp, vp, vp]
     L.dm_set_debug.argtypes = [vp, vp]
+    L.dm_set_seed.argtypes = [vp, C.c_uint64]
     L.dm_get_work.argtypes = [vp, vp, vp]
     L.dm_set_clip_flags.argtypes = [vp, i32, i32]
     L.dm_fill_random_actions.argtypes = [vp, vp, C.c_uint32, vp]
@@ -130,8 +135,9 @@ def _ptr(t):
 class HipEngine:
     """Thin object wrapper over a DmHandle; all tensors are torch CUDA tensors owned by the caller."""
 
-    def __init__(self, model, num_envs, device=0, seed=1234, auto_reset=True, **cfg_kw):
+    def __init__(self, model, num_envs, device=0, seed=1234, auto_reset=True, integrator=None, **cfg_kw):
         import torch
+        cfg_kw["integrator"] = INTEGRATORS[integrator]
         if not torch.cuda.is_available():
             raise RuntimeError("no MI355X visible to HIP: the DeepMimic engine has no CPU fallback")
         self.torch = torch
@@ -150,6 +156,10 @@ class HipEngine:
         self.terms_dim = self.L.dm_terms_dim(h)  # 5 or 8
         self.clip_len = {}
         self._debug = None
+
+    def set_seed(self, seed):
+        """gym's env.seed(): re-key the reset / random-action generator."""
+        self._chk(self.L.dm_set_seed(self.h, C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF)), "dm_set_seed")
 
     def close(self):
         if getattr(self, "h", None):

@@ -71,6 +71,7 @@ extern "C" void dm_default_config(DmConfig *c) {
   c->task = DM_TASK_DPENV;
   c->amnesty_steps = 150;    // src/combined_env.py:34
   c->to_getup_len = 180;     // :97
+  c->integrator = DM_CFG_INT_MODEL;   // the XML's (RK4, xml :9)
 }
 
 static void build_tables(const DmModel &m, DmDev &T) {
@@ -171,7 +172,7 @@ static void build_tables(const DmModel &m, DmDev &T) {
 static int check_model(DmEngine *e, const DmModel &m) {
   if (m.nq != DM_NQ || m.nv != DM_NV || m.nu != DM_NU || m.nbody != DM_NBODY || m.ngeom != DM_NGEOM)
     return fail(e, DM_EINVAL, "model dimensions do not match the compiled-in humanoid3d dimensions");
-  if (m.integrator != DM_INT_RK4) return fail(e, DM_EINVAL, "only integrator=RK4 is built (reference xml :9)");
+  if (m.integrator != DM_INT_RK4 && m.integrator != DM_INT_EULER) return fail(e, DM_EINVAL, "integrator must be RK4 or Euler");
   if (m.npair < 0 || m.npair > DM_MAXPAIR) return fail(e, DM_EINVAL, "npair out of range");
   for (int b = 1; b < DM_NBODY; b++) {
     if (m.body_quat[b][0] != 1.0) return fail(e, DM_EINVAL, "kernels assume identity body quaternions");
@@ -349,12 +350,15 @@ static void fill_launch(DmEngine *e, DmLaunch &P, int mode) {
   P.w_pose = e->cfg.w_pose; P.w_vel = e->cfg.w_vel; P.w_ee = e->cfg.w_end_eff; P.w_com = e->cfg.w_com; P.w_jl = e->cfg.w_joint_limit;
   P.seed = e->cfg.seed;
   P.amnesty_steps = e->cfg.amnesty_steps; P.to_getup_len = e->cfg.to_getup_len;
+  P.integrator = e->cfg.integrator == DM_CFG_INT_EULER ? DM_INT_EULER : e->cfg.integrator == DM_CFG_INT_RK4 ? DM_INT_RK4 : e->model.integrator;
   P.debug = e->debug;
 }
 
 static int launch(DmEngine *e, DmLaunch &P, int nslots, void *stream) {
   P.nslots = nslots;
   if (e->clipL[0] < 1) return fail(e, DM_EINVAL, "no clip loaded (dm_load_clip clip 0 first)");
+  if (e->cfg.task == DM_TASK_COMBINED && (e->clipL[1] < 1 || e->clipL[2] < 2))
+    return fail(e, DM_EINVAL, "combined task needs clips 0,1,2 = walk, run, getup");
   HIPCHK(e, hipSetDevice(e->cfg.device));
   hipStream_t s = (hipStream_t)stream;
   const int evi = (int)(e->nrec % DmEngine::NEV);
@@ -362,7 +366,6 @@ static int launch(DmEngine *e, DmLaunch &P, int nslots, void *stream) {
   if (rec) hipEventRecord(e->ev0[evi], s);
   const dim3 grid((P.nslots + DMK_ENVS_PER_BLOCK - 1) / DMK_ENVS_PER_BLOCK), block(64 * DMK_ENVS_PER_BLOCK);
   if (e->cfg.task == DM_TASK_COMBINED) {
-    if (e->clipL[1] < 1 || e->clipL[2] < 2) return fail(e, DM_EINVAL, "combined task needs clips 0,1,2 = walk, run, getup");
     hipLaunchKernelGGL(dm_step_combined_kernel, grid, block, 0, s, P);
   } else if (e->waves == 3 || (e->waves == 0 && P.nslots >= 6144)) {
     hipLaunchKernelGGL(dm_step_kernel_w3, grid, block, 0, s, P);   // three waves per SIMD pay off from ~1.5 x 4096 envs
@@ -479,6 +482,12 @@ extern "C" int dm_get_work(DmHandle e, int32_t *work_out, void *stream) {
   if (!e || !work_out) return DM_EINVAL;
   HIPCHK(e, hipSetDevice(e->cfg.device));
   HIPCHK(e, hipMemcpyAsync(work_out, e->dCost, e->N * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return DM_OK;
+}
+
+extern "C" int dm_set_seed(DmHandle e, uint64_t seed) {
+  if (!e) return DM_EINVAL;
+  e->cfg.seed = seed;
   return DM_OK;
 }
 

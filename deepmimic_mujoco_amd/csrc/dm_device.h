@@ -150,6 +150,7 @@ struct DmLaunch {
   DmClipDev clips[8];
   int32_t N, nslots, mode, auto_reset, max_ep_length;
   int32_t amnesty_steps, to_getup_len;   // DPCombinedEnv task only
+  int32_t integrator, pad_i;             // DM_INT_RK4 (xml :9) or DM_INT_EULER
   float vel_obs_scale, low_z, high_z, obs_bound;
   float w_pose, w_vel, w_ee, w_com, w_jl;
   uint64_t seed;

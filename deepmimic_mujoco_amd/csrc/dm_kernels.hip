@@ -519,7 +519,11 @@ __shared__ EnvLds g_S;  // one environment per 64-thread block
 // ---- forward evaluation, part 1: kinematics, inertia, factorisation, bias forces, qacc_smooth
 // Every pass is lane-parallel: bodies walk their (<= 4 deep) ancestor chain instead of waiting for a
 // level-by-level sweep, and the L^T D L factorisation keeps row i of M in the registers of lane i.
-__device__ __forceinline__ void fwd_smooth(GDev &T, const int lane) {
+// DAMP2 (Euler integrator only): re-factorise M + h diag(damping) at the same configuration (cdof / cinert of the
+// evaluation just done are still in LDS) and return (M + h B)^-1 rhs — MuJoCo's Euler integrates joint damping
+// implicitly [EXT mj_Euler]; kinematics, velocity stage and bias forces are skipped.
+template <bool DAMP2 = false>
+__device__ __forceinline__ float fwd_smooth(GDev &T, const int lane, const float rhs = 0.f) {
   EnvLds &S = g_S;
   const int lb = lane < DMK_NB ? lane : 0;       // lane as body
   const int lk = lane < DMK_NV ? lane : 0;       // lane as dof
@@ -533,6 +537,7 @@ __device__ __forceinline__ void fwd_smooth(GDev &T, const int lane) {
   const int d_body = T.d_body[lk], d_nanc = T.d_nanc[lk], d_pbody = T.d_pbody[lk];
   const float mtot_inv = T.total_mass_inv;
 
+  if constexpr (!DAMP2) {
   // ---- P0: normalise the free-joint quaternion in place (mj_kinematics does); half-angle sin/cos
   {
     float q[4] = {S.qpos[3], S.qpos[4], S.qpos[5], S.qpos[6]};
@@ -679,6 +684,7 @@ __device__ __forceinline__ void fwd_smooth(GDev &T, const int lane) {
   }
   SYNC();
   PROF(1);
+  }  // !DAMP2
   // ---- composite inertia per body via the subtree mask (lane = body)
   {
     // body c adds its cinert to c and to every ancestor of c: a compile-time lane set (dm_topology.h)
@@ -709,7 +715,7 @@ __device__ __forceinline__ void fwd_smooth(GDev &T, const int lane) {
       for (int i = 0; i < 6; i++) S.u.v.mbuf[lk][i] = buf[i];
     }
     SYNC();
-    const float armv = isdof ? T.d_arm[lk] : 0.f;
+    const float armv = isdof ? (DAMP2 ? fmaf(T.timestep, T.d_damp[lk], T.d_arm[lk]) : T.d_arm[lk]) : 0.f;
     // dots[k] = cdof_lane . buf_k.  k < 32 on the matrix pipe (32 x 32 x 6: operand A = buf from LDS, operand B = the
     // lanes' cdof with the odd components swapped into the upper half-wave; dof lanes 32, 33 only own rows 32, 33);
     // k = 32, 33 with FMAs.
@@ -782,6 +788,10 @@ __device__ __forceinline__ void fwd_smooth(GDev &T, const int lane) {
   }
   SYNC();
   PROF(3);
+  float xs = 0;
+  if constexpr (DAMP2) {
+    xs = isdof ? rhs : 0.f;
+  } else {
   // ---- velocity stage, lane-parallel.  Pass A (lane = body): w_b = sum over the body's dofs of cdof * qvel
   if (isbody) {
     float w[6] = {0, 0, 0, 0, 0, 0};
@@ -871,7 +881,6 @@ __device__ __forceinline__ void fwd_smooth(GDev &T, const int lane) {
   SYNC();
   PROF2(10);
   // ---- smooth forces and qacc_smooth = M^-1 (passive - bias + actuation)   (lane = dof)
-  float xs = 0;
   if (isdof) {
     float bias = 0;
     for (int i = 0; i < 6; i++) bias += S.cdof[lk][i] * S.u.v.cacc[d_body][i];
@@ -880,12 +889,16 @@ __device__ __forceinline__ void fwd_smooth(GDev &T, const int lane) {
     if (da >= 0) act = T.d_gear[lk] * clampf(S.ctrl[da], T.d_clo[lk], T.d_chi[lk]);
     xs = -T.d_damp[lk] * S.qvel[lk] - bias + act;
   }
+  }  // !DAMP2
   xs = solve_LT(xs, dv, -d_nanc_s, g_S.M);
   xs = solve_L(xs, dv, isdof ? mrow : DMK_MAXANC, g_S.M);
   xs *= dv;
-  if (isdof) S.qacc_smooth[lk] = xs;
+  if constexpr (!DAMP2) {
+    if (isdof) S.qacc_smooth[lk] = xs;
+  }
   SYNC();
   PROF(4);
+  return xs;
 }
 
 // ---- forward evaluation, part 2: collision detection -> contact list in LDS; returns ncon | overflow << 8
@@ -1726,7 +1739,8 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
     }
    }  // !sim_err
 
-    if (!sim_err && it < 3) {  // RK4 intermediate stages (tableau A = diag(1/2, 1/2, 1), B = 1/6 1/3 1/3 1/6)
+    const bool euler = (P.integrator == DM_INT_EULER) && mode == DMK_MODE_STEP;
+    if (!sim_err && it < 3 && !euler) {  // RK4 intermediate stages (tableau A = diag(1/2, 1/2, 1), B = 1/6 1/3 1/3 1/6)
       const float Bw = (it == 0) ? (1.f / 6.f) : (1.f / 3.f);
       const float Aw = (it == 2) ? 1.f : 0.5f;
       accq += Bw * curv;
@@ -1752,9 +1766,20 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
       it++;
       continue;
     }
-    if (!sim_err && it == 3) {  // final combination (mj_advance with the RK4 weights)
-      accq += (1.f / 6.f) * curv;
-      accv += (1.f / 6.f) * qacc_out;
+    if (!sim_err && (it == 3 || (it == 0 && euler))) {  // final combination (mj_advance)
+      if (euler) {
+        // [EXT mj_Euler] semi-implicit Euler, joint damping integrated implicitly: (M + h B) a' = M a, i.e.
+        // a' = a - (M + h B)^-1 h B a; velocity first, then the position with the NEW velocity
+        const float hb = (lane < DMK_NV) ? h * T.d_damp[lk] : 0.f;
+        float a2 = qacc_out;
+        if (__any(hb != 0.f)) a2 = qacc_out - fwd_smooth<true>(T, lane, hb * qacc_out);
+        accv = a2;
+        accq = x0v + h * a2;
+        it = 3;
+      } else {
+        accq += (1.f / 6.f) * curv;
+        accv += (1.f / 6.f) * qacc_out;
+      }
       float w3[3] = {rl(accq, 3), rl(accq, 4), rl(accq, 5)};
       float wn = sqrtf(dot3(w3, w3));
       float qr[4] = {1, 0, 0, 0}, qn[4];

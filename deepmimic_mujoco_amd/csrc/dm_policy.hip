@@ -318,12 +318,16 @@ extern "C" int dm_policy_forward(const float *obs, int N, int D, int H1, int H2,
   if ((reinterpret_cast<uintptr_t>(pi_packed) | reinterpret_cast<uintptr_t>(vf_packed)) & 15) return -22;
   const size_t lds = pol_lds_bytes(D, H1);
   if (lds > 160 * 1024) return -22;
-  static size_t lds_allowed = 64 * 1024;
-  if (lds > lds_allowed) {
+  // hipFuncSetAttribute applies to the CURRENT device: remember the raised limit per device ordinal
+  static size_t lds_allowed[64];
+  int dev_id = 0;
+  if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) return -5;
+  const size_t allowed = lds_allowed[dev_id] ? lds_allowed[dev_id] : (size_t)64 * 1024;
+  if (lds > allowed) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(pol_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess)
       return -5;
-    lds_allowed = lds;
+    lds_allowed[dev_id] = lds;
   }
   PolArgs a;
   a.obs = obs; a.N = N; a.D = D; a.Dp = pol_dp(D); a.H1 = H1; a.H2 = H2; a.A = A;

@@ -531,12 +531,16 @@ extern "C" int dm_ppo_mlp_grad(const DmPpoMlpStep *s, void *stream) {
   if (s->workspace_floats < (long long)L.total) return -22;
   const size_t lds = mlp_lds_bytes(D, H1, H2);
   if (lds > 160 * 1024) return -22;
-  static size_t lds_allowed = 64 * 1024;
-  if (lds > lds_allowed) {
+  // hipFuncSetAttribute applies to the CURRENT device: remember the raised limit per device ordinal
+  static size_t lds_allowed[64];
+  int dev_id = 0;
+  if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) return -5;
+  const size_t allowed = lds_allowed[dev_id] ? lds_allowed[dev_id] : (size_t)64 * 1024;
+  if (lds > allowed) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_fwdbwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess)
       return -5;
-    lds_allowed = lds;
+    lds_allowed[dev_id] = lds;
   }
   hipStream_t st = (hipStream_t)stream;
   float *stats = s->workspace + 2 * L.per_trunk;

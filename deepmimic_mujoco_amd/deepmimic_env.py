@@ -207,7 +207,10 @@ class DPEnv:
             return obs, 0, False, {}
         if reason in (5, 6):                                                  # :366-378 / :465-476
             if reason == 6:
+                # the reference advances idx_curr / episode_reward / episode_length (:452-455) BEFORE the observation
+                # guard (:465-476) zeroes the returned reward: take the pre-guard sum from the engine's counter
                 self.idx_curr = (self.idx_curr + 1) % self.mocap_data_len
+                self.episode_reward = float(self._eng.get_counters()[2][0].item())
                 self.episode_length += 1
             return obs, 0, True, {}
         reward = float(self._out["rew"][0].item())
@@ -245,32 +248,56 @@ class DPEnv:
 
     def seed(self, seed=None):
         random.seed(seed)
+        if seed is not None:
+            self._eng.set_seed(seed)
         return [seed]
 
     def close(self):
         self._eng.close()
 
 
-class LazyInfos:
-    """`infos` list of a VecEnv step; dicts are built on access (4096 dicts/step would dominate)."""
+class LazyInfos(list):
+    """`infos` of a VecEnv step: a real ``list`` (SB3's wrappers slice it, assign into it and test it with
+    ``isinstance(infos, (list, tuple))``) whose dicts are built on first access — 4096 dicts per step would dominate the
+    numpy surface.  Unmaterialised slots hold ``None`` internally; every public access path materialises them."""
 
     def __init__(self, terms, reason, done, terminal_obs):
+        super().__init__([None] * len(done))
         self._terms, self._reason, self._done, self._tobs = terms, reason, done, terminal_obs
-        self._cache = {}
 
-    def __len__(self):
-        return len(self._done)
+    def _get(self, i):
+        v = list.__getitem__(self, i)
+        if v is None:
+            if i < 0:
+                i += len(self)
+            v = _make_info(self._terms[i], self._reason[i])
+            if self._done[i]:
+                v["terminal_observation"] = self._tobs[i].copy()
+            list.__setitem__(self, i, v)
+        return v
 
     def __getitem__(self, i):
-        if i not in self._cache:
-            info = _make_info(self._terms[i], self._reason[i])
-            if self._done[i]:
-                info["terminal_observation"] = self._tobs[i].copy()
-            self._cache[i] = info
-        return self._cache[i]
+        if isinstance(i, slice):
+            return [self._get(j) for j in range(*i.indices(len(self)))]
+        return self._get(i)
 
     def __iter__(self):
-        return (self[i] for i in range(len(self)))
+        return (self._get(i) for i in range(len(self)))
+
+    def _all(self):
+        return [self._get(i) for i in range(len(self))]
+
+    def copy(self):
+        return self._all()
+
+    def __eq__(self, other):
+        return self._all() == list(other)
+
+    def __reduce__(self):          # pickles / deep-copies as the plain list it stands for
+        return (list, (self._all(),))
+
+    def __repr__(self):
+        return repr(self._all())
 
 
 class HipDeepMimicVecEnv(_SB3VecEnv):
@@ -325,6 +352,8 @@ class HipDeepMimicVecEnv(_SB3VecEnv):
         self.observation_space = Box(-np.inf, np.inf, (NOBS,), np.float32)
         self._actions = torch.zeros(self.num_envs, NU, device=self.device)
         self.version, self.ENV_CFG = DPEnv.version, DPEnv.ENV_CFG
+        self.render_mode = None
+        self.reset_infos = [{} for _ in range(self.num_envs)]
         if _SB3VecEnv is not object:  # pragma: no cover
             _SB3VecEnv.__init__(self, self.num_envs, self.observation_space, self.action_space)
 
@@ -379,17 +408,37 @@ class HipDeepMimicVecEnv(_SB3VecEnv):
             e.close()
 
     def seed(self, seed=None):
-        return [None] * self.num_envs
+        """SB3 VecEnv.seed: env i gets seed + i.  Here: re-keys the engines' counter-based reset generator (env index and
+        reset count are part of the key already) and returns the per-env seeds SB3 expects."""
+        if seed is None:
+            return [None] * self.num_envs
+        for k, e in enumerate(self.engines):
+            e.set_seed(int(seed) + 104729 * k)
+        return [int(seed) + i for i in range(self.num_envs)]
+
+    def _n_indices(self, indices):
+        return self.num_envs if indices is None else len(np.atleast_1d(indices))
 
     def get_attr(self, attr_name, indices=None):
-        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
-        return [getattr(self, attr_name)] * n
+        return [getattr(self, attr_name)] * self._n_indices(indices)
 
     def set_attr(self, attr_name, value, indices=None):
         setattr(self, attr_name, value)
 
     def env_method(self, method_name, *args, indices=None, **kwargs):
-        raise NotImplementedError("per-env method calls have no batched equivalent")
+        """SB3 VecEnv.env_method: the envs of the batch are identical, so a method of the batch object answers for every
+        env (what SB3 itself uses it for: ``seed``, ``get_wrapper_attr``-style queries); unknown names raise
+        AttributeError as a missing method of a sub-env would."""
+        fn = getattr(self, method_name)
+        out = fn(*args, **kwargs)
+        return [out] * self._n_indices(indices)
+
+    def getattr_depth_check(self, name, already_found):
+        return None
+
+    @property
+    def unwrapped(self):
+        return self
 
     def env_is_wrapped(self, wrapper_class, indices=None):
         n = self.num_envs if indices is None else len(np.atleast_1d(indices))

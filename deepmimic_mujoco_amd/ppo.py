@@ -430,7 +430,7 @@ class PPO:
                  gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5,
                  normalize_advantage=True, seed=0, device=None, buffer_dtype=torch.float32, policy=None,
                  use_hip_graph=None, fused_loss=True, flat_adam=True, two_stream=True, rollout_graph=True, fused_rollout=True,
-                 fused_policy=True, fused_mlp=True, epoch_graph=True):
+                 fused_policy=True, fused_mlp=True, epoch_graph=True, dist_graph=True):
         # rollout_graph only takes effect for an env built with sub_batches > 1
         self.env = env
         self.device = device if device is not None else getattr(env, "device", torch.device("cpu"))
@@ -446,7 +446,11 @@ class PPO:
         self.fused_policy = fused_policy      # dm_policy_forward: the whole policy side of a rollout step as one launch
         self.epoch_graph = epoch_graph        # one hipGraph replay per epoch (gathers + optimizer steps) instead of one per minibatch
         self.fused_mlp = fused_mlp            # dm_ppo_mlp_grad: loss + all gradients of a minibatch in three launches
-        self._rollout_seed = 0x5EED0000 + seed
+        self.dist_graph = dist_graph          # several ranks: [gather + gradient] and [Adam] stay captured graphs around the all-reduce
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        # the fused samplers key their draws on (seed, LOCAL env index, counter, action index): the rank must be part of
+        # the seed or every rank would explore with bit-identical noise (weights still start identical: torch seed below)
+        self._rollout_seed = (0x5EED0000 + seed + 0x9E3779B1 * self.rank) & 0x7FFFFFFFFFFFFFFF
         self.buffer_dtype = buffer_dtype
         torch.manual_seed(seed)  # identical initial weights on every rank; no parameter broadcast needed
         self.obs_dim = int(env.observation_space.shape[0]) if env is not None else 67   # 67 DPEnv, 72 DPCombinedEnv
@@ -465,7 +469,6 @@ class PPO:
         self._mlp_grads = {}                                                        # FusedMlpGrad per minibatch size
         self._loss_acc = torch.zeros(2, device=self.device) if on_gpu else None     # device-side (sum of losses, count)
         self.grad_sync = self.optimizer if self.flat_adam else FlatGradAllReduce(self.policy.parameters())
-        self.rank = dist.get_rank() if dist.is_initialized() else 0
         if dist.is_initialized():  # decorrelate action noise across ranks after the common init
             torch.manual_seed(seed + 1000 * (self.rank + 1))
         lo = torch.as_tensor(env.action_space.low, device=self.device) if env is not None else None
@@ -488,9 +491,16 @@ class PPO:
             z = lambda *shape: torch.zeros(*shape, device=self.device)
             sc[key] = dict(act=z(n, 28), act_env=z(n, 28), logp=z(n))
             self._rsc = sc
-        if getattr(self, "_rctr", None) is None:
-            self._rctr = torch.zeros(1, dtype=torch.int32, device=self.device)      # draw counter, advanced on the device
+        if getattr(self, "_rctrs", None) is None:
+            # draw counters, advanced on the device: ONE PER SUB-BATCH — sub-batch chains run on their own streams (or as
+            # independent branches of a captured graph), so a shared counter bumped by one chain would be read by the
+            # others at unordered times (same noise at consecutive steps, non-reproducible rollouts)
+            self._rctrs = torch.zeros(16, dtype=torch.int32, device=self.device)
+            self._rctr = self._rctrs[0:1]
         return sc[key]
+
+    def _ctr(self, k):
+        return self._rctrs[k:k + 1]
 
     def _policy_step_fused(self, obs, env_index=0):
         """mean/value by the MLP (library GEMMs), then one launch for sample + logp + clamp."""
@@ -502,14 +512,14 @@ class PPO:
         val = self.policy.value_net(self.policy.vf(obs)).squeeze(-1).contiguous()
         p = lambda t: C.c_void_p(t.data_ptr())
         rc = _lib.load_library().dm_policy_sample(p(mean.contiguous()), p(self.policy.log_std), n, 28,
-                                                  C.c_uint64(self._rollout_seed + 7919 * env_index), p(self._rctr), p(self.act_lo),
+                                                  C.c_uint64(self._rollout_seed + 7919 * env_index), p(self._ctr(env_index)), p(self.act_lo),
                                                   p(self.act_hi), p(sc["act"]), p(sc["act_env"]), p(sc["logp"]),
                                                   C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         if rc != 0:
             raise RuntimeError("dm_policy_sample failed (%d)" % rc)
         return sc, val
 
-    def _store_fused(self, rb, t, sl, last, sc, val, out, bump):
+    def _store_fused(self, rb, t, sl, last, sc, val, out, bump, env_index=0):
         import ctypes as C
         from . import _lib
         p = lambda x: C.c_void_p(x.data_ptr())
@@ -517,7 +527,7 @@ class PPO:
         rc = _lib.load_library().dm_rollout_store(
             n, self.obs_dim, 28, p(last[sl]), p(sc["act"]), p(val), p(sc["logp"]), p(out["rew"]), p(out["done"]), p(out["obs"]),
             p(rb["obs"][t, sl]), p(rb["act"][t, sl]), p(rb["val"][t, sl]), p(rb["logp"][t, sl]), p(rb["rew"][t, sl]),
-            p(rb["done"][t, sl]), p(last[sl]), p(self._rctr) if bump else None,
+            p(rb["done"][t, sl]), p(last[sl]), p(self._ctr(env_index)) if bump else None,
             C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         if rc != 0:
             raise RuntimeError("dm_rollout_store failed (%d)" % rc)
@@ -618,7 +628,7 @@ class PPO:
                 if self._fused_rollout_ok():
                     sc, val = self._policy_step_fused(obs, env_index=k)
                     out = env.step_sub(k, sc["act_env"])
-                    self._store_fused(rb, t, sl, last, sc, val, out, bump=(k == K - 1))
+                    self._store_fused(rb, t, sl, last, sc, val, out, bump=True, env_index=k)
                     continue
                 act, val, logp = self.policy(obs)
                 rb["obs"][t, sl] = obs
@@ -675,7 +685,7 @@ class PPO:
                         sl = env.sub_slices[k]
                         sc, val = self._policy_step_fused(last[sl], env_index=k)
                         out = env.step_sub(k, sc["act_env"])
-                        self._store_fused(rb, t, sl, last, sc, val, out, bump=(k == K - 1))
+                        self._store_fused(rb, t, sl, last, sc, val, out, bump=True, env_index=k)
             for st in streams:
                 cur.wait_stream(st)
             last_val = self.policy.predict_values(last)
@@ -763,6 +773,24 @@ class PPO:
             nsteps = self.n_epochs * (n // self.batch_size)
             acc = self._loss_acc if on_dev else torch.stack([eg["loss"], torch.full((), float(nsteps), device=self.device)])
             self.stats["loss"] = float(acc[0] / torch.clamp(acc[1], min=1.0))
+            return self.stats["loss"]
+        if self._dist_graph_ok(flat, n, on_dev):
+            # several ranks: a minibatch is [graph A: gather + dm_ppo_mlp_grad] -> all-reduce of the flat gradient (the ONE
+            # collective, eager, on the same stream) -> [graph B: dm_adam_clip_update]: three host calls and no eager
+            # kernel launches, instead of falling back to the un-captured step
+            dg = self._dist_graphs(flat, n)
+            for k in dg["flat"]:
+                dg["flat"][k].copy_(flat[k])
+            B = self.batch_size
+            for _ in range(self.n_epochs):
+                torch.randperm(n, device=self.device, generator=generator, out=dg["perm"])
+                for s in range(0, n, B):
+                    dg["idx"].copy_(dg["perm"][s:s + B])
+                    dg["grad"].replay()
+                    self.optimizer.all_reduce()
+                    dg["adam"].replay()
+                    nsteps += 1
+            self.stats["loss"] = float(self._loss_acc[0] / torch.clamp(self._loss_acc[1], min=1.0))
             return self.stats["loss"]
         for _ in range(self.n_epochs):
             perm = torch.randperm(n, device=self.device, generator=generator)
@@ -873,9 +901,17 @@ class PPO:
             for _ in range(3):
                 warm()
         torch.cuda.current_stream(dev).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = body()
+        if isinstance(body, (list, tuple)):      # several graphs captured back to back (e.g. around a collective)
+            graph, out = [], []
+            for b in body:
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_):
+                    out.append(b())
+                graph.append(g_)
+        else:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = body()
         with torch.no_grad():
             for p, q in zip(self.policy.parameters(), snap_p):
                 p.copy_(q)
@@ -895,6 +931,39 @@ class PPO:
     def _epoch_graph_ok(self, flat, n):
         return (self.use_hip_graph and self.device.type == "cuda" and n % self.batch_size == 0 and self.epoch_graph
                 and all(flat[k].dtype == torch.float32 for k in ("obs", "act", "adv", "ret", "logp")))
+
+    def _dist_graph_ok(self, flat, n, on_dev):
+        return (self.dist_graph and on_dev and dist.is_initialized() and dist.get_world_size() > 1
+                and all(flat[k].dtype == torch.float32 for k in ("obs", "act", "adv", "ret", "logp")))
+
+    def _dist_graphs(self, flat, n):
+        """Two captured graphs per minibatch for the multi-rank learner (see train())."""
+        dg = getattr(self, "_dg", None)
+        if dg is not None and dg["n"] == n:
+            return dg
+        dev, B = self.device, self.batch_size
+        dg = dict(n=n, perm=torch.arange(n, device=dev), idx=torch.arange(B, device=dev),
+                  flat={k: torch.zeros_like(flat[k]) for k in ("obs", "act", "adv", "ret", "logp")})
+        gin = self._static_minibatch()
+        mg = self._mlp_grads.get(B)
+        if mg is None:
+            mg = self._mlp_grads[B] = FusedMlpGrad(self.policy, self.optimizer, B, loss_acc=self._loss_acc)
+        norm = self.normalize_advantage and B > 1
+
+        def grad():
+            self._gather_minibatch(dg["flat"], dg["idx"], gin)
+            return mg(gin["obs"], gin["act"], gin["adv"], gin["ret"], gin["logp"], self.clip_range, self.vf_coef, self.ent_coef, norm)
+
+        def adam():
+            self.optimizer.step(begin=False)
+
+        def warm():              # local only: no collective during warm-up / capture, every rank does the same
+            grad()
+            adam()
+
+        (dg["grad"], dg["adam"]), _ = self._capture_with_restore(warm, [grad, adam])
+        self._dg = dg
+        return dg
 
     def _epoch_graph(self, flat, n):
         eg = getattr(self, "_eg", None)

@@ -46,6 +46,11 @@ typedef struct DmEngine *DmHandle;
 #define DM_REASON_OBS_BOUNDS 6
 #define DM_REASON_FALLEN_NO_AMNESTY 7 /* DPCombinedEnv "fallen without amnesty" (src/combined_env.py:436) */
 
+/* Integrator selector (DmConfig.integrator) */
+#define DM_CFG_INT_MODEL 0
+#define DM_CFG_INT_EULER 1
+#define DM_CFG_INT_RK4 2
+
 /* Task selector (DmConfig.task) */
 #define DM_TASK_DPENV 0     /* DPEnv            (src/deepmimic_env.py:272-484): obs 67, terms 5 */
 #define DM_TASK_COMBINED 1  /* DPCombinedEnv    (src/combined_env.py:101-533) on humanoid3d: obs 72, terms 8;
@@ -67,6 +72,10 @@ typedef struct DmConfig {
   int32_t task;            /* DM_TASK_DPENV (default) or DM_TASK_COMBINED */
   int32_t amnesty_steps;   /* 150  DPCombinedEnvConfig.AMNESTY_STEPS (combined_env.py:34) */
   int32_t to_getup_len;    /* 180  MTToGetup.length (combined_env.py:97) */
+  int32_t integrator;      /* DM_CFG_INT_MODEL (default): <option integrator> of the XML (RK4, xml :9);
+                            * DM_CFG_INT_EULER: MuJoCo's semi-implicit Euler with implicit joint damping [EXT mj_Euler]
+                            * (one forward evaluation per step instead of four); DM_CFG_INT_RK4 */
+  int32_t reserved0;
 } DmConfig;
 
 void dm_default_config(DmConfig *cfg);
@@ -131,6 +140,10 @@ int dm_get_state(DmHandle h, const int32_t *env_ids, int n, float *qpos, float *
 int dm_get_counters(DmHandle h, int32_t *idx_curr, int32_t *episode_length, float *episode_reward,
                     void *stream);
 int dm_set_counters(DmHandle h, const int32_t *idx_curr, const int32_t *episode_length, void *stream);
+
+/* Replaces: gym.Env.seed() (random.seed for reference_state_init, src/deepmimic_env.py:313): re-keys the counter-based
+ * generator of the random-frame resets (and of dm_fill_random_actions).  Takes effect from the next launch. */
+int dm_set_seed(DmHandle h, uint64_t seed);
 
 /* Derived quantities of the LAST forward evaluation of every env, for parity tests:
  * sim.data.body_xpos/geom_xpos/cvel/qacc and the contact list.  Layout per env (floats):

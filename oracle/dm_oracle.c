@@ -1059,8 +1059,24 @@ int dmo_step(const DmModel *m, DmoData *d) { /* [EXT] mj_step with mj_RungeKutta
     for (int k = 0; k < NV; k++) d->qvel[k] = X0v[k] + h * dv[k];
     integrate_pos(m, d->qpos, dq, h);
     d->time = t0 + h;
-  } else { /* semi-implicit Euler without the implicit-damping correction */
-    for (int k = 0; k < NV; k++) d->qvel[k] += h * d->qacc[k];
+  } else { /* [EXT] mj_Euler: semi-implicit Euler; joint damping integrated implicitly when any dof has damping:
+            * (M + h B) qacc' = qfrc_smooth + qfrc_constraint, then qvel += h qacc', qpos (+)= h qvel(new) */
+    double qa[NV];
+    int damped = 0;
+    for (int k = 0; k < NV; k++) damped |= m->dof_damping[k] > 0;
+    if (!damped) {
+      memcpy(qa, d->qacc, sizeof qa);
+    } else {
+      double qM0[DM_NM];
+      memcpy(qM0, d->qM, sizeof qM0);
+      for (int k = 0; k < NV; k++) d->qM[m->dof_Madr[k]] += h * m->dof_damping[k];
+      factor_m(m, d);
+      for (int k = 0; k < NV; k++) qa[k] = d->qfrc_smooth[k] + d->qfrc_constraint[k];
+      solve_m(m, d, qa);
+      memcpy(d->qM, qM0, sizeof qM0); /* MuJoCo factorises a copy: qM / qLD stay those of M */
+      factor_m(m, d);
+    }
+    for (int k = 0; k < NV; k++) d->qvel[k] += h * qa[k];
     integrate_pos(m, d->qpos, d->qvel, h);
     d->time += h;
   }

@@ -55,10 +55,11 @@ def _oracle_states(model, clip, nenv, nsteps, scale, seed, caps=(32, 128)):
     return recs
 
 
-def _run_teacher_forced(model, clips, oracle_clips, torch, scale, seed, nenv=16, nsteps=60, motion="walk", tile=1):
-    recs = _oracle_states(model, oracle_clips[motion], nenv, nsteps, scale, seed) * tile
+def _run_teacher_forced(model, clips, oracle_clips, torch, scale, seed, nenv=16, nsteps=60, motion="walk", tile=1,
+                        oracle_model=None, **engine_kw):
+    recs = _oracle_states(oracle_model or model, oracle_clips[motion], nenv, nsteps, scale, seed) * tile
     n = len(recs)
-    eng = _engine(model, clips, n, torch, motion=motion)
+    eng = _engine(model, clips, n, torch, motion=motion, **engine_kw)
     dev = eng.device
     f32 = lambda key: torch.tensor(np.array([r["before"][key] for r in recs]), dtype=torch.float32, device=dev)
     eng.set_state(f32("qpos"), f32("qvel"), f32("warm"), f32("ctrl"))
@@ -351,6 +352,39 @@ def test_narrowphase_coverage_all_pair_types(model, clips, oracle_clips, torch_m
     assert worst_dist < 2e-6
     assert worst_acc < 2e-3
     eng.close()
+
+
+def _gates(res):
+    hard = [m for m in res["contact_mismatch"] if not m[3]]
+    assert len(hard) == 0, hard[:3]
+    ok = np.ones(len(res["qpos"]), bool)
+    for m in res["contact_mismatch"]:
+        ok[m[0]] = False
+    ok[res["stage_flips"]] = False
+    assert len(res["stage_flips"]) <= 0.01 * len(ok)
+    assert res["qpos"][ok].max() < TOL_QPOS and res["qvel"][ok].max() < TOL_QVEL
+    assert res["obs"][ok].max() < TOL_OBS and res["rew"][ok].max() < TOL_REW
+    assert not res["done"][ok].any()
+    return ok
+
+
+@pytest.mark.parametrize("how", ["xml", "config"])
+def test_euler_integrator_parity(model, clips, oracle_clips, torch_mod, how):
+    """north_star's semi-implicit Euler option (MuJoCo's mj_Euler: one forward evaluation, joint damping integrated
+    implicitly through a second factorisation of M + h B): HIP vs the oracle's Euler on 960 teacher-forced states at
+    full torque scale, selected either by the model (<option integrator="Euler">) or by DmConfig.integrator on the RK4
+    model; and the Euler step differs from the RK4 step of the same state (the option really switches)."""
+    from deepmimic_mujoco_amd.model import INT_EULER, compile_mjcf
+    me = compile_mjcf()
+    me.integrator = me.cstruct.integrator = INT_EULER
+    if how == "xml":
+        res = _run_teacher_forced(me, clips, oracle_clips, torch_mod, 2.0, 5)
+    else:
+        res = _run_teacher_forced(model, clips, oracle_clips, torch_mod, 2.0, 5, oracle_model=me, integrator="Euler")
+    ok = _gates(res)
+    print("euler", how, "qpos", res["qpos"][ok].max(), "qvel", res["qvel"][ok].max(), "obs", res["obs"][ok].max())
+    rk = _run_teacher_forced(model, clips, oracle_clips, torch_mod, 2.0, 5, oracle_model=me, integrator="RK4")
+    assert np.median(rk["qvel"]) > 10 * np.median(res["qvel"])     # RK4 engine vs Euler oracle: visibly different
 
 
 def test_three_wave_kernel_variant_parity(model, clips, oracle_clips, torch_mod):

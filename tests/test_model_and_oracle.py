@@ -158,3 +158,26 @@ def test_oracle_episode_length_is_1001(model, oracle_clips):
         if done:
             break
     assert n == 1001 and reason == 3
+
+
+def test_oracle_euler_integrates_damping_implicitly():
+    """[EXT mj_Euler] (M + h B) qacc' = qfrc_smooth + qfrc_constraint = M qacc; qvel += h qacc'; qpos from the NEW qvel."""
+    m = M.compile_mjcf()
+    m.integrator = m.cstruct.integrator = M.INT_EULER
+    s = OracleSim(m)
+    rng = np.random.default_rng(3)
+    q = m.qpos0.copy()
+    q[7:] = rng.uniform(-0.5, 0.5, 28)
+    q[2] = 0.95
+    v = rng.normal(size=34)
+    s.set("qpos", q); s.set("qvel", v); s.set("ctrl", rng.uniform(-1, 1, 28))
+    assert s.forward() == 0
+    Md, qacc = _dense_M(m, s.get("qM")), s.get("qacc")
+    h, B = m.timestep, np.diag(m.dof_damping)
+    want = np.linalg.solve(Md + h * B, Md @ qacc)
+    assert np.abs(want - qacc).max() > 1e-3                      # the implicit treatment matters (damping 1 on hinges)
+    assert s.step() == 0
+    v1 = s.get("qvel")
+    assert np.abs(v1 - (v + h * want)).max() < 1e-9
+    assert np.abs(s.get("qpos")[:3] - (q[:3] + h * v1[:3])).max() < 1e-12
+    assert np.abs(s.get("qpos")[7:] - (q[7:] + h * v1[6:])).max() < 1e-12
