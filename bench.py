@@ -29,18 +29,124 @@ HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
 EVENT_STRIDE = 4                    # every 4th launch of the timed region carries a HIP event pair
 
 
-def measured_traffic_bytes():
-    """HBM bytes per launch of dm_step_kernel from the committed PMC profile (same command, 4096 envs)."""
+def _newest_pmc():
+    """Counter means of dm_step_kernel from the newest committed PMC profile (same command, 4096 envs)."""
     import csv
     import glob
+    import re
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dm_step_kernel.csv"))
+    path = max(files, key=lambda f: tuple(int(x) for x in re.findall(r"\d+", os.path.basename(f))))   # newest round / version
+    vals = {r["counter"]: float(r["mean_per_dispatch_over_last_10_dispatches"]) for r in csv.DictReader(open(path))}
+    return vals, os.path.basename(path)
+
+
+def measured_traffic_bytes():
+    """HBM bytes per launch of dm_step_kernel from the committed PMC profile."""
     try:
-        import re
-        files = glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dm_step_kernel.csv"))
-        path = max(files, key=lambda f: tuple(int(x) for x in re.findall(r"\d+", os.path.basename(f))))   # newest round / version
-        vals = {r["counter"]: float(r["mean_per_dispatch_over_last_10_dispatches"]) for r in csv.DictReader(open(path))}
+        vals, _ = _newest_pmc()
         return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
     except Exception:
         return None
+
+
+def valu_view(kernel_ms, n_envs):
+    """What actually bounds dm_step_kernel (the HBM roofline is nominal): vector-instruction issue.
+    Counters from the newest committed PMC file (one wave = one env-step; SQ_* cycle counters are in quad-cycles);
+    issue cost 2 cycles per wave64 VALU instruction on a SIMD-32 (MI355X_MICROARCH.md), 1024 SIMDs, two resident
+    waves per SIMD; the launch duration is the one measured live in THIS run."""
+    try:
+        v, src = _newest_pmc()
+        waves = v["SQ_WAVES"]
+        insts = v["SQ_INSTS_VALU"] / waves
+        wave_cycles = 4.0 * v["SQ_WAVE_CYCLES"] / waves
+        clock_ghz = 2.4
+        simds, resident = 1024, 2
+        rounds = n_envs / float(simds * resident)
+        steady_cycles = rounds * wave_cycles                       # launch length if every SIMD always held two waves
+        launch_cycles = kernel_ms * 1e-3 * clock_ghz * 1e9
+        return {"insts_per_env_step": insts, "salu_per_env_step": v["SQ_INSTS_SALU"] / waves, "lds_per_env_step": v["SQ_INSTS_LDS"] / waves,
+                "vmem_per_env_step": v["SQ_INSTS_VMEM"] / waves, "wave_cycles_per_env_step": wave_cycles,
+                "issue_frac_steady": resident * insts * 2.0 / wave_cycles,
+                "issue_frac_launch": n_envs * insts * 2.0 / (simds * launch_cycles),
+                "wait_frac": v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], "wait_inst_frac": v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"],
+                "rampdown_frac": max(0.0, 1.0 - steady_cycles / launch_cycles),
+                "vector_tflops_frac": None, "clock_ghz_assumed": clock_ghz, "counters_from": "profiles/" + src}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
+
+
+def _mlp_flops_per_step(B, D, H1, H2, A):
+    """Algorithmic FLOPs of one PPO minibatch gradient (policy trunk D-H1-H2-A, value trunk D-H1-H2-1): forward,
+    input gradients (no gradient into the observations), weight gradients."""
+    def trunk(a):
+        l1, l2, l3 = D * H1, H1 * H2, H2 * a
+        return 2.0 * B * ((l1 + l2 + l3) + (l2 + l3) + (l1 + l2 + l3))
+    return trunk(A) + trunk(1)
+
+
+def ppo_loop_record(args, dev, local_rank, rank, world, launched, barrier):
+    """PPO loop of BASELINE configs 3 (one GPU: 4096 envs `walk`) / 4 (per-GPU share: 4096 envs `spinkick`): rollout incl.
+    policy inference, GAE, 20 epochs x 32 minibatches of 4096 with ONE all-reduce of the flat gradient per optimizer step
+    when several ranks run.  One untimed iteration (graph capture, warm-up), then `iters` timed ones."""
+    import torch
+    import torch.distributed as dist
+    from deepmimic_mujoco_amd.deepmimic_env import HipDeepMimicVecEnv
+    from deepmimic_mujoco_amd.ppo import PPO
+    motion = "spinkick" if world > 1 else "walk"
+    rec = {"motion": motion, "envs_per_gpu": args.envs, "horizon": 32, "epochs": 20, "minibatch": 4096, "n_gpus": world,
+           "timed_iterations": args.ppo_iters}
+    for arch in ((256, 128), (1024, 512)):
+        key = "%d,%d" % arch
+        try:
+            env = HipDeepMimicVecEnv(args.envs, motion=motion, device=local_rank, seed=1234 + 7919 * rank)
+            ppo = PPO(env, net_arch=arch, n_steps=32, batch_size=4096, n_epochs=20, seed=0)
+            ppo.train(ppo.collect_rollouts())                    # untimed: captures the graphs
+            torch.cuda.synchronize()
+            barrier()
+            t_roll = t_train = 0.0
+            t0 = time.perf_counter()
+            for _ in range(args.ppo_iters):
+                a = time.perf_counter()
+                buf = ppo.collect_rollouts()
+                torch.cuda.synchronize()
+                b = time.perf_counter()
+                ppo.train(buf)
+                torch.cuda.synchronize()
+                t_roll += b - a
+                t_train += time.perf_counter() - b
+            barrier()
+            dt = time.perf_counter() - t0
+            coll_us = None
+            if launched and world > 1:
+                g = ppo.optimizer.flat_g if hasattr(ppo.optimizer, "flat_g") else ppo.grad_sync.flat
+                for _ in range(5):
+                    dist.all_reduce(g)
+                torch.cuda.synchronize()
+                c0 = time.perf_counter()
+                for _ in range(50):
+                    dist.all_reduce(g)
+                torch.cuda.synchronize()
+                coll_us = (time.perf_counter() - c0) / 50 * 1e6
+                t = torch.tensor([dt, t_roll, t_train], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt, t_roll, t_train = (float(x) for x in t)
+            steps_per_iter = 32 * args.envs * world
+            nopt = 20 * (32 * args.envs // 4096)
+            opt_us = t_train / (args.ppo_iters * nopt) * 1e6
+            flops = _mlp_flops_per_step(4096, 67, arch[0], arch[1], 28)
+            rec[key] = {"loop_env_steps_per_s": args.ppo_iters * steps_per_iter / dt,
+                        "rollout_env_steps_per_s": args.ppo_iters * steps_per_iter / t_roll,
+                        "optimizer_step_us": opt_us, "optimizer_steps_per_iteration": nopt,
+                        "mfma_frac": flops / (opt_us * 1e-6) / 157.3e12, "flops_per_optimizer_step": flops,
+                        "collective_us": coll_us, "collectives_per_iteration": nopt if world > 1 else 0,
+                        "grad_floats": int(sum(p.numel() for p in ppo.policy.parameters())),
+                        "learner_path": ("dist two-graph" if getattr(ppo, "_dg", None) is not None else
+                                         "epoch graph" if getattr(ppo, "_eg", None) is not None else "eager"),
+                        "mean_reward": ppo.stats.get("mean_reward")}
+            env.close()
+        except Exception as e:  # noqa: BLE001  (never lose the headline line to the auxiliary record)
+            rec[key] = {"error": repr(e)[:300]}
+    return rec
 
 
 def cpu_baseline(model, mocap, budget_s=12.0):
@@ -53,7 +159,7 @@ def cpu_baseline(model, mocap, budget_s=12.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))                              # the one-GPU box gives a 16-core share whatever the affinity mask says
+    cores = max(1, cores)                                       # threads actually used = the affinity mask of this process
     t0 = time.perf_counter()
     bench_steps(model, clip, 4, 250, 1234)                      # single-thread rate, to size the sample
     rate1 = 1000 / (time.perf_counter() - t0)
@@ -79,6 +185,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the auxiliary two-sub-batch measurement (profiling runs)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--no-ppo-loop", action="store_true", help="skip the auxiliary PPO-loop record (configs 3 / 4)")
+    ap.add_argument("--ppo-iters", type=int, default=2, help="timed PPO iterations per net in the ppo_loop record")
     args = ap.parse_args()
 
     import torch
@@ -94,10 +202,12 @@ def main():
     launched = "RANK" in os.environ
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        tmo = datetime.timedelta(minutes=5)        # a rank that dies must not leave the others waiting forever
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev), timeout=tmo)
         else:
-            dist.init_process_group(args.dist_backend)
+            dist.init_process_group(args.dist_backend, timeout=tmo)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     local_rank = local_dev
@@ -180,6 +290,13 @@ def main():
         for e2, _, _, _ in subs:
             e2.close()
 
+    ppo_loop = None
+    if not args.no_ppo_loop and args.actions == "random" and N % 4096 == 0:
+        try:
+            ppo_loop = ppo_loop_record(args, dev, local_rank, rank, world, launched, barrier)
+        except Exception as e:  # noqa: BLE001
+            ppo_loop = {"error": repr(e)[:300]}
+
     if rank == 0:
         total_steps = args.steps * N * world
         value = total_steps / dt
@@ -200,8 +317,11 @@ def main():
                          "traffic_note": "bytes/launch = (FETCH_SIZE + WRITE_SIZE) * 1024 from the separate rocprofv3 --pmc passes "
                                          "committed under profiles/ (4-byte-per-lane accesses: FETCH_SIZE uncalibrated on gfx950)",
                          "kernel": "dm_step_kernel", "kernel_ms": kms, "kernel_launches_timed": kcount, "kernel_event_stride": EVENT_STRIDE,
-                         "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP},
+                         "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
+                         "valu": valu_view(kms, N) if (N == 4096 and args.actions == "random") else None},
         }
+        if ppo_loop is not None:
+            line["ppo_loop"] = ppo_loop
         if pipelined is not None:
             line["pipelined"] = pipelined
         if world == 1 and not args.no_cpu_baseline:

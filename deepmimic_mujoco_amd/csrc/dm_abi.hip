@@ -367,6 +367,10 @@ static int launch(DmEngine *e, DmLaunch &P, int nslots, void *stream) {
   const dim3 grid((P.nslots + DMK_ENVS_PER_BLOCK - 1) / DMK_ENVS_PER_BLOCK), block(64 * DMK_ENVS_PER_BLOCK);
   if (e->cfg.task == DM_TASK_COMBINED) {
     hipLaunchKernelGGL(dm_step_combined_kernel, grid, block, 0, s, P);
+#ifdef DM_EXPERIMENT_W4
+  } else if (e->waves == 4) {
+    hipLaunchKernelGGL(dm_step_kernel_w4, grid, block, 0, s, P);
+#endif
   } else if (e->waves == 3 || (e->waves == 0 && P.nslots >= 6144)) {
     hipLaunchKernelGGL(dm_step_kernel_w3, grid, block, 0, s, P);   // three waves per SIMD pay off from ~1.5 x 4096 envs
   } else {

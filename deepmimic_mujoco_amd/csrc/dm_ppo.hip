@@ -305,8 +305,10 @@ extern "C" int dm_ppo_gather(const long long *idx, int B, const float *obs, int 
 // Gradient-norm clipping + Adam on one flat parameter / gradient / moment buffer (all tensors of the policy are views
 // of it): three launches instead of the ~9 of clip_grad_norm_ + torch.optim.Adam.  Semantics of
 // torch.nn.utils.clip_grad_norm_(max_norm) followed by torch.optim.Adam(lr, betas, eps) (no weight decay, no amsgrad).
-// state[0] = sum of squared gradients (scratch), state[1] = step count (float), both on the device so the sequence
-// can be replayed from a captured hipGraph.
+// state[0] = scratch, state[1] = step count (float), state[2 .. 2 + DM_ADAM_PARTIALS) = per-block partial sums of
+// squares — all on the device so the sequence can be replayed from a captured hipGraph.  The squared norm is reduced
+// in a FIXED order (per-block partials, then one tree every block repeats): data-parallel replicas that hold the same
+// all-reduced gradient then compute bit-identical updates (a float-atomic sum would let them drift apart by ulps).
 namespace {
 __global__ void adam_begin_kernel(float *state) {
   if (threadIdx.x == 0) { state[0] = 0.f; state[1] += 1.f; }
@@ -318,11 +320,13 @@ __global__ void adam_sumsq_kernel(const float *g, int n, float *state) {
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&state[0], red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) state[2 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 __global__ void adam_update_kernel(float *p, const float *g, float *m, float *v, int n, float lr, float b1, float b2, float eps,
                                    float max_norm, const float *state) {
-  const float total = sqrtf(state[0]);
+  float part = 0;
+  for (int i = threadIdx.x & 63; i < (int)gridDim.x; i += 64) part += state[2 + i];   // same partials, same order in every block
+  const float total = sqrtf(ppo_wave_sum(part));
   const float coef = fminf(1.f, max_norm / (total + 1e-6f));          // clip_grad_norm_
   const float t = state[1];
   const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));

@@ -369,7 +369,7 @@ class FlatAdam:
         self.flat_p = torch.empty(n, device=dev)
         self.flat_g = torch.zeros(n, device=dev)
         self.m, self.v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
-        self.state2 = torch.zeros(2, device=dev)          # [sum of squares scratch, step count]
+        self.state2 = torch.zeros(2 + 1024, device=dev)   # [scratch, step count, DM_ADAM_PARTIALS per-block sums of squares]
         self.slices = []
         off = 0
         with torch.no_grad():

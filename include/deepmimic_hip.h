@@ -200,8 +200,10 @@ int dm_ppo_gather(const long long *idx, int B, const float *obs, int D, const fl
                   void *stream);
 
 /* torch.nn.utils.clip_grad_norm_(max_norm) + torch.optim.Adam.step() [EXT, as used by SB3's PPO.train] on one flat
- * parameter / gradient / moment buffer of n floats.  state2 = {scratch, step count} on the device (zero-initialised by
- * the caller once); no weight decay, no amsgrad. */
+ * parameter / gradient / moment buffer of n floats.  state2 = {scratch, step count, DM_ADAM_PARTIALS partial sums} on the
+ * device: 2 + DM_ADAM_PARTIALS floats, zero-initialised by the caller once; no weight decay, no amsgrad.  The gradient
+ * norm is reduced in a fixed order, so replicas holding the same (all-reduced) gradient stay bit-identical. */
+#define DM_ADAM_PARTIALS 1024
 int dm_adam_clip_step(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
                       float max_norm, float *state2, void *stream);
 /* the same without the begin launch (state2 prepared by dm_ppo_mlp_grad's adam_state2 fold): two launches */
