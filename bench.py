@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the auxiliary two-sub-batch measurement (profiling runs)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--integrator", default="model", choices=["model", "RK4", "Euler"],
+                    help="model = the XML's (RK4, the headline); Euler = north_star's semi-implicit Euler option (auxiliary figure)")
     ap.add_argument("--no-ppo-loop", action="store_true", help="skip the auxiliary PPO-loop record (configs 3 / 4)")
     ap.add_argument("--ppo-iters", type=int, default=2, help="timed PPO iterations per net in the ppo_loop record")
     args = ap.parse_args()
@@ -225,7 +227,7 @@ def main():
     mocap = MocapDM(model=model)
     mocap.load_mocap(MotionConfig(args.motion).mocap_path)
     N = args.envs
-    eng = HipEngine(model, N, device=local_rank, seed=1234 + rank, auto_reset=True)
+    eng = HipEngine(model, N, device=local_rank, seed=1234 + rank, auto_reset=True, integrator=args.integrator)
     eng.load_clip(0, mocap)
     L = eng.clip_len[0]
     out = eng.alloc_outputs()
@@ -291,7 +293,7 @@ def main():
             e2.close()
 
     ppo_loop = None
-    if not args.no_ppo_loop and args.actions == "random" and N % 4096 == 0:
+    if not args.no_ppo_loop and args.actions == "random" and N == 4096 and args.integrator != "Euler":
         try:
             ppo_loop = ppo_loop_record(args, dev, local_rank, rank, world, launched, barrier)
         except Exception as e:  # noqa: BLE001
@@ -301,15 +303,16 @@ def main():
         total_steps = args.steps * N * world
         value = total_steps / dt
         achieved = N * ALGO_BYTES_PER_ENV_STEP / (kms * 1e-3) / 1e9
-        traffic = measured_traffic_bytes() if (N == 4096 and args.actions == "random") else None
+        traffic = measured_traffic_bytes() if (N == 4096 and args.actions == "random" and args.integrator != "Euler") else None
         line = {
             "metric": "env-steps/sec (whole node), 34-DoF humanoid, 4096 envs, at 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg2_random_torque: %d envs/GPU, humanoid3d, clip %s, RK4 h=0.0166 PGS<=50, "
+            "config": {"workload": "cfg2_random_torque: %d envs/GPU, humanoid3d, clip %s, %s h=0.0166 PGS<=50, "
                                    "full DPEnv.step (physics+obs+reward+done+auto-reset), actions %s"
-                                   % (N, args.motion, "U(-2,2) device RNG" if args.actions == "random" else "zero"),
+                                   % (N, args.motion, "Euler (implicit damping)" if args.integrator == "Euler" else "RK4",
+                                      "U(-2,2) device RNG" if args.actions == "random" else "zero"),
                        "envs_per_gpu": N, "parallelism": "env-sharded x%d, no data-path collective" % world,
                        "done_fraction_last_step": done_frac},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -318,7 +321,7 @@ def main():
                                          "committed under profiles/ (4-byte-per-lane accesses: FETCH_SIZE uncalibrated on gfx950)",
                          "kernel": "dm_step_kernel", "kernel_ms": kms, "kernel_launches_timed": kcount, "kernel_event_stride": EVENT_STRIDE,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
-                         "valu": valu_view(kms, N) if (N == 4096 and args.actions == "random") else None},
+                         "valu": valu_view(kms, N) if (N == 4096 and args.actions == "random" and args.integrator != "Euler") else None},
         }
         if ppo_loop is not None:
             line["ppo_loop"] = ppo_loop

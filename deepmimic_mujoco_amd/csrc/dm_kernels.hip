@@ -901,6 +901,11 @@ __device__ __forceinline__ float fwd_smooth(GDev &T, const int lane, const float
   return xs;
 }
 
+// Euler integrator only: out of line, so that the RK4 path's register allocation is the one it had without the option
+__device__ __noinline__ float euler_damped_solve(GDev &T, const int lane, const float rhs) {
+  return fwd_smooth<true>(T, lane, rhs);
+}
+
 // ---- forward evaluation, part 2: collision detection -> contact list in LDS; returns ncon | overflow << 8
 __device__ __forceinline__ int fwd_collide(GDev &T, const int lane) {
   EnvLds &S = g_S;
@@ -1772,7 +1777,7 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
         // a' = a - (M + h B)^-1 h B a; velocity first, then the position with the NEW velocity
         const float hb = (lane < DMK_NV) ? h * T.d_damp[lk] : 0.f;
         float a2 = qacc_out;
-        if (__any(hb != 0.f)) a2 = qacc_out - fwd_smooth<true>(T, lane, hb * qacc_out);
+        if (__any(hb != 0.f)) a2 = qacc_out - euler_damped_solve(T, lane, hb * qacc_out);
         accv = a2;
         accq = x0v + h * a2;
         it = 3;

@@ -599,7 +599,7 @@ class PPO:
                     torch.cuda.current_stream(dev).wait_stream(side)
                     torch.cuda.synchronize(dev)
                     st["graph"] = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(st["graph"]):
+                    with torch.cuda.graph(st["graph"], **(dict(capture_error_mode="thread_local") if dist.is_initialized() else {})):
                         whole()
                 st["graph"].replay()
             else:
@@ -651,7 +651,7 @@ class PPO:
                 cur.wait_stream(streams[k])
             torch.cuda.synchronize(dev)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, **(dict(capture_error_mode="thread_local") if dist.is_initialized() else {})):
                 cap = torch.cuda.current_stream(dev)
                 for k in range(K):
                     streams[k].wait_stream(cap)
@@ -901,16 +901,19 @@ class PPO:
             for _ in range(3):
                 warm()
         torch.cuda.current_stream(dev).wait_stream(side)
+        # with a process group alive, its watchdog thread queries events while we capture: "global" capture mode would
+        # fail the capture on that foreign call, "thread_local" only polices this thread
+        mode = dict(capture_error_mode="thread_local") if dist.is_initialized() else {}
         if isinstance(body, (list, tuple)):      # several graphs captured back to back (e.g. around a collective)
             graph, out = [], []
             for b in body:
                 g_ = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_):
+                with torch.cuda.graph(g_, **mode):
                     out.append(b())
                 graph.append(g_)
         else:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, **mode):
                 out = body()
         with torch.no_grad():
             for p, q in zip(self.policy.parameters(), snap_p):
