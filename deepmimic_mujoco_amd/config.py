@@ -19,8 +19,16 @@ class RobotConfig:
             self.extra_contact_geom_names = None
             self.endeffector_geom_names = ["left_ankle", "right_ankle", "left_wrist", "right_wrist"]
             self.low_z = 0.7
-        elif self.robot == "unitree_g1":
-            raise NotImplementedError("unitree_g1 is a 'next' row (SURVEY §8f-2); only humanoid3d is built")
+        elif self.robot == "unitree_g1":  # src/config.py:14-22 — names only: the G1 physics is not built;
+            # the retargeting tool (retarget.py) needs the asset path, the envs refuse this robot (model.load_model)
+            self.torso_body_name = "pelvis"
+            self.lfoot_geom_name = "left_foot"
+            self.rfoot_geom_name = "right_foot"
+            self.floor_geom_name = "floor"
+            self.extra_contact_geom_names = ["left_foot_lheel", "left_foot_rheel", "left_foot_ltoe", "left_foot_rtoe",
+                                             "right_foot_lheel", "right_foot_rheel", "right_foot_ltoe", "right_foot_rtoe"]
+            self.endeffector_geom_names = ["left_foot", "right_foot", "left_hand", "right_hand"]
+            self.low_z = 0.4
         else:
             raise Exception("Unknown robot: %s" % (self.robot))
         self.env_name = "deepmimic_" + self.robot

@@ -165,7 +165,9 @@ def compile_mjcf(xml_path: str | None = None) -> CompiledModel:
 
     comp = root.find("compiler")
     if comp is None or comp.get("angle") != "radian" or comp.get("inertiafromgeom") != "true":
-        raise ValueError("unsupported <compiler>: need angle=radian inertiafromgeom=true")
+        raise NotImplementedError("unsupported <compiler>: the MJCF subset built here is the humanoid3d asset's (angle=radian, "
+                                  "inertiafromgeom=true, primitive geoms); the Unitree G1 model (explicit inertials, mesh "
+                                  "geoms, frictionloss) is SURVEY §8f-2, not built")
 
     dflt = {"joint": {}, "geom": {}, "motor": {}}
     d = root.find("default")

@@ -84,6 +84,24 @@ def main():
                         extra_obs=extra_obs, extra_act=extra_act)
     print("policy:", pol.W0.shape, pol.W2.shape, pol.WA.shape, "KAT ok")
 
+    # retarget tool (src/retarget.py): the reference's own outputs for the three humanoid3d clips it was run on are
+    # the golden vectors (numeric frames + joint names); plus Euler helper vectors for the axis orders the tool uses
+    import json
+    out = {}
+    for motion in ("run", "walk", "getup_facedown"):
+        d = json.load(open(os.path.join(REF, "mujoco", "motions", "unitree_g1_%s.txt" % motion)))
+        assert d["Format"] == "direct_qpos"
+        out[motion + "_frames"] = np.array(d["Frames"], np.float64)
+        out[motion + "_loop"] = np.array(d["Loop"])
+        out["joint_names"] = np.array(d["JointNames"])
+        out["labels"] = np.array(d["Labels"])
+    eul = rng.uniform(-np.pi, np.pi, size=(300, 3))
+    eul[:20, 1] = np.pi / 2 * np.sign(eul[:20, 1])                         # gimbal lock rows
+    mats = np.array([tr.euler_matrix(e[0], e[1], e[2], "rxyz")[:3, :3] for e in eul])
+    yxz = np.array([tr.euler_from_matrix(m, "ryxz") for m in mats])
+    np.savez_compressed(os.path.join(HERE, "retarget_golden.npz"), euler_rxyz_in=eul, matrix_rxyz=mats, euler_ryxz_out=yxz, **out)
+    print("retarget:", {k: v.shape for k, v in out.items()})
+
 
 if __name__ == "__main__":
     main()

@@ -62,8 +62,12 @@ def test_config_mirrors_reference_names():
     mc = MotionConfig()
     assert mc.motion == "walk" and os.path.exists(mc.mocap_path) and os.path.exists(mc.xml_path)
     assert "getup_facedown" in mc.floor_motions and "walk" not in mc.acyclical_motions
+    g1 = RobotConfig("unitree_g1")                       # names for the retargeting tool; the physics refuses the model
+    assert g1.torso_body_name == "pelvis" and g1.low_z == 0.4 and len(g1.extra_contact_geom_names) == 8
+    assert os.path.exists(g1.xml_path)
+    from deepmimic_mujoco_amd.model import compile_mjcf
     with pytest.raises(NotImplementedError):
-        RobotConfig("unitree_g1")
+        compile_mjcf(g1.xml_path)
 
 
 def test_c_abi_library_loads_and_exports_every_declared_symbol():
