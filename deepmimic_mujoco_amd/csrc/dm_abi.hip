@@ -371,8 +371,11 @@ static int launch(DmEngine *e, DmLaunch &P, int nslots, void *stream) {
   } else if (e->waves == 4) {
     hipLaunchKernelGGL(dm_step_kernel_w4, grid, block, 0, s, P);
 #endif
-  } else if (e->waves == 3 || (e->waves == 0 && P.nslots >= 6144)) {
-    hipLaunchKernelGGL(dm_step_kernel_w3, grid, block, 0, s, P);   // three waves per SIMD pay off from ~1.5 x 4096 envs
+  } else if (e->waves == 3 || (e->waves == 0 && P.nslots >= 3072)) {
+    // three waves per SIMD (168 VGPRs): faster than the two-wave build from 3 072 envs up since r2 (per-stage laundering of
+    // the lane id: no hoisted lane-compare masks spilled across the stage loop): 13.4 vs 12.9 M at 4 096 envs, 21.4 vs
+    // 17.5 M at 65 536
+    hipLaunchKernelGGL(dm_step_kernel_w3, grid, block, 0, s, P);
   } else {
     hipLaunchKernelGGL(dm_step_kernel, grid, block, 0, s, P);
   }

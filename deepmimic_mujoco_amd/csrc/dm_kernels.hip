@@ -475,6 +475,11 @@ __device__ __noinline__ void np_box_box(EnvLds &S, GPair *pr) {
   S.u.bb.ncand = cnt;
 }
 
+// general-power branch of the impedance: never taken with MuJoCo's default solimp (power 2); out of line so that powf's
+// register footprint does not weigh on the constraint-row phase
+__device__ __noinline__ float impedance_pow(float x, float mid, float power) {
+  return (x <= mid) ? powf(x, power) / powf(mid, power - 1) : 1 - powf(1 - x, power) / powf(1 - mid, power - 1);
+}
 __device__ __forceinline__ float impedance(const float *solimp, float pos, float margin) {
   float dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
   if (dmin == dmax || width <= MINVALF) return 0.5f * (dmin + dmax);
@@ -484,8 +489,7 @@ __device__ __forceinline__ float impedance(const float *solimp, float pos, float
   float y;
   if (power == 1) y = x;
   else if (power == 2) y = (x <= mid) ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);   // MuJoCo default
-  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1);
-  else y = 1 - powf(1 - x, power) / powf(1 - mid, power - 1);
+  else y = impedance_pow(x, mid, power);
   return dmin + y * (dmax - dmin);
 }
 
@@ -1721,7 +1725,16 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
     GDev *Tp = (GDev *)P.T;
     asm volatile("" : "+s"(Tp));
     GDev &Ts = *Tp;
-    fwd_smooth(Ts, lane);
+#ifndef DM_NO_LANE_LAUNDER
+    // the lane id is laundered per stage too: per-lane compares (lane == k, lane < n) are then recomputed inside the stage
+    // (one v_cmp) instead of being hoisted out of the stage loop into SGPRs that spill to VGPR lanes (v_writelane / two
+    // v_readlane per use)
+    int lane_st = lane;
+    asm volatile("" : "+v"(lane_st));
+#else
+    const int lane_st = lane;
+#endif
+    fwd_smooth(Ts, lane_st);
     if (it == 0) {  // capture X0 (after normalisation)
       x0v = (lane < DMK_NV) ? S.qvel[lk] : 0.f;
       x0q = (lane < 3) ? S.qpos[lane] : ((lane >= 6 && lane < DMK_NV) ? S.qpos[lane + 1] : 0.f);
@@ -1729,9 +1742,9 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
       curv = x0v;
     }
     {
-      const int cr = fwd_collide(Ts, lane);
+      const int cr = fwd_collide(Ts, lane_st);
       ncon = cr & 0xFF;
-      qacc_out = fwd_constraint(Ts, lane, ncon, cr >> 8, P.debug ? P.debug + (size_t)env * DM_DEBUG_STRIDE + 352 : nullptr,
+      qacc_out = fwd_constraint(Ts, lane_st, ncon, cr >> 8, P.debug ? P.debug + (size_t)env * DM_DEBUG_STRIDE + 352 : nullptr,
                                 P.ar_scratch + (size_t)env * DMK_MAXROW * DMK_MAXROW);
       nefc = S.info[1]; nlimit = S.info[2]; solver_iter = S.info[3]; overflow = S.info[4];
       if (it < 4) { stage_ncon |= (unsigned)(ncon & 0xFF) << (8 * it); stage_nefc |= (unsigned)(nefc & 0xFF) << (8 * it); }
@@ -2038,9 +2051,8 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_
 extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_PER_SIMD) dm_step_combined_kernel(DmLaunch P) {
   step_body<1>(P);
 }
-// Same body compiled for three waves per SIMD (168 VGPRs, ~190 extra scratch accesses): +8..10 % once the batch
-// fills more than two rounds of the two-wave kernel (>= 6144 envs); at 4096 envs it would leave a one-third-full
-// second round, so dm_step picks the variant from the batch size.
+// Same body compiled for three waves per SIMD (168 VGPRs, 93 spilled): dm_step launches it from 3 072 envs up
+// (dm_abi.hip: launch()); below that the batch does not fill two waves per SIMD and the 256-VGPR build is faster.
 extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, 3) dm_step_kernel_w3(DmLaunch P) {
   step_body<0>(P);
 }

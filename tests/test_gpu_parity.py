@@ -388,7 +388,7 @@ def test_euler_integrator_parity(model, clips, oracle_clips, torch_mod, how):
 
 
 def test_three_wave_kernel_variant_parity(model, clips, oracle_clips, torch_mod):
-    """Batches of >= 6144 envs run dm_step_kernel_w3 (the same body compiled for 3 waves/SIMD, 168 VGPRs): same parity
+    """Batches of >= 3072 envs run dm_step_kernel_w3 (the same body compiled for 3 waves/SIMD, 168 VGPRs): same parity
     gates as the two-wave kernel, on 960 oracle states tiled to 6720 envs."""
     res = _run_teacher_forced(model, clips, oracle_clips, torch_mod, 2.0, 3, tile=7)
     assert len(res["qpos"]) == 6720
