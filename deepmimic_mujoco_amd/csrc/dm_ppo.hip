@@ -292,17 +292,15 @@ extern "C" int dm_ppo_gather(const long long *idx, int B, const float *obs, int 
 
 // ---------------------------------------------------------------------------------------------------------------
 // Gradient-norm clipping + Adam on one flat parameter / gradient / moment buffer (all tensors of the policy are views
-// of it): three launches instead of the ~9 of clip_grad_norm_ + torch.optim.Adam.  Semantics of
+// of it): two launches instead of the ~9 of clip_grad_norm_ + torch.optim.Adam.  Semantics of
 // torch.nn.utils.clip_grad_norm_(max_norm) followed by torch.optim.Adam(lr, betas, eps) (no weight decay, no amsgrad).
 // state[0] = scratch, state[1] = step count (float), state[2 .. 2 + DM_ADAM_PARTIALS) = per-block partial sums of
 // squares — all on the device so the sequence can be replayed from a captured hipGraph.  The squared norm is reduced
 // in a FIXED order (per-block partials, then one tree every block repeats): data-parallel replicas that hold the same
 // all-reduced gradient then compute bit-identical updates (a float-atomic sum would let them drift apart by ulps).
 namespace {
-__global__ void adam_begin_kernel(float *state) {
-  if (threadIdx.x == 0) { state[0] = 0.f; state[1] += 1.f; }
-}
-__global__ void adam_sumsq_kernel(const float *g, int n, float *state) {
+__global__ void adam_sumsq_kernel(const float *g, int n, float *state, int bump_step) {
+  if (bump_step && blockIdx.x == 0 && threadIdx.x == 0) state[1] += 1.f;    // Adam's step count (read by the update launch)
   float s = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s += g[i] * g[i];
   s = ppo_wave_sum(s);
@@ -349,8 +347,7 @@ extern "C" int dm_adam_clip_step(float *p, const float *g, float *m, float *v, i
   hipStream_t s = (hipStream_t)stream;
   int blocks = (n + 256 * 8 - 1) / (256 * 8);
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(adam_begin_kernel, dim3(1), dim3(64), 0, s, state2);
-  hipLaunchKernelGGL(adam_sumsq_kernel, dim3(blocks), dim3(256), 0, s, g, n, state2);
+  hipLaunchKernelGGL(adam_sumsq_kernel, dim3(blocks), dim3(256), 0, s, g, n, state2, 1);      // step count folded in: two launches
   hipLaunchKernelGGL(adam_update_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, max_norm, state2);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
@@ -361,7 +358,7 @@ extern "C" int dm_adam_clip_update(float *p, const float *g, float *m, float *v,
   hipStream_t s = (hipStream_t)stream;
   int blocks = (n + 256 * 8 - 1) / (256 * 8);
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(adam_sumsq_kernel, dim3(blocks), dim3(256), 0, s, g, n, state2);
+  hipLaunchKernelGGL(adam_sumsq_kernel, dim3(blocks), dim3(256), 0, s, g, n, state2, 0);
   hipLaunchKernelGGL(adam_update_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, max_norm, state2);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

@@ -305,6 +305,27 @@ class FusedPPOLoss(torch.autograd.Function):
         b = ctx.b
         return (g * b["gm"], g * b["gl"], g * b["gv"]) + (None,) * 8
 
+    @staticmethod
+    def raw(mean, log_std, value, act, old_logp, adv, ret, clip_range, vf_coef, ent_coef, normalize, grad_log_std=None):
+        """The same launch outside autograd: returns (loss, d loss / d mean, d loss / d value) as static buffers and
+        writes d loss / d log_std into ``grad_log_std`` (e.g. the optimizer's arena slice).  The caller seeds the
+        backward pass with ``torch.autograd.backward([mean, value], [gm, gv])``: no `g * grad` products, no gradient
+        tensors handed back through a Function node (three multiplies, an add and a copy per step on the library path)."""
+        from . import _lib
+        import ctypes as C
+        B, A = mean.shape
+        b = FusedPPOLoss.buffers(B, A, mean.device)
+        gl = grad_log_std if grad_log_std is not None else b["gl"]
+        args = [t.detach() for t in (mean, log_std, value, act, old_logp, adv, ret)]
+        assert all(t.is_contiguous() and t.dtype == torch.float32 for t in args)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rc = _lib.load_library().dm_ppo_loss(*[p(t) for t in args], B, A, float(clip_range), float(vf_coef), float(ent_coef),
+                                             1 if normalize else 0, p(b["gm"]), p(gl), p(b["gv"]), p(b["out"]), p(b["scratch"]),
+                                             C.c_void_p(torch.cuda.current_stream(mean.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("dm_ppo_loss failed (%d)" % rc)
+        return b["out"][0], b["gm"], b["gv"]
+
 
 def compute_gae(rewards, values, dones, last_values, gamma, lam):
     """SB3 ``RolloutBuffer.compute_returns_and_advantage`` [EXT]: tensors [T, N]; dones[t] is the done
@@ -357,7 +378,7 @@ class FlatGradAllReduce:
 class FlatAdam:
     """clip_grad_norm_ + Adam on one flat buffer (`dm_adam_clip_step`, csrc/dm_ppo.hip): every parameter of the policy
     becomes a view of `flat_p`, every gradient is gathered in `flat_g` (the HipLinear layers write theirs there
-    directly), and the whole update is three launches.  With several ranks `flat_g` is also what is all-reduced: the
+    directly), and the whole update is two launches.  With several ranks `flat_g` is also what is all-reduced: the
     one collective of the data-parallel learner, without staging copies.  GPU only; `state` mimics torch.optim's layout
     far enough for the snapshot / restore around hipGraph capture."""
 
@@ -820,7 +841,7 @@ class PPO:
         vl = torch.nn.functional.mse_loss(ret, value)
         return pg + self.vf_coef * vl - self.ent_coef * entropy.mean()
 
-    def _loss_fused(self, obs, act, adv, ret, old_logp):
+    def _trunks(self, obs):
         # The policy and value trunks are independent until the loss: the value trunk runs on a second stream, forward
         # and (autograd replays each node on its forward stream) backward, so the two chains of small launch-bound
         # kernels overlap — also as parallel branches of the captured hipGraph.
@@ -836,6 +857,10 @@ class PPO:
         else:
             mean = self.policy.action_net(self.policy.pi(obs))
             value = self.policy.value_net(self.policy.vf(obs)).squeeze(-1)
+        return mean, value
+
+    def _loss_fused(self, obs, act, adv, ret, old_logp):
+        mean, value = self._trunks(obs)
         return FusedPPOLoss.apply(mean, self.policy.log_std, value, act, old_logp, adv, ret, self.clip_range, self.vf_coef,
                                   self.ent_coef, self.normalize_advantage and obs.shape[0] > 1)
 
@@ -856,6 +881,19 @@ class PPO:
             # every gradient lands in one flat buffer (one memset), clipping + Adam are one fused update on it, and
             # with several ranks that buffer is the operand of the ONE collective of the data-parallel learner
             self.optimizer.zero_grad()
+            if self.fused_loss and obs.is_cuda:
+                mean, value = self._trunks(obs)
+                gls = self.optimizer.slices[[id(q) for q in self.optimizer.params].index(id(self.policy.log_std))]
+                loss, gm, gv = FusedPPOLoss.raw(mean.contiguous(), self.policy.log_std, value.contiguous(), act, old_logp, adv, ret,
+                                                self.clip_range, self.vf_coef, self.ent_coef,
+                                                self.normalize_advantage and obs.shape[0] > 1, grad_log_std=gls)
+                torch.autograd.backward([mean, value], [gm, gv])
+                if getattr(self, "_vf_stream", None) is not None:
+                    torch.cuda.current_stream(obs.device).wait_stream(self._vf_stream)
+                self.optimizer.gather_grads()
+                self.optimizer.all_reduce()
+                self.optimizer.step()
+                return loss.detach()
             loss = (self._loss_fused if self.fused_loss else self._loss_torch)(obs, act, adv, ret, old_logp)
             loss.backward()
             if getattr(self, "_vf_stream", None) is not None:
