@@ -46,9 +46,10 @@ class _HipLinearFn(torch.autograd.Function):
         p = lambda t: C.c_void_p(t.data_ptr())
         stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         L = _lib.load_library()
-        if max(w.shape) > 256:
-            # layers beyond 256 units: dW on the library GEMM, written straight into the arena (no autograd-owned gradient, so
-            # no copy into the flat buffer afterwards), db by dm_colsum
+        if max(w.shape) > 256 and min(w.shape) > 128:
+            # large square-ish layers: dW on the library GEMM, written straight into the arena (no autograd-owned gradient, so
+            # no copy into the flat buffer afterwards), db by dm_colsum.  Skinny layers of a big net (1024 x 67, 28 x 512,
+            # 1 x 512: K = 4096 reductions into small outputs, ~38 us each in the library) take dm_linear_wgrad below.
             if arena is not None:
                 gw, gb = arena
                 torch.mm(gy.t(), x, out=gw)
@@ -76,8 +77,9 @@ class _HipLinearFn(torch.autograd.Function):
 
 class HipLinear(nn.Linear):
     """nn.Linear whose weight / bias gradients bypass autograd's generic kernels when the batch is a large CUDA minibatch:
-    layers up to 256 x 256 on `dm_linear_wgrad` (the library's K = 4096 GEMMs into tiny outputs take 25 us each), larger ones
-    on the library GEMM + `dm_colsum`, all written straight into the optimizer's flat gradient arena."""
+    layers up to 256 x 256 and skinny layers (one side <= 128) on `dm_linear_wgrad` (the library's K = 4096 GEMMs into small
+    outputs take 25-38 us each), large ones on the library GEMM + `dm_colsum`, all written straight into the optimizer's flat
+    gradient arena."""
 
     def forward(self, x):
         if (x.is_cuda and x.dim() == 2 and x.shape[0] >= 1024 and x.shape[0] % 64 == 0 and x.dtype == torch.float32
