@@ -156,19 +156,44 @@ def cpu_baseline(model, mocap, budget_s=12.0):
     from oracle.oracle import OracleClip, bench_steps
     clip = OracleClip(*mocap.tables())
     try:
-        cores = len(os.sched_getaffinity(0))
+        affinity = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, cores)                                       # threads actually used = the affinity mask of this process
+        affinity = os.cpu_count() or 1
+    # threads actually used = the CPU share of this process: the affinity mask, capped by the cgroup CPU quota when one is
+    # set (the one-GPU box shows 256 cores in the mask and grants 16 of them: 256 threads there run at half the rate of 16)
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota = None if txt[0] == "max" else float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                quota = None if q <= 0 else q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:
+            continue
+    limit = max(1, affinity if quota is None else min(affinity, int(quota + 0.999)))
     t0 = time.perf_counter()
     bench_steps(model, clip, 4, 250, 1234)                      # single-thread rate, to size the sample
     rate1 = 1000 / (time.perf_counter() - t0)
+    # a container may grant fewer CPUs than its affinity mask shows without any quota file saying so: take the thread count
+    # that the box actually rewards, from a short calibration over powers of two up to the mask
+    cand = sorted({c for c in (4, 8, 16, 32, 64, 128, limit) if c <= limit} | {limit})
+    calib = {}
+    for c in cand:
+        with ThreadPoolExecutor(c) as ex:
+            t0 = time.perf_counter()
+            list(ex.map(lambda k: bench_steps(model, clip, 4, 250, 99 + k), range(c)))
+            calib[c] = c * 4 * 250 / (time.perf_counter() - t0)
+    cores = max(calib, key=calib.get)
     nenv = max(2, min(64, int(rate1 * budget_s / 1000)))        # envs per thread, 1000 steps each
     with ThreadPoolExecutor(cores) as ex:                       # ctypes releases the GIL; each call owns its DmoData
         t0 = time.perf_counter()
         list(ex.map(lambda k: bench_steps(model, clip, nenv, 1000, 1234 + k), range(cores)))
         dt = time.perf_counter() - t0
     return {"value": cores * nenv * 1000 / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "affinity_cores": affinity, "cgroup_cpu_quota": quota, "thread_calibration_env_steps_per_s": calib,
             "single_thread_value": rate1,
             "sample": "%d threads x %d envs x 1000 random-torque steps, walk clip, fp64 oracle (oracle/dm_oracle.c)"
                       % (cores, nenv)}
