@@ -365,13 +365,15 @@ static int launch(DmEngine *e, DmLaunch &P, int nslots, void *stream) {
   const bool rec = e->timing && (e->nlaunch++ % e->stride) == 0;
   if (rec) hipEventRecord(e->ev0[evi], s);
   const dim3 grid((P.nslots + DMK_ENVS_PER_BLOCK - 1) / DMK_ENVS_PER_BLOCK), block(64 * DMK_ENVS_PER_BLOCK);
+  const bool three_waves = e->waves == 3 || (e->waves == 0 && P.nslots >= 3072);
   if (e->cfg.task == DM_TASK_COMBINED) {
-    hipLaunchKernelGGL(dm_step_combined_kernel, grid, block, 0, s, P);
+    if (three_waves) hipLaunchKernelGGL(dm_step_combined_kernel_w3, grid, block, 0, s, P);
+    else hipLaunchKernelGGL(dm_step_combined_kernel, grid, block, 0, s, P);
 #ifdef DM_EXPERIMENT_W4
   } else if (e->waves == 4) {
     hipLaunchKernelGGL(dm_step_kernel_w4, grid, block, 0, s, P);
 #endif
-  } else if (e->waves == 3 || (e->waves == 0 && P.nslots >= 3072)) {
+  } else if (three_waves) {
     // three waves per SIMD (168 VGPRs): faster than the two-wave build from 3 072 envs up since r2 (per-stage laundering of
     // the lane id: no hoisted lane-compare masks spilled across the stage loop): 13.4 vs 12.9 M at 4 096 envs, 21.4 vs
     // 17.5 M at 65 536

@@ -2056,6 +2056,9 @@ extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, DMK_WAVES_
 extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, 3) dm_step_kernel_w3(DmLaunch P) {
   step_body<0>(P);
 }
+extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, 3) dm_step_combined_kernel_w3(DmLaunch P) {
+  step_body<1>(P);
+}
 #ifdef DM_EXPERIMENT_W4
 // Experiment: four waves per SIMD = 128 VGPRs.  Never selected by dm_step; DM_WAVES=4 forces it.
 extern "C" __global__ void __launch_bounds__(64 * DMK_ENVS_PER_BLOCK, 4) dm_step_kernel_w4(DmLaunch P) {

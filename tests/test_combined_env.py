@@ -160,10 +160,13 @@ def _gpu_engine(model, comb_mocaps, n, **kw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,scale,start", [(0, 2.0, (WALK, 165)), (1, 0.5, (GETUP, 20)), (2, 2.0, (WALK, 200))])
-def test_gpu_combined_teacher_forced_parity(model, comb_mocaps, comb_oracle_clips, seed, scale, start):
+@pytest.mark.parametrize("seed,scale,start,tile", [(0, 2.0, (WALK, 165), 1), (1, 0.5, (GETUP, 20), 1), (2, 2.0, (WALK, 200), 1),
+                                                   (0, 2.0, (WALK, 165), 6)])
+def test_gpu_combined_teacher_forced_parity(model, comb_mocaps, comb_oracle_clips, seed, scale, start, tile):
+    """tile = 6: the 520 oracle states six times = 3 120 envs, which dm_step runs on dm_step_combined_kernel_w3 (three waves
+    per SIMD from 3 072 envs): same gates as the two-wave kernel."""
     import torch
-    recs = _rollout(model, comb_oracle_clips, seed=seed, nsteps=520, scale=scale, start=start)
+    recs = _rollout(model, comb_oracle_clips, seed=seed, nsteps=520, scale=scale, start=start) * tile
     n = len(recs)
     eng = _gpu_engine(model, comb_mocaps, n, auto_reset=False)
     assert eng.obs_dim == 72 and eng.terms_dim == 8
@@ -209,6 +212,9 @@ def test_gpu_combined_teacher_forced_parity(model, comb_mocaps, comb_oracle_clip
     if seed == 0:
         assert seen == [WALK, GETUP, TO_GETUP]
         assert (WALK, TO_GETUP) in trans and (TO_GETUP, GETUP) in trans and (GETUP, TO_GETUP) in trans
+    if tile > 1:                                       # identical inputs in every tile -> identical outputs
+        q = qpos.reshape(tile, -1)
+        assert np.array_equal(q[0], q[tile // 2]) and np.array_equal(q[0], q[-1])
     eng.close()
 
 
