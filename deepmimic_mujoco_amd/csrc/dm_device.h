@@ -74,7 +74,7 @@ struct DmDev {
   uint8_t tri_a[80], tri_b[80]; // lower-triangle pair decode for the factorisation
 };
 
-// Per-env LDS working set (one wave).  ~15 KB.
+// Per-env LDS working set (one wave).  13 008 B: twelve waves per CU (three per SIMD) need <= 13 653 B each.
 struct EnvLds {
   float qpos[36], qvel[36], warm[36], ctrl[28];
   float qacc_smooth[36], qacc[36];
@@ -88,12 +88,15 @@ struct EnvLds {
   float cvel[DMK_NB][6];
   float M[DM_NM + 2];                 // sparse L^T D L factor, MuJoCo row layout (dm_topology.h)
   float dinv[36], dsqrtinv[36];
+  float rk[5][36], rkq[4];            // RK4 bookkeeping per dof: X0 position, X0 velocity, sum b_i v_i, sum b_i a_i, stage velocity; X0 root quaternion
   // contacts of the current forward evaluation
   float c_dist[DMK_MAXCON], c_pos[DMK_MAXCON][3], c_frame[DMK_MAXCON][9];
   int32_t c_g1[DMK_MAXCON], c_g2[DMK_MAXCON];
-  unsigned long long prof_t; unsigned prof[16];  // -DDM_PROFILE diagnostic stamps only
+#ifdef DM_PROFILE
+  unsigned long long prof_t; unsigned prof[16];  // diagnostic stamps (-DDM_PROFILE build only)
+#endif
   int32_t info[8];                    // ncon, nefc, nlimit, solver_iter, overflow (last forward evaluation)
-  int32_t rowinfo[DMK_MAXROW];        // contact rows: (contact << 3) | edge ; limit rows: -1
+  int16_t rowinfo[DMK_MAXROW];        // contact rows: (contact << 3) | edge | 0x4000 (whole pyramid kept); limit rows: -(2 dof + side + 1)
   // velocity-stage scratch (dead before the constraint stage) / box-box polygon scratch
   union {
     struct {

@@ -1385,7 +1385,7 @@ __device__ __forceinline__ float fwd_constraint(GDev &T, const int lane, const i
         else if (q > dhi) { lim = true; ldist = dhi - q; lneg = 1; }
       }
       int myrow = prefix_count(lim, lane, &nlimit);
-      if (lim) { S.rowinfo[myrow] = -(((lane << 1) | lneg) + 1); }
+      if (lim) { S.rowinfo[myrow] = (int16_t)(-(((lane << 1) | lneg) + 1)); }
       int dim3 = 0, have = lane < ncon;
       if (have) {
         int cd1 = T.g_condim[S.c_g1[lane]], cd2 = T.g_condim[S.c_g2[lane]];
@@ -1398,7 +1398,7 @@ __device__ __forceinline__ float fwd_constraint(GDev &T, const int lane, const i
       if (have) {
         int nr = dim3 ? 4 : 1;
         for (int e = 0; e < nr; e++)
-          if (roff + e < DMK_MAXROW) S.rowinfo[roff + e] = (lane << 3) | e | (((roff + nr) <= DMK_MAXROW) ? 0x4000 : 0);
+          if (roff + e < DMK_MAXROW) S.rowinfo[roff + e] = (int16_t)((lane << 3) | e | (((roff + nr) <= DMK_MAXROW) ? 0x4000 : 0));
       }
       if (rtot > DMK_MAXROW) { overflow |= 2; rtot = DMK_MAXROW; }
       nefc = rtot;
@@ -1692,9 +1692,9 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
   }
   SYNC();
 
-  // RK4 bookkeeping, lane = dof (k<3 root translation, 3..5 root rotation, >=6 hinges)
-  float x0q = 0, x0v = 0, accq = 0, accv = 0, curv = 0;
-  float q0[4] = {1, 0, 0, 0};
+  // RK4 bookkeeping, lane = dof (k<3 root translation, 3..5 root rotation, >=6 hinges): X0 (position, velocity), the
+  // weighted sums of the stage derivatives and the current stage velocity live in LDS (S.rk / S.rkq), not in VGPRs —
+  // they are touched once per stage and would otherwise occupy nine registers across every forward evaluation
   int it = (mode == DMK_MODE_STEP) ? 0 : 4;
   bool after_reset = false, done = false, sim_err = false;
   int reason = DM_REASON_NONE;
@@ -1736,10 +1736,12 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
 #endif
     fwd_smooth(Ts, lane_st);
     if (it == 0) {  // capture X0 (after normalisation)
-      x0v = (lane < DMK_NV) ? S.qvel[lk] : 0.f;
-      x0q = (lane < 3) ? S.qpos[lane] : ((lane >= 6 && lane < DMK_NV) ? S.qpos[lane + 1] : 0.f);
-      for (int i = 0; i < 4; i++) q0[i] = S.qpos[3 + i];
-      curv = x0v;
+      if (lane < DMK_NV) {
+        const float v0 = S.qvel[lk];
+        S.rk[0][lk] = (lane < 3) ? S.qpos[lane] : ((lane >= 6) ? S.qpos[lane + 1] : 0.f);
+        S.rk[1][lk] = v0; S.rk[2][lk] = 0.f; S.rk[3][lk] = 0.f; S.rk[4][lk] = v0;
+      }
+      if (lane < 4) S.rkq[lane] = S.qpos[3 + lane];
     }
     {
       const int cr = fwd_collide(Ts, lane_st);
@@ -1758,6 +1760,14 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
    }  // !sim_err
 
     const bool euler = (P.integrator == DM_INT_EULER) && mode == DMK_MODE_STEP;
+    float x0q = 0, x0v = 0, accq = 0, accv = 0, curv = 0;
+    float q0[4] = {1, 0, 0, 0};
+    if (!sim_err && it < 4) {
+      const bool dl = lane < DMK_NV;
+      x0q = dl ? S.rk[0][lk] : 0.f; x0v = dl ? S.rk[1][lk] : 0.f; accq = dl ? S.rk[2][lk] : 0.f;
+      accv = dl ? S.rk[3][lk] : 0.f; curv = dl ? S.rk[4][lk] : 0.f;
+      for (int i = 0; i < 4; i++) q0[i] = S.rkq[i];
+    }
     if (!sim_err && it < 3 && !euler) {  // RK4 intermediate stages (tableau A = diag(1/2, 1/2, 1), B = 1/6 1/3 1/3 1/6)
       const float Bw = (it == 0) ? (1.f / 6.f) : (1.f / 3.f);
       const float Aw = (it == 2) ? 1.f : 0.5f;
@@ -1776,7 +1786,7 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
       }
       quat_mul(qn, q0, qr);
       quat_normalize(qn);
-      if (lane < DMK_NV) S.qvel[lk] = curv;
+      if (lane < DMK_NV) { S.qvel[lk] = curv; S.rk[2][lk] = accq; S.rk[3][lk] = accv; S.rk[4][lk] = curv; }
       if (lane < 3) S.qpos[lane] = x0q + h * dq;
       if (lane >= 6 && lane < DMK_NV) S.qpos[lane + 1] = x0q + h * dq;
       if (lane < 4) S.qpos[3 + lane] = (lane == 0) ? qn[0] : (lane == 1) ? qn[1] : (lane == 2) ? qn[2] : qn[3];
