@@ -95,11 +95,11 @@ def ppo_loop_record(args, dev, local_rank, rank, world, launched, barrier):
     motion = "spinkick" if world > 1 else "walk"
     rec = {"motion": motion, "envs_per_gpu": args.envs, "horizon": 32, "epochs": 20, "minibatch": 4096, "n_gpus": world,
            "timed_iterations": args.ppo_iters}
-    for arch in ((256, 128), (1024, 512)):
-        key = "%d,%d" % arch
+    for arch, mdt in (((256, 128), torch.float32), ((1024, 512), torch.float32), ((1024, 512), torch.bfloat16)):
+        key = "%d,%d" % arch + ("" if mdt == torch.float32 else " bf16-gemm")     # bf16-gemm: auxiliary mixed-precision learner option
         try:
             env = HipDeepMimicVecEnv(args.envs, motion=motion, device=local_rank, seed=1234 + 7919 * rank)
-            ppo = PPO(env, net_arch=arch, n_steps=32, batch_size=4096, n_epochs=20, seed=0)
+            ppo = PPO(env, net_arch=arch, n_steps=32, batch_size=4096, n_epochs=20, seed=0, mlp_dtype=mdt)
             ppo.train(ppo.collect_rollouts())                    # untimed: captures the graphs
             torch.cuda.synchronize()
             barrier()
@@ -140,6 +140,7 @@ def ppo_loop_record(args, dev, local_rank, rank, world, launched, barrier):
                         "mfma_frac": flops / (opt_us * 1e-6) / 157.3e12, "flops_per_optimizer_step": flops,
                         "collective_us": coll_us, "collectives_per_iteration": nopt if world > 1 else 0,
                         "grad_floats": int(sum(p.numel() for p in ppo.policy.parameters())),
+                        "mlp_dtype": "f32" if mdt == torch.float32 else "bf16 GEMMs / activations, f32 master weights, loss and Adam",
                         "learner_path": ("dist two-graph" if getattr(ppo, "_dg", None) is not None else
                                          "epoch graph" if getattr(ppo, "_eg", None) is not None else "eager"),
                         "mean_reward": ppo.stats.get("mean_reward")}

@@ -1627,8 +1627,6 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
   const int lb = lane < DMK_NB ? lane : 0;       // lane as body
   const int lk = lane < DMK_NV ? lane : 0;       // lane as dof
   const int lg = lane < DMK_NG ? lane : 0;       // lane as geom
-  const int bdep = (lane < DMK_NB) ? T.b_depth[lb] : -1;
-  const float bmass = (lane < DMK_NB) ? T.b_mass[lb] : 0.f;
   const float h = T.timestep;
   const float mtot_inv = T.total_mass_inv;
 
@@ -1911,8 +1909,9 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
         }
         const float r_ee = expf(-40.f * wave_sum(df * df));
         float ce = 0;
+        const float bmass_t = (lane < DMK_NB) ? T.b_mass[lb] : 0.f;     // read here: not a register held across the forward evaluations
         for (int i = 0; i < 3; i++) {
-          float d2 = row[72 + i] - wave_sum(bmass * S.xpos[lb][i]) * mtot_inv;
+          float d2 = row[72 + i] - wave_sum(bmass_t * S.xpos[lb][i]) * mtot_inv;
           ce += d2 * d2;
         }
         const float r_com = expf(-10.f * ce);

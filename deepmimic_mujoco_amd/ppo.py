@@ -75,13 +75,44 @@ class _HipLinearFn(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+class _HipLinearBf16Fn(torch.autograd.Function):
+    """y = x W^T + b with bf16 MFMA GEMMs (fp32 accumulation inside the GEMM, bf16 activations) against bf16 shadows of the
+    fp32 master weights kept by ``FlatAdam`` — the mixed-precision option of the library-GEMM learner (``PPO(mlp_dtype=
+    torch.bfloat16)``).  dW / db are written into the optimizer's fp32 gradient arena, as in the fp32 path."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, mod):
+        wb, bb = mod._bf16
+        xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+        ctx.save_for_backward(xb)
+        ctx.mod = mod
+        return torch.addmm(bb, xb, wb.t())
+
+    @staticmethod
+    def backward(ctx, gy):
+        (xb,) = ctx.saved_tensors
+        mod = ctx.mod
+        wb, _ = mod._bf16
+        gy = gy.contiguous()
+        gx = (gy @ wb) if ctx.needs_input_grad[0] else None
+        gw, gb = mod._grad_arena
+        gw.copy_(gy.t() @ xb)                        # bf16 product (fp32 accumulation), widened into the fp32 arena
+        gb.copy_(gy.sum(0, dtype=torch.float32))
+        return gx, None, None, None
+
+
 class HipLinear(nn.Linear):
     """nn.Linear whose weight / bias gradients bypass autograd's generic kernels when the batch is a large CUDA minibatch:
     layers up to 256 x 256 and skinny layers (one side <= 128) on `dm_linear_wgrad` (the library's K = 4096 GEMMs into small
     outputs take 25-38 us each), large ones on the library GEMM + `dm_colsum`, all written straight into the optimizer's flat
     gradient arena."""
 
+    _bf16 = None            # (weight, bias) bf16 shadow views, set by FlatAdam.enable_bf16_shadow
+
     def forward(self, x):
+        if (self._bf16 is not None and x.is_cuda and x.dim() == 2 and torch.is_grad_enabled()
+                and getattr(self, "_grad_arena", None) is not None):
+            return _HipLinearBf16Fn.apply(x, self.weight, self.bias, self)
         if (x.is_cuda and x.dim() == 2 and x.shape[0] >= 1024 and x.shape[0] % 64 == 0 and x.dtype == torch.float32
                 and x.is_contiguous() and torch.is_grad_enabled()):
             return _HipLinearFn.apply(x, self.weight, self.bias, self)
@@ -409,6 +440,20 @@ class FlatAdam:
                 mod._grad_arena = (byid[id(mod.weight)], byid[id(mod.bias)])
         self.state = {"flat": {"exp_avg": self.m, "exp_avg_sq": self.v, "state2": self.state2}}
         self.calls = 0          # collectives issued (multi-rank)
+        self.flat_pb = None     # bf16 shadow of flat_p (mixed-precision learner), refreshed after every update
+        self._policy = policy
+
+    def enable_bf16_shadow(self):
+        """bf16 copies of the fp32 master weights for the GEMMs of the library-path learner; every HipLinear gets views."""
+        self.flat_pb = self.flat_p.to(torch.bfloat16)
+        views, off = {}, 0
+        for p in self.params:
+            k = p.numel()
+            views[id(p)] = self.flat_pb[off:off + k].view_as(p)
+            off += k
+        for mod in self._policy.modules():
+            if isinstance(mod, HipLinear):
+                mod._bf16 = (views[id(mod.weight)], views[id(mod.bias)])
 
     def zero_grad(self, set_to_none=True):
         self.flat_g.zero_()
@@ -438,6 +483,8 @@ class FlatAdam:
                                                    C.c_void_p(torch.cuda.current_stream(self.flat_p.device).cuda_stream))
         if rc != 0:
             raise RuntimeError("dm_adam_clip_step failed (%d)" % rc)
+        if self.flat_pb is not None:
+            self.flat_pb.copy_(self.flat_p)
 
     def state_dict(self):
         return {"flat_adam": True, "exp_avg": self.m.clone(), "exp_avg_sq": self.v.clone(), "state2": self.state2.clone(),
@@ -453,7 +500,7 @@ class PPO:
                  gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5,
                  normalize_advantage=True, seed=0, device=None, buffer_dtype=torch.float32, policy=None,
                  use_hip_graph=None, fused_loss=True, flat_adam=True, two_stream=True, rollout_graph=True, fused_rollout=True,
-                 fused_policy=True, fused_mlp=True, epoch_graph=True, dist_graph=True):
+                 fused_policy=True, fused_mlp=True, epoch_graph=True, dist_graph=True, mlp_dtype=torch.float32):
         # rollout_graph only takes effect for an env built with sub_batches > 1
         self.env = env
         self.device = device if device is not None else getattr(env, "device", torch.device("cpu"))
@@ -488,6 +535,14 @@ class PPO:
         else:
             self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5, fused=on_gpu,
                                               capturable=on_gpu and self.use_hip_graph)
+        # mixed-precision learner (library-GEMM path only): bf16 MFMA GEMMs and activations against bf16 shadows of the fp32
+        # master weights, fp32 loss / gradients-arena / Adam.  fp32 (the reference's dtype) is the default.
+        self.mlp_dtype = mlp_dtype
+        if mlp_dtype == torch.bfloat16:
+            if not self.flat_adam:
+                raise ValueError("mlp_dtype=bfloat16 needs the flat Adam path (GPU)")
+            self.fused_mlp = False                     # the fused [256,128]-class kernel is fp32
+            self.optimizer.enable_bf16_shadow()
         self._graph = None
         self._mlp_grads = {}                                                        # FusedMlpGrad per minibatch size
         self._loss_acc = torch.zeros(2, device=self.device) if on_gpu else None     # device-side (sum of losses, count)
@@ -859,6 +914,8 @@ class PPO:
         else:
             mean = self.policy.action_net(self.policy.pi(obs))
             value = self.policy.value_net(self.policy.vf(obs)).squeeze(-1)
+        if mean.dtype != torch.float32:               # bf16 learner: the loss kernel reads fp32 heads
+            mean, value = mean.float(), value.float()
         return mean, value
 
     def _loss_fused(self, obs, act, adv, ret, old_logp):
@@ -964,6 +1021,8 @@ class PPO:
                         vv.copy_(snap_o[k][kk]) if had_state and k in snap_o else vv.zero_()
             if self._loss_acc is not None:
                 self._loss_acc.zero_()          # the warm-up steps are not part of the statistics
+            if getattr(self.optimizer, "flat_pb", None) is not None:
+                self.optimizer.flat_pb.copy_(self.optimizer.flat_p)
         return graph, out
 
     def _static_minibatch(self):
@@ -1083,5 +1142,7 @@ class PPO:
         ck = torch.load(path, map_location=self.device)
         self.policy.load_state_dict(ck["policy"])
         self.optimizer.load_state_dict(ck["optimizer"])
+        if getattr(self.optimizer, "flat_pb", None) is not None:
+            self.optimizer.flat_pb.copy_(self.optimizer.flat_p)
         self.num_timesteps = ck["num_timesteps"]
         return self

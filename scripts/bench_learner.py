@@ -1,5 +1,5 @@
 """Optimizer step of the PPO learner alone (captured hipGraph, replayed): us per minibatch step.
-usage: python scripts/bench_learner.py [H1,H2] [steps] [--no-fused-mlp] [--no-epoch-graph] [--mb=4096]"""
+usage: python scripts/bench_learner.py [H1,H2] [steps] [--no-fused-mlp] [--no-epoch-graph] [--mb=4096] [--bf16]"""
 import sys, time
 import torch
 sys.path.insert(0, ".")
@@ -16,7 +16,7 @@ buf = dict(obs=torch.randn(T, N, 67, generator=g), act=torch.randn(T, N, 28, gen
 buf = {k: v.to(dev) for k, v in buf.items()}
 epochs = max(1, steps // T)
 ppo = PPO(None, net_arch=arch, n_epochs=epochs, batch_size=MB, device=dev, fused_mlp="--no-fused-mlp" not in sys.argv,
-          epoch_graph="--no-epoch-graph" not in sys.argv)
+          epoch_graph="--no-epoch-graph" not in sys.argv, mlp_dtype=torch.bfloat16 if "--bf16" in sys.argv else torch.float32)
 ppo.train(buf)                       # capture
 torch.cuda.synchronize()
 t0 = time.perf_counter()

@@ -676,3 +676,43 @@ def test_fused_mlp_grad_matches_autograd(arch, B, D, ent):
             q._minibatch_step(obs, act, adv, ret, old_logp)
         res.append(torch.cat([p.detach().reshape(-1) for p in q.policy.parameters()]))
     assert torch.allclose(res[0], res[1], rtol=1e-4, atol=2e-6), float((res[0] - res[1]).abs().max())
+
+
+def test_bf16_learner_option_tracks_the_fp32_learner():
+    """PPO(mlp_dtype=torch.bfloat16): the library-path learner with bf16 MFMA GEMMs / activations against bf16 shadows of the
+    fp32 master weights (fp32 loss kernel, gradient arena and Adam).  On the same minibatch its gradient points where the
+    fp32 learner's does (cosine > 0.995, relative L2 difference < 8 %), five optimizer steps reduce the loss like the fp32
+    run's, and the shadow equals the rounded master weights after every update."""
+    import torch
+    from deepmimic_mujoco_amd.ppo import PPO, MlpPolicy
+    dev = torch.device("cuda", 0)
+    B = 2048
+    g = torch.Generator(device=dev); g.manual_seed(7)
+    obs = torch.randn(B, 67, device=dev, generator=g)
+    act = torch.randn(B, 28, device=dev, generator=g) * 0.5
+    adv = torch.randn(B, device=dev, generator=g)
+    ret = torch.randn(B, device=dev, generator=g)
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        torch.manual_seed(11)
+        pol = MlpPolicy(net_arch=(1024, 512)).to(dev)
+        ppo = PPO(None, policy=pol, device=dev, batch_size=B, use_hip_graph=False, learning_rate=1e-3, mlp_dtype=dt)
+        with torch.no_grad():
+            _, logp, _ = pol.evaluate_actions(obs, act)
+        old_logp = (logp + 0.1 * torch.randn(B, device=dev, generator=torch.Generator(device=dev).manual_seed(3))).contiguous()
+        losses = []
+        for it in range(5):
+            losses.append(float(ppo._minibatch_step(obs, act, adv, ret, old_logp)))
+            if it == 0:
+                grad0 = ppo.optimizer.flat_g.clone()
+            if dt == torch.bfloat16:
+                assert torch.equal(ppo.optimizer.flat_pb, ppo.optimizer.flat_p.to(torch.bfloat16))
+        res[dt] = (grad0, losses)
+    g32, l32 = res[torch.float32]
+    g16, l16 = res[torch.bfloat16]
+    cos = float(torch.dot(g32, g16) / (g32.norm() * g16.norm()))
+    rel = float((g32 - g16).norm() / g32.norm())
+    print("bf16 learner: gradient cosine %.5f, relative L2 diff %.4f, losses fp32 %s bf16 %s" % (cos, rel, l32, l16))
+    assert cos > 0.995 and rel < 0.08
+    assert abs(l16[0] - l32[0]) < 0.02 * max(1.0, abs(l32[0]))
+    assert l16[-1] < l16[0] and abs(l16[-1] - l32[-1]) < 0.05 * max(1.0, abs(l32[-1]))
