@@ -152,14 +152,28 @@ def _fix_singularity(joint, euler, prev, quat_xyzw, dt, vmx):
     return (float(gx.ravel()[best]), float(gy.ravel()[best]), float(gz.ravel()[best])), True
 
 
+_G1 = []
+
+
+def _g1_model():
+    if not _G1:
+        from . import mjcf as _mjcf
+        _G1.append(_mjcf.compile_mjcf_general(os.path.join(_model.ASSET_DIR, "deepmimic_unitree_g1.xml"),
+                                              hulls=_mjcf.load_g1_hulls()))
+    return _G1[0]
+
+
 class MocapDM:
     """Same public surface as the reference class (src/mujoco/mocap_v2.py:12)."""
 
     def __init__(self, robot="humanoid3d", model=None):
-        if robot != "humanoid3d":
-            raise NotImplementedError("only the 34-DoF humanoid3d path is built (SURVEY §8f)")
+        if robot not in ("humanoid3d", "unitree_g1"):
+            raise Exception("Unknown robot: %s" % robot)
         self.robot = robot
         self.model = model
+        if robot == "unitree_g1" and model is None:
+            # G1 clips are "direct_qpos" (44 wide); kinematic tables come from the general MJCF compiler (mjcf.py)
+            self.model = _g1_model()
         self.dt = None
         self.loop = None
         self.data_config = None
@@ -187,7 +201,8 @@ class MocapDM:
         if "Format" in data:
             # "direct_qpos" clips (mocap_v2.py:271-272, written by src/retarget.py:176-190): frames are
             # [dt, qpos...] already in MuJoCo order; velocities / FK tables / interpolation follow as usual.
-            if data["Format"] != "direct_qpos" or motions.shape[1] != 1 + _model.NQ:
+            nq = _model.NQ if self.robot == "humanoid3d" else self.model.nq
+            if data["Format"] != "direct_qpos" or motions.shape[1] != 1 + nq:
                 raise NotImplementedError("unsupported mocap Format %r / width %d" % (data["Format"], motions.shape[1]))
             self.all_states = []
             self.singularity_fired = 0
@@ -246,10 +261,14 @@ class MocapDM:
         self.data_vel = vels
 
         # FK tables (mocap_v2.py:292-307) with the build's own kinematics
-        mdl = self.model or _model.load_model()
+        if self.robot == "humanoid3d":
+            mdl, fk = self.model or _model.load_model(), _model.forward_kinematics
+        else:
+            from .mjcf import forward_kinematics_general as fk
+            mdl = self.model
         self.data_body_xpos, self.data_geom_xpos = [], []
         for q in configs:
-            kin = _model.forward_kinematics(mdl, q)
+            kin = fk(mdl, q)
             self.data_body_xpos.append(kin["xpos"].copy())
             self.data_geom_xpos.append(kin["geom_xpos"].copy())
 
