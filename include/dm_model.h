@@ -22,6 +22,22 @@
 extern "C" {
 #endif
 
+#ifdef DM_ROBOT_G1
+/* Unitree G1 (deepmimic_unitree_g1.xml): dimensions of the CPU-oracle build only (oracle/libdm_oracle_g1.so).
+ * The HIP library is compiled for the humanoid3d dimensions below and rejects any other model. */
+#define DM_NQ 44
+#define DM_NV 43
+#define DM_NU 37        /* 23 driven by the policy, 14 hand motors held at 0 (src/deepmimic_env.py:303-307,348-351) */
+#define DM_NBODY 39
+#define DM_NGEOM 94     /* floor + 47 visual (contype 0) + 46 collision geoms */
+#define DM_NJNT 38      /* free root + 37 hinges */
+#define DM_NM 434
+#define DM_MAXPAIR 1024 /* 1013 used */
+#define DM_NOBS 85      /* 37 + 37 + torso 8 + foot 2 + phase 1 */
+#define DM_NMESH 32
+#define DM_NMESHVERT 40000   /* hull vertices of all collision meshes (39 239 used) */
+#define DM_NREWJ 23     /* joints the imitation reward reads (src/deepmimic_env.py:206-207) */
+#else
 #define DM_NQ 35
 #define DM_NV 34
 #define DM_NU 28
@@ -31,6 +47,7 @@ extern "C" {
 #define DM_NM 310       /* non-zeros of the sparse joint-space inertia */
 #define DM_MAXPAIR 128  /* capacity of the collision candidate table (104 used) */
 #define DM_NOBS 67      /* DPEnv observation (src/deepmimic_env.py:33-45) */
+#endif
 #define DM_NOBS_COMBINED 72 /* DPCombinedEnv observation: 64 + phase + player-action obs 7 (src/combined_env.py:495-505) */
 #define DM_NEE 4        /* end-effector geoms (src/config.py:12) */
 #define DM_MAXCON 32    /* contact slots kept per env per forward evaluation (HIP build) */
@@ -41,7 +58,9 @@ extern "C" {
 #define DM_GEOM_PLANE 0
 #define DM_GEOM_SPHERE 2
 #define DM_GEOM_CAPSULE 3
+#define DM_GEOM_CYLINDER 5 /* G1 oracle build only */
 #define DM_GEOM_BOX 6
+#define DM_GEOM_MESH 7     /* G1 oracle build only: convex hull of the mesh vertices */
 
 #define DM_JNT_FREE 0
 #define DM_JNT_HINGE 3
@@ -121,6 +140,18 @@ typedef struct DmModel {
   int32_t ee_geom[DM_NEE];            /* left_ankle,right_ankle,left_wrist,right_wrist */
   int32_t torso_body;                 /* chest */
   int32_t rfoot_geom, lfoot_geom, floor_geom;
+#ifdef DM_ROBOT_G1
+  /* ---- G1 oracle build: trailing fields ---- */
+  double dof_frictionloss[DM_NV];     /* xml :16 frictionloss="0.1" -> mjCNSTR_FRICTION_DOF rows [EXT] */
+  int32_t geom_mesh[DM_NGEOM];        /* mesh id or -1 */
+  int32_t mesh_vertadr[DM_NMESH], mesh_vertnum[DM_NMESH];
+  double mesh_center[DM_NMESH][3];    /* volume centroid of the hull (interior point of the MPR search) */
+  double mesh_vert[DM_NMESHVERT][3];  /* hull vertices, mesh frame */
+  int32_t nconmax, n_policy_action;   /* xml :10; 23 */
+  double action_scale, low_z;         /* 20 (src/deepmimic_env.py:348), 0.4 (src/config.py:22) */
+  int32_t rew_qposadr[DM_NREWJ], rew_dofadr[DM_NREWJ], rew_jnt[DM_NREWJ]; /* src/deepmimic_env.py:206-207 */
+  int32_t extra_geom[8];              /* foot spheres (src/config.py:19-20) */
+#endif
 } DmModel;
 
 #ifdef __cplusplus

@@ -653,6 +653,8 @@ static int c_box_box(RawCon *c, double margin, const double *p1, const double *R
   return cnt;
 }
 
+#include "dm_convex.h"
+
 static void make_frame(double *f) { /* [EXT] mju_makeFrame */
   normalize3(f);
   if (norm3(f + 3) < 0.5) {
@@ -665,21 +667,68 @@ static void make_frame(double *f) { /* [EXT] mju_makeFrame */
   cross3(f + 6, f, f + 3);
 }
 
+/* analytic pair routines of MuJoCo's collision table [EXT mjCOLLISIONFUNC]; -1 = none (mjc_Convex / plane-mesh) */
+static int analytic_pair(RawCon *rc, double margin, int t1, const double *x1, const double *M1, const double *z1, int t2,
+                         const double *x2, const double *M2, const double *z2) {
+  if (t1 == DM_GEOM_PLANE && t2 == DM_GEOM_SPHERE) return c_plane_sphere(rc, margin, x1, M1, x2, z2[0]);
+  if (t1 == DM_GEOM_PLANE && t2 == DM_GEOM_CAPSULE) return c_plane_capsule(rc, margin, x1, M1, x2, M2, z2);
+  if (t1 == DM_GEOM_PLANE && t2 == DM_GEOM_CYLINDER) return c_plane_cylinder(rc, margin, x1, M1, x2, M2, z2);
+  if (t1 == DM_GEOM_PLANE && t2 == DM_GEOM_BOX) return c_plane_box(rc, margin, x1, M1, x2, M2, z2);
+  if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_SPHERE) return c_sphere_sphere(rc, margin, x1, z1[0], x2, z2[0]);
+  if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_CAPSULE) return c_sphere_capsule(rc, margin, x1, z1[0], x2, M2, z2);
+  if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_BOX) return c_sphere_box(rc, margin, x1, z1[0], x2, M2, z2);
+  if (t1 == DM_GEOM_CAPSULE && t2 == DM_GEOM_CAPSULE) return c_capsule_capsule(rc, margin, x1, M1, z1, x2, M2, z2);
+  if (t1 == DM_GEOM_CAPSULE && t2 == DM_GEOM_BOX) return c_capsule_box(rc, margin, x1, M1, z1, x2, M2, z2);
+  if (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX) return c_box_box(rc, margin, x1, M1, z1, x2, M2, z2);
+  return -1;
+}
+
+#ifdef DM_ROBOT_G1
+static void cvx_from_model(const DmModel *m, const DmoData *d, int g, CvxGeom *c) {
+  c->type = m->geom_type[g];
+  c->pos = d->geom_xpos[g]; c->mat = d->geom_xmat[g]; c->size = m->geom_size[g];
+  c->vert = NULL; c->nvert = 0;
+  memcpy(c->center, d->geom_xpos[g], sizeof c->center);
+  if (c->type == DM_GEOM_MESH) {
+    int me = m->geom_mesh[g];
+    c->vert = m->mesh_vert[m->mesh_vertadr[me]];
+    c->nvert = m->mesh_vertnum[me];
+    double t[3];
+    rot_vec(t, c->mat, m->mesh_center[me]);
+    for (int i = 0; i < 3; i++) c->center[i] += t[i];
+  }
+}
+#endif
+
+/* Test hook: the MPR routine on one pair (vert1 / vert2: hull vertices for DM_GEOM_MESH, else NULL).  out: dist, pos3,
+ * normal3; returns the number of contacts (0 / 1). */
+int dmo_mpr(int t1, const double *x1, const double *M1, const double *z1, const double *vert1, int n1, int t2,
+            const double *x2, const double *M2, const double *z2, const double *vert2, int n2, double *out) {
+  CvxGeom a = {t1, x1, M1, z1, vert1, n1, {x1[0], x1[1], x1[2]}}, b = {t2, x2, M2, z2, vert2, n2, {x2[0], x2[1], x2[2]}};
+  RawCon rc;
+  int n = c_convex(&rc, &a, &b);
+  if (n) { out[0] = rc.dist; memcpy(out + 1, rc.pos, 3 * sizeof(double)); memcpy(out + 4, rc.normal, 3 * sizeof(double)); }
+  return n;
+}
+
+/* Test hook: plane against a hull (c_plane_mesh).  out: n x 7 (dist, pos3, normal3) */
+int dmo_plane_mesh(const double *ppos, const double *pmat, const double *gpos, const double *gmat, const double *vert,
+                   int nvert, double margin, double *out) {
+  RawCon rc[4];
+  int n = c_plane_mesh(rc, margin, ppos, pmat, gpos, gmat, vert, nvert);
+  for (int k = 0; k < n; k++) {
+    out[7 * k] = rc[k].dist; memcpy(out + 7 * k + 1, rc[k].pos, 3 * sizeof(double));
+    memcpy(out + 7 * k + 4, rc[k].normal, 3 * sizeof(double));
+  }
+  return n;
+}
+
 /* Test hook: one primitive pair through the same dispatch as collision().  out: n x 10 doubles (dist, pos3, normal3,
  * tangent3); returns n, or -1 for an unsupported type pair. */
 int dmo_narrowphase(int t1, const double *x1, const double *M1, const double *z1, int t2, const double *x2,
                     const double *M2, const double *z2, double margin, double *out) {
   RawCon rc[8];
-  int n = -1;
-  if (t1 == DM_GEOM_PLANE && t2 == DM_GEOM_SPHERE) n = c_plane_sphere(rc, margin, x1, M1, x2, z2[0]);
-  else if (t1 == DM_GEOM_PLANE && t2 == DM_GEOM_CAPSULE) n = c_plane_capsule(rc, margin, x1, M1, x2, M2, z2);
-  else if (t1 == DM_GEOM_PLANE && t2 == DM_GEOM_BOX) n = c_plane_box(rc, margin, x1, M1, x2, M2, z2);
-  else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_SPHERE) n = c_sphere_sphere(rc, margin, x1, z1[0], x2, z2[0]);
-  else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_CAPSULE) n = c_sphere_capsule(rc, margin, x1, z1[0], x2, M2, z2);
-  else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_BOX) n = c_sphere_box(rc, margin, x1, z1[0], x2, M2, z2);
-  else if (t1 == DM_GEOM_CAPSULE && t2 == DM_GEOM_CAPSULE) n = c_capsule_capsule(rc, margin, x1, M1, z1, x2, M2, z2);
-  else if (t1 == DM_GEOM_CAPSULE && t2 == DM_GEOM_BOX) n = c_capsule_box(rc, margin, x1, M1, z1, x2, M2, z2);
-  else if (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX) n = c_box_box(rc, margin, x1, M1, z1, x2, M2, z2);
+  int n = analytic_pair(rc, margin, t1, x1, M1, z1, t2, x2, M2, z2);
   for (int k = 0; k < n; k++) {
     out[10 * k] = rc[k].dist;
     memcpy(out + 10 * k + 1, rc[k].pos, 3 * sizeof(double));
@@ -699,21 +748,31 @@ static void collision(const DmModel *m, DmoData *d) { /* [EXT] mj_collision */
     const double *M1 = d->geom_xmat[g1], *M2 = d->geom_xmat[g2];
     const double *z1 = m->geom_size[g1], *z2 = m->geom_size[g2];
     /* bounding-sphere filter (result-neutral) */
-    if (t1 != DM_GEOM_PLANE) {
+    {
       double df[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
-      if (norm3(df) > m->geom_rbound[g1] + m->geom_rbound[g2] + margin) continue;
+      if (t1 != DM_GEOM_PLANE) {
+        if (norm3(df) > m->geom_rbound[g1] + m->geom_rbound[g2] + margin) continue;
+      } else if (m->geom_rbound[g2] > 0) {
+        double nrm[3] = {M1[2], M1[5], M1[8]};
+        if (dot3(df, nrm) > m->geom_rbound[g2] + margin) continue;
+      }
     }
     RawCon rc[8];
-    int n = 0;
-    if (t1 == DM_GEOM_PLANE && t2 == DM_GEOM_SPHERE) n = c_plane_sphere(rc, margin, x1, M1, x2, z2[0]);
-    else if (t1 == DM_GEOM_PLANE && t2 == DM_GEOM_CAPSULE) n = c_plane_capsule(rc, margin, x1, M1, x2, M2, z2);
-    else if (t1 == DM_GEOM_PLANE && t2 == DM_GEOM_BOX) n = c_plane_box(rc, margin, x1, M1, x2, M2, z2);
-    else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_SPHERE) n = c_sphere_sphere(rc, margin, x1, z1[0], x2, z2[0]);
-    else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_CAPSULE) n = c_sphere_capsule(rc, margin, x1, z1[0], x2, M2, z2);
-    else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_BOX) n = c_sphere_box(rc, margin, x1, z1[0], x2, M2, z2);
-    else if (t1 == DM_GEOM_CAPSULE && t2 == DM_GEOM_CAPSULE) n = c_capsule_capsule(rc, margin, x1, M1, z1, x2, M2, z2);
-    else if (t1 == DM_GEOM_CAPSULE && t2 == DM_GEOM_BOX) n = c_capsule_box(rc, margin, x1, M1, z1, x2, M2, z2);
-    else if (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX) n = c_box_box(rc, margin, x1, M1, z1, x2, M2, z2);
+    int n = analytic_pair(rc, margin, t1, x1, M1, z1, t2, x2, M2, z2);
+    if (n < 0) { /* no analytic routine: plane-mesh, or libccd MPR through mjc_Convex [EXT] */
+      n = 0;
+#ifdef DM_ROBOT_G1
+      if (t1 == DM_GEOM_PLANE && t2 == DM_GEOM_MESH) {
+        int me = m->geom_mesh[g2];
+        n = c_plane_mesh(rc, margin, x1, M1, x2, M2, m->mesh_vert[m->mesh_vertadr[me]], m->mesh_vertnum[me]);
+      } else if (t1 != DM_GEOM_PLANE) {
+        CvxGeom a, b;
+        cvx_from_model(m, d, g1, &a);
+        cvx_from_model(m, d, g2, &b);
+        n = c_convex(rc, &a, &b);
+      }
+#endif
+    }
     for (int k = 0; k < n; k++) {
       if (d->ncon >= d->maxcon) { d->overflow_con++; continue; }
       DmoContact *c = &d->contact[d->ncon++];
@@ -768,6 +827,15 @@ static int add_row(DmoData *d, int type, int id, double pos, double margin, doub
 
 static void make_constraint(const DmModel *m, DmoData *d) { /* [EXT] mj_makeConstraint */
   d->nefc = 0;
+#ifdef DM_ROBOT_G1
+  /* dof friction loss rows come first [EXT mj_instantiateFriction]: J = e_dof, pos = margin = 0 */
+  for (int k = 0; k < NV; k++) {
+    if (m->dof_frictionloss[k] <= 0) continue;
+    int r = add_row(d, 3, k, 0.0, 0.0, m->dof_invweight0[k]);
+    if (r >= 0) { d->efc_J[(size_t)r * NV + k] = 1.0; d->efc_frictionloss[r] = m->dof_frictionloss[k]; }
+  }
+#endif
+  d->nfriction = d->nefc;
   /* joint limits, in joint order (jnt margin = 0) */
   for (int j = 0; j < DM_NJNT; j++) {
     if (!m->jnt_limited[j] || m->jnt_type[j] != DM_JNT_HINGE) continue;
@@ -780,7 +848,7 @@ static void make_constraint(const DmModel *m, DmoData *d) { /* [EXT] mj_makeCons
       }
     }
   }
-  d->nlimit = d->nefc;
+  d->nlimit = d->nefc - d->nfriction;
   /* contacts, in contact order; pyramidal cones */
   double j1[3 * NV], j2[3 * NV], jd[3 * NV];
   for (int ci = 0; ci < d->ncon; ci++) {
@@ -822,6 +890,7 @@ static void make_constraint(const DmModel *m, DmoData *d) { /* [EXT] mj_makeCons
     double vel = 0;
     for (int k = 0; k < NV; k++) vel += d->efc_J[(size_t)r * NV + k] * d->qvel[k];
     d->efc_vel[r] = vel;
+    if (d->efc_type[r] == 3) K = 0; /* friction rows carry no position term [EXT mj_makeImpedance] */
     d->efc_aref[r] = -B * vel - K * imp * (d->efc_pos[r] - d->efc_margin[r]);
   }
   /* pyramidal contacts: all edges share Rpy = 2 mu^2 R(first edge), impratio = 1 */
@@ -938,7 +1007,12 @@ static void fwd_constraint(const DmModel *m, DmoData *d) { /* [EXT] mj_fwdConstr
   for (int r = 0; r < n; r++) {
     double jar = -d->efc_aref[r];
     for (int k = 0; k < NV; k++) jar += J[(size_t)r * NV + k] * d->qacc_warmstart[k];
-    f[r] = jar < 0 ? -d->efc_D[r] * jar : 0.0;
+    if (d->efc_type[r] == 3) { /* friction loss: quadratic inside +-R*floss, saturated outside [EXT mj_constraintUpdate] */
+      double fl = d->efc_frictionloss[r], rf = d->efc_R[r] * fl;
+      f[r] = jar <= -rf ? fl : (jar >= rf ? -fl : -d->efc_D[r] * jar);
+    } else {
+      f[r] = jar < 0 ? -d->efc_D[r] * jar : 0.0;
+    }
   }
   for (int r = 0; r < n; r++) {
     double s = 0;
@@ -956,7 +1030,10 @@ static void fwd_constraint(const DmModel *m, DmoData *d) { /* [EXT] mj_fwdConstr
       for (int c = 0; c < n; c++) res += AR[(size_t)i * n + c] * f[c];
       double old = f[i], aii = AR[(size_t)i * n + i];
       f[i] -= res / aii;
-      if (f[i] < 0) f[i] = 0;
+      if (d->efc_type[i] == 3) { /* box constraint of a friction-loss row */
+        double fl = d->efc_frictionloss[i];
+        if (f[i] < -fl) f[i] = -fl; else if (f[i] > fl) f[i] = fl;
+      } else if (f[i] < 0) f[i] = 0;
       double dl = f[i] - old;
       improvement -= 0.5 * dl * dl * aii + dl * res;
     }
@@ -1101,17 +1178,18 @@ void dmo_quat_to_rpy(const double *q, double *rpy) {
 
 void dmo_get_obs(const DmModel *m, const DmoData *d, int idx_curr, int L, double *obs) {
   const double S = 0.1; /* VEL_OBS_SCALE, deepmimic_env.py:261 */
-  for (int i = 0; i < 28; i++) obs[i] = d->qpos[7 + i];          /* :34 */
-  for (int i = 0; i < 28; i++) obs[28 + i] = d->qvel[6 + i] * S; /* :35-37 */
+  const int NP = NQ - 7, NW = NV - 6, T0 = NP + NW;               /* humanoid3d 28 + 28, G1 37 + 37 */
+  for (int i = 0; i < NP; i++) obs[i] = d->qpos[7 + i];          /* :34 */
+  for (int i = 0; i < NW; i++) obs[NP + i] = d->qvel[6 + i] * S; /* :35-37 */
   int b = m->torso_body;                                         /* :47-76 */
   double rpy[3];
   dmo_quat_to_rpy(d->xquat[b], rpy);
   const double *cv = d->cvel[b];
   double cy = cos(-rpy[2]), sy = sin(-rpy[2]);
   double vx = cy * cv[3] - sy * cv[4], vy = sy * cv[3] + cy * cv[4], vz = cv[5];
-  obs[56] = rpy[0] * S; obs[57] = rpy[1] * S;
-  obs[58] = vx * S; obs[59] = vy * S; obs[60] = vz * S;
-  obs[61] = cv[0] * S; obs[62] = cv[1] * S; obs[63] = cv[2] * S;
+  obs[T0] = rpy[0] * S; obs[T0 + 1] = rpy[1] * S;
+  obs[T0 + 2] = vx * S; obs[T0 + 3] = vy * S; obs[T0 + 4] = vz * S;
+  obs[T0 + 5] = cv[0] * S; obs[T0 + 6] = cv[1] * S; obs[T0 + 7] = cv[2] * S;
   double rf = 0, lf = 0;                                         /* :78-105, active contacts only (F8) */
   for (int c = 0; c < d->ncon; c++) {
     int g1 = d->contact[c].geom1, g2 = d->contact[c].geom2;
@@ -1119,22 +1197,30 @@ void dmo_get_obs(const DmModel *m, const DmoData *d, int idx_curr, int L, double
     if ((g1 == m->rfoot_geom || g2 == m->rfoot_geom) && floor) rf = 1;
     if ((g1 == m->lfoot_geom || g2 == m->lfoot_geom) && floor) lf = 1;
   }
-  obs[64] = rf; obs[65] = lf;
+  obs[T0 + 8] = rf; obs[T0 + 9] = lf; /* G1: both geoms are visual spheres (contype 0): always 0 */
   double ph = (double)idx_curr / (double)L;                      /* :139-143 */
-  obs[66] = ph < 0 ? 0 : (ph > 1 ? 1 : ph);
+  obs[T0 + 10] = ph < 0 ? 0 : (ph > 1 ? 1 : ph);
 }
 
 double dmo_reward(const DmModel *m, const DmoData *d, const DmoClip *clip, int idx, double *terms) {
   const double *tq = clip->qpos + (size_t)idx * NQ, *tv = clip->qvel + (size_t)idx * NV;
   double err = 0;
+#ifdef DM_ROBOT_G1
+  for (int k = 0; k < DM_NREWJ; k++) { int i = m->rew_qposadr[k]; err += fabs(d->qpos[i] - tq[i]); } /* :204-211 */
+#else
   for (int i = 7; i < NQ; i++) err += fabs(d->qpos[i] - tq[i]);   /* :213-214 */
+#endif
   double rc[3], rt[3];
   dmo_quat_to_rpy(d->qpos + 3, rc);                               /* :216-221 */
   dmo_quat_to_rpy(tq + 3, rt);
   err += fabs(rc[1] - rt[1]);
   double r_cfg = exp(-err);
   double ev = 0;
+#ifdef DM_ROBOT_G1
+  for (int k = 0; k < DM_NREWJ; k++) { int i = m->rew_dofadr[k]; ev += fabs(tv[i] - d->qvel[i]); }
+#else
   for (int i = 6; i < NV; i++) ev += fabs(tv[i] - d->qvel[i]);    /* :225-226 */
+#endif
   double r_vel = exp(-0.1 * ev);
   double ee = 0;                                                  /* :228-233 */
   for (int e = 0; e < DM_NEE; e++) {
@@ -1153,11 +1239,20 @@ double dmo_reward(const DmModel *m, const DmoData *d, const DmoClip *clip, int i
   for (int i = 0; i < 3; i++) { double df = (ct[i] - cc[i]) / mt; ce += df * df; }
   double r_com = exp(-10 * ce);
   int viol = 0;                                                   /* :242-247 */
+#ifdef DM_ROBOT_G1
+  for (int k = 0; k < DM_NREWJ; k++) {                            /* :244-246 */
+    int j = m->rew_jnt[k];
+    double q = d->qpos[m->jnt_qposadr[j]];
+    viol += (q <= m->jnt_range[j][0] * 0.99) + (q >= m->jnt_range[j][1] * 0.99);
+  }
+  double qlim = (double)viol / (double)DM_NREWJ;
+#else
   for (int j = 1; j < DM_NJNT; j++) {
     double q = d->qpos[m->jnt_qposadr[j]];
     viol += (q <= m->jnt_range[j][0] * 0.99) + (q >= m->jnt_range[j][1] * 0.99);
   }
   double qlim = (double)viol / 28.0;
+#endif
   terms[0] = r_cfg; terms[1] = r_vel; terms[2] = r_ee; terms[3] = r_com; terms[4] = qlim;
   return 0.75 * r_cfg + 0.1 * r_vel + 0.15 * r_ee + 0.0 * r_com + (-0.1) * qlim; /* :400-404,249 */
 }
@@ -1169,7 +1264,11 @@ int dmo_env_step(const DmModel *m, DmoData *d, DmoEnv *e, const DmoClip *clip, c
   if (fq && fv) {
     err = dmo_set_state(m, d, fq, fv);                            /* :355-357 */
   } else {
+#ifdef DM_ROBOT_G1
+    for (int a = 0; a < NU; a++) d->ctrl[a] = a < m->n_policy_action ? action[a] * m->action_scale : 0.0; /* :348-351 */
+#else
     for (int a = 0; a < NU; a++) d->ctrl[a] = action[a] * 1.0;    /* :347, do_simulation sets ctrl */
+#endif
     err = dmo_step(m, d);                                         /* :362 */
   }
   if (err) {                                                      /* :366-378 */
@@ -1186,10 +1285,24 @@ int dmo_env_step(const DmModel *m, DmoData *d, DmoEnv *e, const DmoClip *clip, c
   double mt = 0, zc = 0;                                          /* :420-424 */
   for (int b = 0; b < NB; b++) { mt += m->body_mass[b]; zc += m->body_mass[b] * d->xipos[b][2]; }
   zc /= mt;
+#ifdef DM_ROBOT_G1
+  const double low_z = m->low_z;                                  /* src/config.py:22 */
+#else
+  const double low_z = 0.7;                                       /* src/config.py:13 */
+#endif
   if (!(clip->flags & 1)) {                                       /* :420 not a floor motion */
-    done = (zc < 0.7) || (zc > 2.0);
-    *reason = (zc < 0.7) ? DMO_REASON_LOW_Z : DMO_REASON_HIGH_Z;  /* written every step (:424) */
+    done = (zc < low_z) || (zc > 2.0);
+    *reason = (zc < low_z) ? DMO_REASON_LOW_Z : DMO_REASON_HIGH_Z; /* written every step (:424) */
   }
+#ifdef DM_ROBOT_G1
+  if (clip->flags & 4) {                                          /* :426-433 G1 "run": roll / pitch deviation > 60 deg */
+    double rc[3], rt[3];
+    dmo_quat_to_rpy(d->qpos + 3, rc);
+    dmo_quat_to_rpy(clip->qpos + (size_t)e->idx_curr * NQ + 3, rt);
+    const double max_angle = 60.0 * 3.14159265358979323846 / 180.0;
+    if (fabs(rc[0] - rt[0]) > max_angle || fabs(rc[1] - rt[1]) > max_angle) { done = 1; *reason = DMO_REASON_RUN_ANGLE; }
+  }
+#endif
   if (e->episode_length >= 1000) { done = 1; *reason = DMO_REASON_MAX_EP_LEN; } /* :435-438 */
   if ((clip->flags & 2) && e->idx_curr + 1 == clip->L) { done = 1; *reason = DMO_REASON_ACYCLIC_END; } /* :440-442 */
   e->idx_curr = (e->idx_curr + 1) % clip->L;                      /* :452 */
@@ -1215,6 +1328,7 @@ int dmo_env_reset(const DmModel *m, DmoData *d, DmoEnv *e, const DmoClip *clip, 
   return err;
 }
 
+#ifndef DM_ROBOT_G1
 /* ------------------------------------------------------------------ DPCombinedEnv semantics (src/combined_env.py) */
 #define COMB_AMNESTY_STEPS 150   /* DPCombinedEnvConfig.AMNESTY_STEPS :34 */
 #define COMB_MAX_EP_LENGTH 2000  /* :22 */
@@ -1352,6 +1466,8 @@ int dmo_combined_reset(const DmModel *m, DmoData *d, DmoCombEnv *e, const DmoCli
 }
 
 /* ------------------------------------------------------------------ CPU baseline driver */
+#endif /* !DM_ROBOT_G1 */
+
 static uint32_t hash32(uint64_t seed, uint32_t env, uint32_t step, uint32_t j) {
   /* counter-based generator shared with the HIP bench path (csrc/dm_kernels.hip: dm_hash32) */
   uint64_t x = seed ^ ((uint64_t)env * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)step * 0xBF58476D1CE4E5B9ull) ^
@@ -1401,6 +1517,7 @@ int dmo_get(const DmoData *d, const char *name, double *out, int cap) {
   FIELD("efc_R", d->efc_R, d->nefc) FIELD("efc_D", d->efc_D, d->nefc) FIELD("efc_aref", d->efc_aref, d->nefc)
   FIELD("efc_b", d->efc_b, d->nefc) FIELD("efc_force", d->efc_force, d->nefc) FIELD("efc_pos", d->efc_pos, d->nefc)
   FIELD("efc_vel", d->efc_vel, d->nefc) FIELD("time", &d->time, 1)
+  FIELD("efc_frictionloss", d->efc_frictionloss, d->nefc)
   if (src) {
     if (n > cap) return -n;
     memcpy(out, src, sizeof(double) * n);
@@ -1437,6 +1554,7 @@ int dmo_get_int(const DmoData *d, const char *name) {
   if (!strcmp(name, "ncon")) return d->ncon;
   if (!strcmp(name, "nefc")) return d->nefc;
   if (!strcmp(name, "nlimit")) return d->nlimit;
+  if (!strcmp(name, "nfriction")) return d->nfriction;
   if (!strcmp(name, "solver_iter")) return d->solver_iter;
   if (!strcmp(name, "overflow_con")) return d->overflow_con;
   if (!strcmp(name, "overflow_row")) return d->overflow_row;
@@ -1446,6 +1564,7 @@ int dmo_get_int(const DmoData *d, const char *name) {
   if (!strncmp(name, "stage_nefc", 10)) return d->stage_nefc[name[10] - '0'];
   return -1;
 }
+int dmo_model_sizeof(void) { return (int)sizeof(DmModel); }
 int dmo_set_caps(DmoData *d, int maxcon, int maxrow) {
   if (maxcon < 1 || maxcon > DMO_MAXCON || maxrow < 1 || maxrow > DMO_MAXROW) return -1;
   d->maxcon = maxcon; d->maxrow = maxrow;

@@ -25,7 +25,11 @@
 extern "C" {
 #endif
 
+#ifdef DM_ROBOT_G1
+#define DMO_MAXCON 200 /* deepmimic_unitree_g1.xml :10 nconmax="200" */
+#else
 #define DMO_MAXCON 100 /* MuJoCo default nconmax [EXT] */
+#endif
 #define DMO_MAXROW 500 /* MuJoCo default njmax [EXT] */
 
 typedef struct DmoContact {
@@ -59,14 +63,14 @@ typedef struct DmoData {
   double qfrc_bias[DM_NV], qfrc_passive[DM_NV], qfrc_actuator[DM_NV], qfrc_smooth[DM_NV];
   double qfrc_constraint[DM_NV];
   double qacc_smooth[DM_NV], qacc[DM_NV];
-  int32_t ncon, nefc, solver_iter, nlimit;
+  int32_t ncon, nefc, solver_iter, nlimit, nfriction, pad_i;
   int32_t overflow_con, overflow_row; /* counts of dropped contacts / rows */
   int32_t stage_ncon[4], stage_nefc[4]; /* per RK stage of the last dmo_step (test diagnostics) */
   DmoContact contact[DMO_MAXCON];
   int32_t efc_type[DMO_MAXROW], efc_id[DMO_MAXROW]; /* 0 limit, 1 frictionless, 2 pyramidal */
   double efc_pos[DMO_MAXROW], efc_margin[DMO_MAXROW], efc_diagApprox[DMO_MAXROW];
   double efc_R[DMO_MAXROW], efc_D[DMO_MAXROW], efc_vel[DMO_MAXROW], efc_aref[DMO_MAXROW];
-  double efc_b[DMO_MAXROW], efc_force[DMO_MAXROW];
+  double efc_b[DMO_MAXROW], efc_force[DMO_MAXROW], efc_frictionloss[DMO_MAXROW];
   double *efc_J;  /* maxrow x nv  (heap) */
   double *efc_AR; /* maxrow x maxrow (heap) */
 } DmoData;
@@ -90,7 +94,8 @@ typedef struct DmoEnv {
 
 enum { DMO_REASON_NONE = 0, DMO_REASON_LOW_Z = 1, DMO_REASON_HIGH_Z = 2,
        DMO_REASON_MAX_EP_LEN = 3, DMO_REASON_ACYCLIC_END = 4,
-       DMO_REASON_SIM_ERROR = 5, DMO_REASON_OBS_BOUNDS = 6 };
+       DMO_REASON_SIM_ERROR = 5, DMO_REASON_OBS_BOUNDS = 6,
+       DMO_REASON_RUN_ANGLE = 8 /* G1 "run" clip only (src/deepmimic_env.py:426-433) */ };
 
 DmoData *dmo_data_new(const DmModel *m);
 void dmo_data_free(DmoData *d);
