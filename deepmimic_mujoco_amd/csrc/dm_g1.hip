@@ -1,0 +1,1995 @@
+// dm_g1.hip — Unitree G1 engine (second robot of the reference: DPEnv(robot="unitree_g1"), src/deepmimic_env.py:272-484;
+// model deepmimic_unitree_g1.xml: nq 44, nv 43, 39 bodies, 94 geoms of which 46 collide, 32 convex meshes, friction loss).
+//
+// First GPU version of SURVEY §8f-2.  Same mapping as the humanoid3d kernel — ONE 64-lane wavefront per environment, all
+// per-env intermediates in LDS, lanes changing role per phase — but written for generality, not yet for speed: the dof
+// tree is walked through tables (no compile-time topology), the Jacobian rows and A = J M^-1 J^T live in a per-env global
+// scratch (L2), and the narrowphase runs wave-uniform in fp64: analytic routines for the pairs MuJoCo has them for,
+// libccd's Minkowski Portal Refinement (restated from its published algorithm, as MuJoCo 2.x's mjc_Convex uses it) for
+// everything that involves a cylinder or a mesh, with the support mapping of a mesh evaluated by all 64 lanes over its
+// hull vertices.  Everything else is fp32.  Checked against oracle/libdm_oracle_g1.so (tests/test_g1_gpu.py).
+#define DM_ROBOT_G1 1
+#define DmModel DmModelG1
+#include "../../include/dm_model.h"
+#undef DmModel
+#include "../../include/deepmimic_g1_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#define DM_OK 0
+#define DM_EINVAL (-22)
+#define DM_ENOMEM (-12)
+#define DM_EHIP (-5)
+#define DM_ENODEV (-19)
+
+namespace g1 {
+
+constexpr int NQ = 44, NV = 43, NU = 37, NB = 39, NG = 94, NJ = 38, NM = 434, NACT = 23, NOBS = 85, NREW = 23;
+constexpr int MAXCON = DMG1_MAXCON, MAXROW = DMG1_MAXROW, MAXANC = 16, MAXSURV = 384;
+constexpr int STATE = 176;   // floats per env in the HBM state row
+constexpr int S_QPOS = 0, S_QVEL = 44, S_WARM = 87, S_CTRL = 130, S_IDX = 167, S_EPLEN = 168, S_EPREW = 169, S_RCNT = 170;
+constexpr int CLIP_ROW = 64;  // per frame: 23 reward qpos | 23 reward qvel | root quat 4 | ee geom xpos 12
+constexpr float MINVALF = 1e-15f, MAXVALF = 1e10f;
+constexpr double MINVAL = 1e-15;
+enum { MODE_STEP = 0, MODE_FORCED = 1, MODE_RESET = 2, MODE_SETSTATE = 3 };
+enum { ROW_LIMIT = 0, ROW_CONTACT = 2, ROW_FRICTION = 3 };
+
+struct Dev {   // read-only model tables (global memory, fp32)
+  float timestep, tolerance, pgs_scale, K, B, solimp[5], total_mass_inv, gravity[3];
+  float low_z, action_scale;
+  int32_t iterations, npair, maxdepth, torso_body, floor_geom, rfoot_geom, lfoot_geom, ee_geom[4];
+  int32_t rew_q[NREW], rew_v[NREW], rew_j[NREW];
+  float qpos0[NQ];
+  int32_t b_parent[40], b_depth[40], b_dof[40];
+  float b_pos[40][3], b_quat[40][4], b_ipos[40][3], b_inertia[40][6], b_mass[40], b_invw[40];
+  uint64_t b_desc[40];   // bit d: body d is in the subtree of b (incl. b)
+  uint64_t b_chain[40];  // bit k: dof k moves body b
+  int32_t d_body[44], d_nanc[44], d_madr[44], d_act[44];
+  uint8_t d_anc[44][MAXANC];   // ancestors of dof k: parent, grand-parent, ...
+  float d_axis[44][3], d_arm[44], d_damp[44], d_invw[44], d_floss[44], d_lo[44], d_hi[44], d_clo[44], d_chi[44];
+  int32_t g_body[96], g_type[96], g_mesh[96];
+  float g_pos[96][3], g_mat[96][9], g_size[96][3], g_rbound[96], g_mu[96];
+  float g_bc[96][3], g_bh[96][3];   // local bounding box of the geom (centre, half extents) for the OBB filter
+  int16_t p_g1[1024], p_g2[1024];
+  int32_t m_vadr[32], m_vnum[32], m_cadr[32], m_cnum[32];   // vertex range and cluster range of each mesh
+  double m_center[32][3];
+  uint8_t tri_a[128], tri_b[128];
+};
+
+struct Lds {   // per-env working set (one wave)
+  float qpos[NQ], qvel[44], warm[44], ctrl[40];
+  float xpos[40][3], xquat[40][4], xmat[40][9], xipos[40][3];
+  float xaxis[44][3];
+  float gpos[96][3], gmat[96][9];
+  float com[4];
+  float cinert[40][10], crb[40][10];
+  float cdof[44][6], cdofdot[44][6];
+  float cvel[40][6], cacc[40][6], cfrc[40][6];
+  float qM[NM + 2], qLD[NM + 2], dinv[44], dsq[44];
+  float bias[44], fsm[44], qas[44], qacc[44], qfc[44], tmp[44];
+  float x0q[NQ], x0v[44], accq[44], accv[44];
+  float c_dist[MAXCON], c_pos[MAXCON][3], c_frame[MAXCON][9], c_mu[MAXCON];
+  int32_t c_g1[MAXCON], c_g2[MAXCON];
+  float e_R[MAXROW], e_b[MAXROW], e_f[MAXROW], e_lim[MAXROW];   // regulariser, aref then b, force, friction-loss bound
+  int32_t e_meta[MAXROW];                                        // type | id << 2
+  int16_t surv[MAXSURV];
+  int32_t info[8];   // ncon, nefc, nlimit, solver_iter, overflow, nsurv
+};
+
+struct ClipDev {
+  const float *rows;    // L x CLIP_ROW
+  const float *reset;   // L x 88 : qpos 44 | qvel 43
+  const float *com;     // L x 4 : mass-weighted body_xpos COM of the frame
+  int32_t L, flags;
+};
+
+struct Launch {
+  const Dev *T;
+  const double *mesh_vert;   // hull vertices of all meshes, xyz, reordered into clusters of 64 (see g1_build_meshes)
+  const int32_t *mesh_oidx;  // original index of each reordered vertex (tie-break of equal support values)
+  const double *mesh_clus;   // per cluster: bounding-sphere centre xyz, radius
+  float *state;              // N x STATE
+  float *jt, *bt, *ar;       // per-env scratch: J^T [44][MAXROW], (D^-1/2 L^-T J^T) [44][MAXROW], A [MAXROW][MAXROW]
+  ClipDev clip;
+  int32_t N, mode, auto_reset, max_ep_length, run_forward, pad;
+  float vel_obs_scale, high_z, obs_bound;
+  uint64_t seed;
+  const float *actions, *in_qpos, *in_qvel, *in_warm;
+  const uint8_t *mask;
+  const int32_t *idx_init;
+  float *obs, *rew, *terms, *terminal_obs, *debug;
+  uint8_t *done;
+  int32_t *reason;
+};
+
+// ------------------------------------------------------------------------------------------ small math (fp32)
+__device__ __forceinline__ float wsum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ void cross3(float *r, const float *a, const float *b) {
+  float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ float dot3(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void quat_mul(float *r, const float *a, const float *b) {
+  float w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  float x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  float y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  float z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+__device__ __forceinline__ void quat2mat(float *m, const float *q) {
+  float w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+__device__ __forceinline__ void quat_rot(float *r, const float *q, const float *v) {
+  float m[9];
+  quat2mat(m, q);
+  float x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2],
+        z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ void quat_normalize(float *q) {
+  float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < MINVALF) { q[0] = 1; q[1] = q[2] = q[3] = 0; }
+  else { float s = 1.f / n; q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s; }
+}
+__device__ __forceinline__ void mat_vec(float *r, const float *m, const float *v) {
+  float x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2],
+        z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ void mul_inert_vec(float *r, const float *I, const float *v) {   // [EXT] mju_mulInertVec
+  r[0] = I[0] * v[0] + I[3] * v[1] + I[4] * v[2] - I[8] * v[4] + I[7] * v[5];
+  r[1] = I[3] * v[0] + I[1] * v[1] + I[5] * v[2] + I[8] * v[3] - I[6] * v[5];
+  r[2] = I[4] * v[0] + I[5] * v[1] + I[2] * v[2] - I[7] * v[3] + I[6] * v[4];
+  r[3] = I[8] * v[1] - I[7] * v[2] + I[9] * v[3];
+  r[4] = I[6] * v[2] - I[8] * v[0] + I[9] * v[4];
+  r[5] = I[7] * v[0] - I[6] * v[1] + I[9] * v[5];
+}
+__device__ __forceinline__ void cross_motion(float *r, const float *vel, const float *v) {   // [EXT] mju_crossMotion
+  r[0] = -vel[2] * v[1] + vel[1] * v[2];
+  r[1] = vel[2] * v[0] - vel[0] * v[2];
+  r[2] = -vel[1] * v[0] + vel[0] * v[1];
+  r[3] = -vel[2] * v[4] + vel[1] * v[5] - vel[5] * v[1] + vel[4] * v[2];
+  r[4] = vel[2] * v[3] - vel[0] * v[5] + vel[5] * v[0] - vel[3] * v[2];
+  r[5] = -vel[1] * v[3] + vel[0] * v[4] - vel[4] * v[0] + vel[3] * v[1];
+}
+__device__ __forceinline__ void cross_force(float *r, const float *vel, const float *f) {   // [EXT] mju_crossForce
+  r[0] = -vel[2] * f[1] + vel[1] * f[2] - vel[5] * f[4] + vel[4] * f[5];
+  r[1] = vel[2] * f[0] - vel[0] * f[2] + vel[5] * f[3] - vel[3] * f[5];
+  r[2] = -vel[1] * f[0] + vel[0] * f[1] - vel[4] * f[3] + vel[3] * f[4];
+  r[3] = -vel[2] * f[4] + vel[1] * f[5];
+  r[4] = vel[2] * f[3] - vel[0] * f[5];
+  r[5] = -vel[1] * f[3] + vel[0] * f[4];
+}
+__device__ __forceinline__ void quat_to_rpy(const float *q, float *rpy) {
+  float w = q[0], x = q[1], y = q[2], z = q[3];
+  rpy[0] = atan2f(2 * (w * x + y * z), 1 - 2 * (x * x + y * y));
+  float s = 2 * (w * y - z * x);
+  rpy[1] = asinf(fminf(fmaxf(s, -1.f), 1.f));
+  rpy[2] = atan2f(2 * (w * z + x * y), 1 - 2 * (y * y + z * z));
+}
+__device__ __host__ __forceinline__ uint32_t hash32(uint64_t seed, uint32_t env, uint32_t step, uint32_t j) {
+  uint64_t x = seed ^ ((uint64_t)env * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)step * 0xBF58476D1CE4E5B9ull) ^
+               ((uint64_t)j * 0x94D049BB133111EBull);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (uint32_t)(x >> 32);
+}
+
+#define SYNC() __syncthreads()
+
+// ------------------------------------------------------------------------------------------ position stage
+__device__ void kinematics(const Dev &T, Lds &S, const int lane) {   // [EXT] mj_kinematics
+  if (lane == 0) {
+    S.xpos[0][0] = S.xpos[0][1] = S.xpos[0][2] = 0;
+    S.xquat[0][0] = 1; S.xquat[0][1] = S.xquat[0][2] = S.xquat[0][3] = 0;
+    for (int i = 0; i < 9; i++) S.xmat[0][i] = (i % 4 == 0) ? 1.f : 0.f;
+    S.xipos[0][0] = S.xipos[0][1] = S.xipos[0][2] = 0;
+  }
+  SYNC();
+  for (int L = 1; L <= T.maxdepth; L++) {
+    if (lane >= 1 && lane < NB && T.b_depth[lane] == L) {
+      const int b = lane, p = T.b_parent[b];
+      float pos[3], q[4];
+      if (b == 1) {   // free root: MuJoCo normalises the stored quaternion in place
+        float qq[4] = {S.qpos[3], S.qpos[4], S.qpos[5], S.qpos[6]};
+        quat_normalize(qq);
+        for (int i = 0; i < 4; i++) { S.qpos[3 + i] = qq[i]; q[i] = qq[i]; }
+        for (int i = 0; i < 3; i++) pos[i] = S.qpos[i];
+      } else {
+        float t[3], bp[3] = {T.b_pos[b][0], T.b_pos[b][1], T.b_pos[b][2]};
+        mat_vec(t, S.xmat[p], bp);
+        for (int i = 0; i < 3; i++) pos[i] = S.xpos[p][i] + t[i];
+        float pq[4] = {S.xquat[p][0], S.xquat[p][1], S.xquat[p][2], S.xquat[p][3]};
+        float bq[4] = {T.b_quat[b][0], T.b_quat[b][1], T.b_quat[b][2], T.b_quat[b][3]};
+        quat_mul(q, pq, bq);
+        const int k = T.b_dof[b];   // the body's single hinge; joint anchor = body origin
+        float ax[3] = {T.d_axis[k][0], T.d_axis[k][1], T.d_axis[k][2]}, wa[3];
+        quat_rot(wa, q, ax);
+        for (int i = 0; i < 3; i++) S.xaxis[k][i] = wa[i];
+        const float ang = S.qpos[k + 1] - T.qpos0[k + 1];
+        float sn, cs;
+        sincosf(0.5f * ang, &sn, &cs);
+        float ql[4] = {cs, ax[0] * sn, ax[1] * sn, ax[2] * sn}, qn[4];
+        quat_mul(qn, q, ql);
+        for (int i = 0; i < 4; i++) q[i] = qn[i];
+      }
+      quat_normalize(q);
+      float m[9];
+      quat2mat(m, q);
+      for (int i = 0; i < 3; i++) S.xpos[b][i] = pos[i];
+      for (int i = 0; i < 4; i++) S.xquat[b][i] = q[i];
+      for (int i = 0; i < 9; i++) S.xmat[b][i] = m[i];
+      float ip[3] = {T.b_ipos[b][0], T.b_ipos[b][1], T.b_ipos[b][2]}, t[3];
+      mat_vec(t, m, ip);
+      for (int i = 0; i < 3; i++) S.xipos[b][i] = pos[i] + t[i];
+    }
+    SYNC();
+  }
+  for (int g = lane; g < NG; g += 64) {
+    const int b = T.g_body[g];
+    float gp[3] = {T.g_pos[g][0], T.g_pos[g][1], T.g_pos[g][2]}, t[3];
+    mat_vec(t, S.xmat[b], gp);
+    for (int i = 0; i < 3; i++) S.gpos[g][i] = S.xpos[b][i] + t[i];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++)
+        S.gmat[g][3 * i + j] = S.xmat[b][3 * i] * T.g_mat[g][j] + S.xmat[b][3 * i + 1] * T.g_mat[g][3 + j] +
+                               S.xmat[b][3 * i + 2] * T.g_mat[g][6 + j];
+  }
+  SYNC();
+}
+
+__device__ void com_pos(const Dev &T, Lds &S, const int lane) {   // [EXT] mj_comPos
+  float m = (lane >= 1 && lane < NB) ? T.b_mass[lane] : 0.f, c[3];
+  for (int i = 0; i < 3; i++) c[i] = wsum(m * ((lane < NB) ? S.xipos[lane][i] : 0.f)) * T.total_mass_inv;
+  if (lane == 0) for (int i = 0; i < 3; i++) S.com[i] = c[i];
+  if (lane < NB) {
+    const int b = lane;
+    float *ci = S.cinert[b];
+    if (b == 0) { for (int i = 0; i < 10; i++) ci[i] = 0; }
+    else {
+      const float *I = T.b_inertia[b], *R = S.xmat[b];
+      float Ib[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]}, Tm[9], W[9];
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) Tm[3 * i + j] = R[3 * i] * Ib[j] + R[3 * i + 1] * Ib[3 + j] + R[3 * i + 2] * Ib[6 + j];
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) W[3 * i + j] = Tm[3 * i] * R[3 * j] + Tm[3 * i + 1] * R[3 * j + 1] + Tm[3 * i + 2] * R[3 * j + 2];
+      float o[3] = {S.xipos[b][0] - c[0], S.xipos[b][1] - c[1], S.xipos[b][2] - c[2]}, mass = T.b_mass[b];
+      float oo = dot3(o, o);
+      ci[0] = W[0] + mass * (oo - o[0] * o[0]); ci[1] = W[4] + mass * (oo - o[1] * o[1]); ci[2] = W[8] + mass * (oo - o[2] * o[2]);
+      ci[3] = W[1] - mass * o[0] * o[1]; ci[4] = W[2] - mass * o[0] * o[2]; ci[5] = W[5] - mass * o[1] * o[2];
+      ci[6] = mass * o[0]; ci[7] = mass * o[1]; ci[8] = mass * o[2]; ci[9] = mass;
+    }
+  }
+  if (lane < NV) {   // cdof: (angular, linear) about the whole-body COM
+    const int k = lane;
+    float *cd = S.cdof[k];
+    if (k < 3) { for (int i = 0; i < 6; i++) cd[i] = 0; cd[3 + k] = 1; }
+    else {
+      float ax[3], off[3];
+      const int b = T.d_body[k];
+      if (k < 6) { ax[0] = S.xmat[1][k - 3]; ax[1] = S.xmat[1][3 + k - 3]; ax[2] = S.xmat[1][6 + k - 3]; }
+      else { ax[0] = S.xaxis[k][0]; ax[1] = S.xaxis[k][1]; ax[2] = S.xaxis[k][2]; }
+      for (int i = 0; i < 3; i++) off[i] = c[i] - S.xpos[b][i];
+      cd[0] = ax[0]; cd[1] = ax[1]; cd[2] = ax[2];
+      cross3(cd + 3, ax, off);
+    }
+  }
+  SYNC();
+}
+
+__device__ void crb_factor(const Dev &T, Lds &S, const int lane) {   // [EXT] mj_crb + mj_factorM
+  if (lane < NB) {
+    float acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t mk = T.b_desc[lane];
+    if (lane == 0) mk = 0;
+    while (mk) {
+      const int d = __ffsll((long long)mk) - 1;
+      mk &= mk - 1;
+      for (int i = 0; i < 10; i++) acc[i] += S.cinert[d][i];
+    }
+    for (int i = 0; i < 10; i++) S.crb[lane][i] = acc[i];
+  }
+  SYNC();
+  if (lane < NV) {
+    const int i = lane;
+    float buf[6], cd[6];
+    for (int q = 0; q < 6; q++) cd[q] = S.cdof[i][q];
+    mul_inert_vec(buf, S.crb[T.d_body[i]], cd);
+    int adr = T.d_madr[i];
+    float v = T.d_arm[i];
+    for (int q = 0; q < 6; q++) v += cd[q] * buf[q];
+    S.qM[adr] = v; S.qLD[adr] = v;
+    const int n = T.d_nanc[i];
+    for (int a = 0; a < n; a++) {
+      const int j = T.d_anc[i][a];
+      float s = 0;
+      for (int q = 0; q < 6; q++) s += S.cdof[j][q] * buf[q];
+      S.qM[adr + 1 + a] = s; S.qLD[adr + 1 + a] = s;
+    }
+  }
+  SYNC();
+  // L^T D L, rows of dof k: [k, parent(k), grand-parent, ...]; step k updates the rows of its ancestors
+  for (int k = NV - 1; k >= 0; k--) {
+    const int n = T.d_nanc[k], kk = T.d_madr[k];
+    if (n > 0) {
+      const float dk = S.qLD[kk];
+      const int np = n * (n + 1) / 2;
+      for (int p = lane; p < np; p += 64) {
+        const int a = T.tri_a[p], c = T.tri_b[p];   // a <= c < n: ancestor i = anc[a], column j = anc[c]
+        const int i = T.d_anc[k][a];
+        S.qLD[T.d_madr[i] + (c - a)] -= S.qLD[kk + 1 + c] * (S.qLD[kk + 1 + a] / dk);
+      }
+      SYNC();
+      if (lane < n) S.qLD[kk + 1 + lane] = S.qLD[kk + 1 + lane] / dk;
+      SYNC();
+    }
+  }
+  if (lane < NV) { const float d = S.qLD[T.d_madr[lane]]; S.dinv[lane] = 1.f / d; S.dsq[lane] = 1.f / sqrtf(d); }
+  SYNC();
+}
+
+// x <- M^-1 x for an LDS vector
+__device__ void solve_m(const Dev &T, Lds &S, float *x, const int lane) {
+  for (int i = NV - 1; i >= 0; i--) {
+    const int n = T.d_nanc[i];
+    if (lane < n) x[T.d_anc[i][lane]] -= S.qLD[T.d_madr[i] + 1 + lane] * x[i];
+    if (n) SYNC();
+  }
+  if (lane < NV) x[lane] *= S.dinv[lane];
+  SYNC();
+  for (int i = 0; i < NV; i++) {
+    const int n = T.d_nanc[i];
+    if (n) {
+      float p = (lane < n) ? S.qLD[T.d_madr[i] + 1 + lane] * x[T.d_anc[i][lane]] : 0.f;
+      p = wsum(p);
+      if (lane == 0) x[i] -= p;
+      SYNC();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ velocity stage
+__device__ void fwd_smooth(const Dev &T, Lds &S, const int lane) {   // mj_comVel, mj_passive, mj_rne, mj_fwdActuation
+  if (lane == 0) for (int i = 0; i < 6; i++) { S.cvel[0][i] = 0; S.cacc[0][i] = (i == 5) ? -T.gravity[2] : 0.f; }
+  SYNC();
+  for (int L = 1; L <= T.maxdepth; L++) {
+    if (lane >= 1 && lane < NB && T.b_depth[lane] == L) {
+      const int b = lane, p = T.b_parent[b];
+      float cv[6], ca[6];
+      for (int i = 0; i < 6; i++) { cv[i] = S.cvel[p][i]; ca[i] = S.cacc[p][i]; }
+      if (b == 1) {
+        for (int k = 0; k < 3; k++) {
+          for (int i = 0; i < 6; i++) S.cdofdot[k][i] = 0;
+          for (int i = 0; i < 6; i++) cv[i] += S.cdof[k][i] * S.qvel[k];
+        }
+        for (int k = 3; k < 6; k++) {
+          float dd[6], cd[6];
+          for (int i = 0; i < 6; i++) cd[i] = S.cdof[k][i];
+          cross_motion(dd, cv, cd);
+          for (int i = 0; i < 6; i++) { S.cdofdot[k][i] = dd[i]; ca[i] += dd[i] * S.qvel[k]; }
+        }
+        for (int k = 3; k < 6; k++)
+          for (int i = 0; i < 6; i++) cv[i] += S.cdof[k][i] * S.qvel[k];
+      } else {
+        const int k = T.b_dof[b];
+        float dd[6], cd[6];
+        for (int i = 0; i < 6; i++) cd[i] = S.cdof[k][i];
+        cross_motion(dd, cv, cd);
+        const float qv = S.qvel[k];
+        for (int i = 0; i < 6; i++) { S.cdofdot[k][i] = dd[i]; ca[i] += dd[i] * qv; cv[i] += cd[i] * qv; }
+      }
+      float t[6], t1[6], f[6];
+      mul_inert_vec(f, S.cinert[b], ca);
+      mul_inert_vec(t, S.cinert[b], cv);
+      cross_force(t1, cv, t);
+      for (int i = 0; i < 6; i++) { S.cvel[b][i] = cv[i]; S.cacc[b][i] = ca[i]; S.cfrc[b][i] = f[i] + t1[i]; }
+    }
+    SYNC();
+  }
+  // subtree sums of cfrc into crb[b][0..5] (crb is dead after the factorisation)
+  if (lane >= 1 && lane < NB) {
+    float acc[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t mk = T.b_desc[lane];
+    while (mk) {
+      const int d = __ffsll((long long)mk) - 1;
+      mk &= mk - 1;
+      for (int i = 0; i < 6; i++) acc[i] += S.cfrc[d][i];
+    }
+    for (int i = 0; i < 6; i++) S.crb[lane][i] = acc[i];
+  }
+  SYNC();
+  if (lane < NV) {
+    const int k = lane;
+    float bias = 0;
+    for (int i = 0; i < 6; i++) bias += S.cdof[k][i] * S.crb[T.d_body[k]][i];
+    const float passive = -T.d_damp[k] * S.qvel[k];
+    float act = 0;
+    const int a = T.d_act[k];
+    if (a >= 0) act = fminf(fmaxf(S.ctrl[a], T.d_clo[k]), T.d_chi[k]);   // gear 1
+    const float fs = passive - bias + act;
+    S.bias[k] = bias; S.fsm[k] = fs; S.qas[k] = fs;
+  }
+  SYNC();
+  solve_m(T, S, S.qas, lane);
+  SYNC();
+}
+
+// ------------------------------------------------------------------------------------------ narrowphase (fp64, wave-uniform)
+struct Con { double dist, pos[3], n[3]; };
+struct Geo {
+  int type, nvert, nclus;
+  double pos[3], mat[9], size[3], center[3];
+  const double *vert, *clus;
+  const int32_t *oidx;
+};
+__device__ __forceinline__ double ddot(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void dcross(double *r, const double *a, const double *b) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ double dnorm(const double *a) { return sqrt(ddot(a, a)); }
+__device__ __forceinline__ double dnormalize(double *a) {
+  double n = dnorm(a);
+  if (n < MINVAL) { a[0] = 1; a[1] = a[2] = 0; return n; }   // [EXT] mju_normalize3
+  a[0] /= n; a[1] /= n; a[2] /= n;
+  return n;
+}
+__device__ __forceinline__ void drot(double *r, const double *m, const double *v) {
+  double x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2],
+         z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ void drot_t(double *r, const double *m, const double *v) {
+  double x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2], y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2],
+         z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ double dclamp(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+__device__ __forceinline__ void dsub(double *r, const double *a, const double *b) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
+
+// Support vertex of a hull in local direction dl.  The vertices are stored in clusters of 64 with a bounding sphere each:
+// the wave scans the cluster whose centre is furthest along dl, then only the clusters whose bound
+// (centre . dl + radius |dl|) can still reach the best value found — exact, ~6 passes instead of one per 64 vertices.
+// Equal support values resolve to the lowest ORIGINAL vertex index, as a serial first-maximum scan would.
+__device__ int mesh_support_index(const Geo &g, const double *dl, const int lane) {
+  const double dn = sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
+  const int nc = g.nclus;
+  double ub[2] = {-1e300, -1e300};   // bounds of clusters lane, lane + 64 (a hull has at most 128 clusters)
+  double cbest = -1e300;
+  int cidx = 0x7fffffff;
+#pragma unroll
+  for (int m = 0; m < 2; m++) {
+    const int c = lane + 64 * m;
+    if (c < nc) {
+      const double *cl = g.clus + 4 * c;
+      const double dc = cl[0] * dl[0] + cl[1] * dl[1] + cl[2] * dl[2];
+      ub[m] = dc + cl[3] * dn;
+      if (dc > cbest) { cbest = dc; cidx = c; }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ob = __shfl_xor(cbest, o);
+    const int oi = __shfl_xor(cidx, o);
+    if (ob > cbest || (ob == cbest && oi < cidx)) { cbest = ob; cidx = oi; }
+  }
+  double best = -1e300;
+  int bi = 0, bo = 0x7fffffff;
+  auto scan = [&](int c) {
+    const int k = 64 * c + lane;
+    double sv = -1e300;
+    int so = 0x7fffffff;
+    if (k < g.nvert) { sv = g.vert[3 * k] * dl[0] + g.vert[3 * k + 1] * dl[1] + g.vert[3 * k + 2] * dl[2]; so = g.oidx[k]; }
+    int sk = k;
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ob = __shfl_xor(sv, o);
+      const int oo = __shfl_xor(so, o), ok = __shfl_xor(sk, o);
+      if (ob > sv || (ob == sv && oo < so)) { sv = ob; so = oo; sk = ok; }
+    }
+    if (sv > best || (sv == best && so < bo)) { best = sv; bo = so; bi = sk; }
+  };
+  scan(cidx);
+#pragma unroll
+  for (int m = 0; m < 2; m++) {
+    unsigned long long todo = __ballot(ub[m] >= best && (lane + 64 * m) != cidx && (lane + 64 * m) < nc);
+    while (todo) {
+      const int l = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const double u = __shfl(ub[m], l);
+      if (u >= best) scan(l + 64 * m);
+    }
+  }
+  return bi;
+}
+
+__device__ void support(const Geo &g, const double *dir, double *out, const int lane) {   // [EXT] mjccd_support
+  double dl[3], p[3] = {0, 0, 0};
+  drot_t(dl, g.mat, dir);
+  if (g.type == DM_GEOM_SPHERE) {
+    const double n = dnorm(dl);
+    if (n > 0) for (int i = 0; i < 3; i++) p[i] = dl[i] * g.size[0] / n;
+  } else if (g.type == DM_GEOM_CYLINDER) {
+    const double n = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
+    if (n > MINVAL) { p[0] = dl[0] * g.size[0] / n; p[1] = dl[1] * g.size[0] / n; }
+    p[2] = dl[2] >= 0 ? g.size[1] : -g.size[1];
+  } else if (g.type == DM_GEOM_BOX) {
+    for (int i = 0; i < 3; i++) p[i] = dl[i] >= 0 ? g.size[i] : -g.size[i];
+  } else if (g.type == DM_GEOM_MESH) {
+    const int bi = mesh_support_index(g, dl, lane);
+    p[0] = g.vert[3 * bi]; p[1] = g.vert[3 * bi + 1]; p[2] = g.vert[3 * bi + 2];
+  }
+  drot(out, g.mat, p);
+  for (int i = 0; i < 3; i++) out[i] += g.pos[i];
+}
+
+// ---- libccd MPR (ccdMPRPenetration), restated; tolerance / iteration cap = MuJoCo's mpr_tolerance / mpr_iterations
+#define CCD_EPS 2.220446049250313e-16
+#define MPR_TOL 1e-6
+#define MPR_ITER 50
+struct Sup { double v[3], v1[3], v2[3]; };
+__device__ __forceinline__ bool ccd_zero(double x) { return fabs(x) < CCD_EPS; }
+__device__ __forceinline__ bool ccd_eq(double a, double b) {
+  double ab = fabs(a - b);
+  if (ab < CCD_EPS) return true;
+  a = fabs(a); b = fabs(b);
+  return b > a ? ab < CCD_EPS * b : ab < CCD_EPS * a;
+}
+__device__ void mpr_support(const Geo &a, const Geo &b, const double *dir, Sup &s, const int lane) {
+  double nd[3] = {-dir[0], -dir[1], -dir[2]};
+  support(a, dir, s.v1, lane);
+  support(b, nd, s.v2, lane);
+  dsub(s.v, s.v1, s.v2);
+}
+__device__ __forceinline__ void portal_dir(const Sup *ps, double *dir) {
+  double a[3], b[3];
+  dsub(a, ps[2].v, ps[1].v);
+  dsub(b, ps[3].v, ps[1].v);
+  dcross(dir, a, b);
+  dnormalize(dir);
+}
+__device__ __forceinline__ bool reach_tol(const Sup *ps, const Sup &v4, const double *dir) {
+  const double dv4 = ddot(v4.v, dir);
+  double m = fmin(fmin(dv4 - ddot(ps[1].v, dir), dv4 - ddot(ps[2].v, dir)), dv4 - ddot(ps[3].v, dir));
+  return ccd_eq(m, MPR_TOL) || m < MPR_TOL;
+}
+__device__ __forceinline__ void expand_portal(Sup *ps, const Sup &v4) {
+  double c[3];
+  dcross(c, v4.v, ps[0].v);
+  if (ddot(ps[1].v, c) > 0) { if (ddot(ps[2].v, c) > 0) ps[1] = v4; else ps[3] = v4; }
+  else { if (ddot(ps[3].v, c) > 0) ps[2] = v4; else ps[1] = v4; }
+}
+__device__ double tri_closest_origin(const double *a, const double *b, const double *c, double *w) {
+  double ab[3], ac[3], ap[3] = {-a[0], -a[1], -a[2]};
+  dsub(ab, b, a); dsub(ac, c, a);
+  const double d1 = ddot(ab, ap), d2 = ddot(ac, ap);
+  if (d1 <= 0 && d2 <= 0) { for (int i = 0; i < 3; i++) w[i] = a[i]; return ddot(w, w); }
+  double bp[3] = {-b[0], -b[1], -b[2]};
+  const double d3 = ddot(ab, bp), d4 = ddot(ac, bp);
+  if (d3 >= 0 && d4 <= d3) { for (int i = 0; i < 3; i++) w[i] = b[i]; return ddot(w, w); }
+  const double vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) {
+    const double v = d1 / (d1 - d3);
+    for (int i = 0; i < 3; i++) w[i] = a[i] + v * ab[i];
+    return ddot(w, w);
+  }
+  double cp[3] = {-c[0], -c[1], -c[2]};
+  const double d5 = ddot(ab, cp), d6 = ddot(ac, cp);
+  if (d6 >= 0 && d5 <= d6) { for (int i = 0; i < 3; i++) w[i] = c[i]; return ddot(w, w); }
+  const double vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) {
+    const double v = d2 / (d2 - d6);
+    for (int i = 0; i < 3; i++) w[i] = a[i] + v * ac[i];
+    return ddot(w, w);
+  }
+  const double va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+    const double v = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    for (int i = 0; i < 3; i++) w[i] = b[i] + v * (c[i] - b[i]);
+    return ddot(w, w);
+  }
+  const double den = 1.0 / (va + vb + vc), v = vb * den, u = vc * den;
+  for (int i = 0; i < 3; i++) w[i] = a[i] + ab[i] * v + ac[i] * u;
+  return ddot(w, w);
+}
+// 0 = penetration (depth, dir a -> b, pos), -1 = none
+__device__ int mpr_penetration(const Geo &a, const Geo &b, double *depth, double *dir, double *pos, const int lane) {
+  Sup ps[4], v4;
+  double d[3], va[3], vb[3], dot;
+  for (int i = 0; i < 3; i++) { ps[0].v1[i] = a.center[i]; ps[0].v2[i] = b.center[i]; ps[0].v[i] = a.center[i] - b.center[i]; }
+  if (ccd_zero(ps[0].v[0]) && ccd_zero(ps[0].v[1]) && ccd_zero(ps[0].v[2])) ps[0].v[0] += CCD_EPS * 10;
+  for (int i = 0; i < 3; i++) d[i] = -ps[0].v[i];
+  dnormalize(d);
+  mpr_support(a, b, d, ps[1], lane);
+  dot = ddot(ps[1].v, d);
+  if (ccd_zero(dot) || dot < 0) return -1;
+  dcross(d, ps[0].v, ps[1].v);
+  if (ccd_zero(ddot(d, d))) {
+    for (int i = 0; i < 3; i++) pos[i] = 0.5 * (ps[1].v1[i] + ps[1].v2[i]);
+    if (ccd_zero(ps[1].v[0]) && ccd_zero(ps[1].v[1]) && ccd_zero(ps[1].v[2])) { *depth = 0; dir[0] = dir[1] = dir[2] = 0; return 0; }
+    for (int i = 0; i < 3; i++) dir[i] = ps[1].v[i];
+    *depth = dnormalize(dir);
+    return 0;
+  }
+  dnormalize(d);
+  mpr_support(a, b, d, ps[2], lane);
+  dot = ddot(ps[2].v, d);
+  if (ccd_zero(dot) || dot < 0) return -1;
+  dsub(va, ps[1].v, ps[0].v); dsub(vb, ps[2].v, ps[0].v);
+  dcross(d, va, vb);
+  dnormalize(d);
+  if (ddot(d, ps[0].v) > 0) { Sup t = ps[1]; ps[1] = ps[2]; ps[2] = t; for (int i = 0; i < 3; i++) d[i] = -d[i]; }
+  for (int guard = 0;; guard++) {
+    if (guard > 1000) return -1;
+    mpr_support(a, b, d, ps[3], lane);
+    dot = ddot(ps[3].v, d);
+    if (ccd_zero(dot) || dot < 0) return -1;
+    bool cont = false;
+    dcross(va, ps[1].v, ps[3].v);
+    dot = ddot(va, ps[0].v);
+    if (dot < 0 && !ccd_zero(dot)) { ps[2] = ps[3]; cont = true; }
+    if (!cont) {
+      dcross(va, ps[3].v, ps[2].v);
+      dot = ddot(va, ps[0].v);
+      if (dot < 0 && !ccd_zero(dot)) { ps[1] = ps[3]; cont = true; }
+    }
+    if (!cont) break;
+    dsub(va, ps[1].v, ps[0].v); dsub(vb, ps[2].v, ps[0].v);
+    dcross(d, va, vb);
+    dnormalize(d);
+  }
+  for (int guard = 0;; guard++) {   // refinePortal
+    if (guard >= 10000) return -1;
+    portal_dir(ps, d);
+    dot = ddot(d, ps[1].v);
+    if (ccd_zero(dot) || dot > 0) break;
+    mpr_support(a, b, d, v4, lane);
+    dot = ddot(v4.v, d);
+    if (!(ccd_zero(dot) || dot > 0) || reach_tol(ps, v4, d)) return -1;
+    expand_portal(ps, v4);
+  }
+  for (int it = 0;; it++) {   // findPenetr
+    portal_dir(ps, d);
+    mpr_support(a, b, d, v4, lane);
+    if (reach_tol(ps, v4, d) || it > MPR_ITER) {
+      *depth = sqrt(tri_closest_origin(ps[1].v, ps[2].v, ps[3].v, dir));
+      if (ccd_zero(*depth)) dir[0] = dir[1] = dir[2] = 0; else dnormalize(dir);
+      double bb[4], t[3], sum;
+      portal_dir(ps, d);
+      dcross(t, ps[1].v, ps[2].v); bb[0] = ddot(t, ps[3].v);
+      dcross(t, ps[3].v, ps[2].v); bb[1] = ddot(t, ps[0].v);
+      dcross(t, ps[0].v, ps[1].v); bb[2] = ddot(t, ps[3].v);
+      dcross(t, ps[2].v, ps[1].v); bb[3] = ddot(t, ps[0].v);
+      sum = bb[0] + bb[1] + bb[2] + bb[3];
+      if (ccd_zero(sum) || sum < 0) {
+        bb[0] = 0;
+        dcross(t, ps[2].v, ps[3].v); bb[1] = ddot(t, d);
+        dcross(t, ps[3].v, ps[1].v); bb[2] = ddot(t, d);
+        dcross(t, ps[1].v, ps[2].v); bb[3] = ddot(t, d);
+        sum = bb[1] + bb[2] + bb[3];
+      }
+      const double inv = 1.0 / sum;
+      double p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
+      for (int k = 0; k < 4; k++)
+        for (int i = 0; i < 3; i++) { p1[i] += bb[k] * ps[k].v1[i]; p2[i] += bb[k] * ps[k].v2[i]; }
+      for (int i = 0; i < 3; i++) pos[i] = 0.5 * inv * (p1[i] + p2[i]);
+      return 0;
+    }
+    expand_portal(ps, v4);
+  }
+}
+
+// [EXT] mjc_Convex at margin 0; spheres get their analytic normal afterwards (mjc_fixNormal)
+__device__ int np_convex(Con *c, const Geo &a, const Geo &b, const int lane) {
+  double depth, dir[3], pos[3];
+  if (mpr_penetration(a, b, &depth, dir, pos, lane) != 0) return 0;
+  if (dir[0] == 0 && dir[1] == 0 && dir[2] == 0) return 0;
+  c->dist = -depth;
+  for (int i = 0; i < 3; i++) { c->pos[i] = pos[i]; c->n[i] = dir[i]; }
+  double n1[3], n2[3];
+  bool h1 = false, h2 = false;
+  if (a.type == DM_GEOM_SPHERE) { dsub(n1, pos, a.pos); h1 = dnormalize(n1) > MINVAL; }
+  if (b.type == DM_GEOM_SPHERE) { dsub(n2, b.pos, pos); h2 = dnormalize(n2) > MINVAL; }
+  if (h1 && h2) { for (int i = 0; i < 3; i++) c->n[i] = n1[i] + n2[i]; dnormalize(c->n); }
+  else if (h1) for (int i = 0; i < 3; i++) c->n[i] = n1[i];
+  else if (h2) for (int i = 0; i < 3; i++) c->n[i] = n2[i];
+  return 1;
+}
+
+__device__ int np_plane_sphere(Con *c, const Geo &p, const double *spos, double r) {
+  double n[3] = {p.mat[2], p.mat[5], p.mat[8]}, df[3];
+  dsub(df, spos, p.pos);
+  const double dist = ddot(df, n) - r;
+  if (dist > 0) return 0;
+  c->dist = dist;
+  for (int i = 0; i < 3; i++) { c->n[i] = n[i]; c->pos[i] = spos[i] - n[i] * (r + 0.5 * dist); }
+  return 1;
+}
+__device__ int np_plane_box(Con *c, const Geo &p, const Geo &b) {
+  double n[3] = {p.mat[2], p.mat[5], p.mat[8]}, df[3];
+  dsub(df, b.pos, p.pos);
+  const double dist = ddot(df, n);
+  int cnt = 0;
+  for (int i = 0; i < 8; i++) {
+    double v[3] = {b.size[0] * ((i & 1) ? 1 : -1), b.size[1] * ((i & 2) ? 1 : -1), b.size[2] * ((i & 4) ? 1 : -1)}, corner[3];
+    drot(corner, b.mat, v);
+    const double ld = ddot(n, corner);
+    if (dist + ld > 0 || ld > 0) continue;
+    c[cnt].dist = dist + ld;
+    for (int k = 0; k < 3; k++) { c[cnt].n[k] = n[k]; c[cnt].pos[k] = corner[k] + b.pos[k] - n[k] * 0.5 * c[cnt].dist; }
+    if (++cnt >= 4) return 4;
+  }
+  return cnt;
+}
+__device__ int np_plane_cylinder(Con *c, const Geo &p, const Geo &cy) {   // [EXT] mjc_PlaneCylinder
+  double normal[3] = {p.mat[2], p.mat[5], p.mat[8]}, axis[3] = {cy.mat[2], cy.mat[5], cy.mat[8]};
+  double prjaxis = ddot(normal, axis);
+  if (prjaxis > 0) { for (int i = 0; i < 3; i++) axis[i] = -axis[i]; prjaxis = -prjaxis; }
+  double dif[3], vec[3];
+  dsub(dif, cy.pos, p.pos);
+  const double dist0 = ddot(dif, normal);
+  for (int i = 0; i < 3; i++) vec[i] = axis[i] * prjaxis - normal[i];
+  const double len2 = ddot(vec, vec);
+  if (len2 >= MINVAL * MINVAL) { const double s = cy.size[0] / sqrt(len2); for (int i = 0; i < 3; i++) vec[i] *= s; }
+  else for (int i = 0; i < 3; i++) vec[i] = cy.mat[3 * i] * cy.size[0];
+  const double prjvec = ddot(vec, normal);
+  for (int i = 0; i < 3; i++) axis[i] *= cy.size[1];
+  prjaxis *= cy.size[1];
+  int n = 0;
+  if (dist0 + prjaxis + prjvec > 0) return 0;
+  { const double dd = dist0 + prjaxis + prjvec; c[n].dist = dd;
+    for (int i = 0; i < 3; i++) { c[n].pos[i] = cy.pos[i] + vec[i] + axis[i] - normal[i] * dd * 0.5; c[n].n[i] = normal[i]; } n++; }
+  if (dist0 - prjaxis + prjvec <= 0) {
+    const double dd = dist0 - prjaxis + prjvec; c[n].dist = dd;
+    for (int i = 0; i < 3; i++) { c[n].pos[i] = cy.pos[i] + vec[i] - axis[i] - normal[i] * dd * 0.5; c[n].n[i] = normal[i]; } n++;
+  }
+  const double prjvec1 = -0.5 * prjvec;
+  if (dist0 + prjaxis + prjvec1 <= 0) {
+    double vec1[3];
+    dcross(vec1, vec, axis);
+    dnormalize(vec1);
+    for (int i = 0; i < 3; i++) vec1[i] *= cy.size[0] * sqrt(3.0) * 0.5;
+    const double dd = dist0 + prjaxis + prjvec1;
+    for (int sg = 1; sg >= -1; sg -= 2) {
+      c[n].dist = dd;
+      for (int i = 0; i < 3; i++) { c[n].pos[i] = cy.pos[i] + sg * vec1[i] + axis[i] - 0.5 * vec[i] - normal[i] * dd * 0.5; c[n].n[i] = normal[i]; }
+      n++;
+    }
+  }
+  return n;
+}
+// [EXT] mjc_PlaneConvex for a mesh: support vertex towards the plane + three directions tilted by 0.3 (low-confidence
+// restatement of the multi-contact rule, identical to the oracle's)
+__device__ int np_plane_mesh(Con *c, const Geo &p, const Geo &g, const int lane) {
+  double normal[3] = {p.mat[2], p.mat[5], p.mat[8]}, t1[3] = {p.mat[0], p.mat[3], p.mat[6]}, t2[3] = {p.mat[1], p.mat[4], p.mat[7]};
+  int used[4], n = 0;
+  for (int k = 0; k < 4; k++) {
+    double dw[3], dl[3];
+    if (k == 0) for (int i = 0; i < 3; i++) dw[i] = -normal[i];
+    else {
+      const double ang = 2.0 * 3.14159265358979323846 * (k - 1) / 3.0, ca = 0.3 * cos(ang), sa = 0.3 * sin(ang);
+      for (int i = 0; i < 3; i++) dw[i] = -normal[i] + ca * t1[i] + sa * t2[i];
+    }
+    drot_t(dl, g.mat, dw);
+    const int vi = mesh_support_index(g, dl, lane);
+    bool dup = false;
+    for (int j = 0; j < n; j++) dup |= used[j] == vi;
+    if (dup) continue;
+    double v[3], dif[3], vl[3] = {g.vert[3 * vi], g.vert[3 * vi + 1], g.vert[3 * vi + 2]};
+    drot(v, g.mat, vl);
+    for (int i = 0; i < 3; i++) v[i] += g.pos[i];
+    dsub(dif, v, p.pos);
+    const double dist = ddot(dif, normal);
+    if (dist > 0) { if (k == 0) return 0; continue; }
+    used[n] = vi;
+    c[n].dist = dist;
+    for (int i = 0; i < 3; i++) { c[n].pos[i] = v[i] - 0.5 * dist * normal[i]; c[n].n[i] = normal[i]; }
+    n++;
+  }
+  return n;
+}
+__device__ int np_sphere_sphere(Con *c, const double *p1, double r1, const double *p2, double r2) {
+  double df[3];
+  dsub(df, p2, p1);
+  const double cd = dnorm(df), dist = cd - r1 - r2;
+  if (dist > 0) return 0;
+  c->dist = dist;
+  if (cd < MINVAL) { c->n[0] = 1; c->n[1] = c->n[2] = 0; }
+  else for (int i = 0; i < 3; i++) c->n[i] = df[i] / cd;
+  for (int i = 0; i < 3; i++) c->pos[i] = p1[i] + c->n[i] * (r1 + 0.5 * dist);
+  return 1;
+}
+__device__ int np_sphere_box(Con *c, const Geo &s, const Geo &b) {
+  double t[3], ctr[3], cl[3], nl[3];
+  const double r = s.size[0];
+  dsub(t, s.pos, b.pos);
+  drot_t(ctr, b.mat, t);
+  for (int i = 0; i < 3; i++) { cl[i] = dclamp(ctr[i], -b.size[i], b.size[i]); nl[i] = cl[i] - ctr[i]; }
+  const double dd = dnorm(nl);
+  double dist, pl[3];
+  if (dd - r > 0) return 0;
+  if (dd <= MINVAL) {
+    double closest = 2 * (b.size[0] + b.size[1] + b.size[2]);
+    int k = 0;
+    for (int i = 0; i < 6; i++) {
+      const double test = b.size[i / 2] - ((i % 2) ? -1.0 : 1.0) * ctr[i / 2];
+      if (test < closest) { closest = test; k = i; }
+    }
+    nl[0] = nl[1] = nl[2] = 0;
+    nl[k / 2] = (k % 2) ? 1.0 : -1.0;
+    dist = -closest - r;
+  } else {
+    for (int i = 0; i < 3; i++) nl[i] /= dd;
+    dist = dd - r;
+  }
+  for (int i = 0; i < 3; i++) pl[i] = ctr[i] + nl[i] * (r + 0.5 * dist);
+  c->dist = dist;
+  drot(c->n, b.mat, nl);
+  drot(t, b.mat, pl);
+  for (int i = 0; i < 3; i++) c->pos[i] = t[i] + b.pos[i];
+  return 1;
+}
+// box-box (SAT + face clipping), same construction as the humanoid3d path (own construction, not MuJoCo's code)
+__device__ int np_box_box(Con *c, const Geo &A, const Geo &Bx) {
+  const double *p1 = A.pos, *R1 = A.mat, *s1 = A.size, *p2 = Bx.pos, *R2 = Bx.mat, *s2 = Bx.size;
+  double R[9], AR[9], t[3], tw[3];
+  dsub(tw, p2, p1);
+  drot_t(t, R1, tw);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      R[3 * i + j] = R1[i] * R2[j] + R1[3 + i] * R2[3 + j] + R1[6 + i] * R2[6 + j];
+      AR[3 * i + j] = fabs(R[3 * i + j]) + 1e-9;
+    }
+  double best = -1e30, bn[3] = {0, 0, 0};
+  int code = -1;
+  for (int i = 0; i < 3; i++) {
+    const double s = fabs(t[i]) - (s1[i] + s2[0] * AR[3 * i] + s2[1] * AR[3 * i + 1] + s2[2] * AR[3 * i + 2]);
+    if (s > 0) return 0;
+    if (s > best) { best = s; code = i; }
+  }
+  for (int j = 0; j < 3; j++) {
+    const double tj = t[0] * R[j] + t[1] * R[3 + j] + t[2] * R[6 + j];
+    const double s = fabs(tj) - (s2[j] + s1[0] * AR[j] + s1[1] * AR[3 + j] + s1[2] * AR[6 + j]);
+    if (s > 0) return 0;
+    if (s > best) { best = s; code = 3 + j; }
+  }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double ei[3] = {0, 0, 0}, ej[3] = {R[j], R[3 + j], R[6 + j]}, ax[3];
+      ei[i] = 1;
+      dcross(ax, ei, ej);
+      const double l = dnorm(ax);
+      if (l < 1e-6) continue;
+      for (int k = 0; k < 3; k++) ax[k] /= l;
+      double ra = 0, rb = 0;
+      for (int k = 0; k < 3; k++) ra += s1[k] * fabs(ax[k]);
+      for (int k = 0; k < 3; k++) { double ek[3] = {R[k], R[3 + k], R[6 + k]}; rb += s2[k] * fabs(ddot(ax, ek)); }
+      const double s = fabs(ddot(t, ax)) - (ra + rb);
+      if (s > 0) return 0;
+      if (s > best + 0.05 * fabs(best) + 1e-6) { best = s; code = 6 + 3 * i + j; bn[0] = ax[0]; bn[1] = ax[1]; bn[2] = ax[2]; }
+    }
+  if (code < 0) return 0;
+  if (code >= 6) {
+    const int i = (code - 6) / 3, j = (code - 6) % 3;
+    double n1[3] = {bn[0], bn[1], bn[2]};
+    if (ddot(n1, t) < 0) for (int k = 0; k < 3; k++) n1[k] = -n1[k];
+    double pa[3], pb[3];
+    for (int k = 0; k < 3; k++) pa[k] = (k == i) ? 0 : ((n1[k] > 0) ? s1[k] : -s1[k]);
+    for (int k = 0; k < 3; k++) pb[k] = t[k];
+    for (int k = 0; k < 3; k++) {
+      if (k == j) continue;
+      double ek[3] = {R[k], R[3 + k], R[6 + k]};
+      const double sg = (ddot(n1, ek) > 0) ? -s2[k] : s2[k];
+      for (int q = 0; q < 3; q++) pb[q] += sg * ek[q];
+    }
+    double ua[3] = {0, 0, 0}, ub[3] = {R[j], R[3 + j], R[6 + j]}, w[3];
+    ua[i] = 1;
+    dsub(w, pb, pa);
+    const double uaub = ddot(ua, ub), q1 = ddot(ua, w), q2 = -ddot(ub, w), dd = 1 - uaub * uaub;
+    double alpha = 0, beta = 0;
+    if (dd > 1e-12) { alpha = (q1 + uaub * q2) / dd; beta = (uaub * q1 + q2) / dd; }
+    alpha = dclamp(alpha, -s1[i], s1[i]);
+    beta = dclamp(beta, -s2[j], s2[j]);
+    double mid[3], mw[3];
+    for (int k = 0; k < 3; k++) mid[k] = 0.5 * ((pa[k] + ua[k] * alpha) + (pb[k] + ub[k] * beta));
+    drot(mw, R1, mid);
+    drot(c->n, R1, n1);
+    for (int k = 0; k < 3; k++) c->pos[k] = mw[k] + p1[k];
+    c->dist = best;
+    return 1;
+  }
+  const double *Ra, *Rb, *sa, *sb, *pa, *pb;
+  int ax, flip;
+  if (code < 3) { Ra = R1; Rb = R2; sa = s1; sb = s2; pa = p1; pb = p2; ax = code; flip = 0; }
+  else { Ra = R2; Rb = R1; sa = s2; sb = s1; pa = p2; pb = p1; ax = code - 3; flip = 1; }
+  double nrm[3] = {Ra[ax], Ra[3 + ax], Ra[6 + ax]}, dab[3];
+  dsub(dab, pb, pa);
+  if (ddot(nrm, dab) < 0) for (int k = 0; k < 3; k++) nrm[k] = -nrm[k];
+  int ib = 0;
+  double bestd = -1, nb[3];
+  drot_t(nb, Rb, nrm);
+  for (int k = 0; k < 3; k++) if (fabs(nb[k]) > bestd) { bestd = fabs(nb[k]); ib = k; }
+  const double sgn = (nb[ib] > 0) ? -1.0 : 1.0;
+  const int u = (ib + 1) % 3, v = (ib + 2) % 3;
+  double poly[16][3], tmp[16][3];
+  int np = 4;
+  for (int q = 0; q < 4; q++) {
+    const double su = (q == 0 || q == 3) ? -sb[u] : sb[u], sv = (q < 2) ? -sb[v] : sb[v];
+    double loc[3], w[3], rel[3];
+    loc[ib] = sgn * sb[ib]; loc[u] = su; loc[v] = sv;
+    drot(w, Rb, loc);
+    for (int k = 0; k < 3; k++) rel[k] = w[k] + pb[k] - pa[k];
+    drot_t(poly[q], Ra, rel);
+  }
+  const int axes[2] = {(ax + 1) % 3, (ax + 2) % 3};
+  for (int e = 0; e < 2; e++)
+    for (int sd = -1; sd <= 1; sd += 2) {
+      const int a = axes[e];
+      int nn = 0;
+      for (int q = 0; q < np; q++) {
+        const double *P = poly[q], *Q = poly[(q + 1) % np];
+        const double dp = sd * P[a] - sa[a], dq = sd * Q[a] - sa[a];
+        if (dp <= 0) { for (int k = 0; k < 3; k++) tmp[nn][k] = P[k]; nn++; }
+        if ((dp < 0 && dq > 0) || (dp > 0 && dq < 0)) {
+          const double f = dp / (dp - dq);
+          for (int k = 0; k < 3; k++) tmp[nn][k] = P[k] + f * (Q[k] - P[k]);
+          nn++;
+        }
+        if (nn >= 15) break;
+      }
+      np = nn;
+      for (int q = 0; q < np; q++) for (int k = 0; k < 3; k++) poly[q][k] = tmp[q][k];
+      if (np == 0) return 0;
+    }
+  double nl[3];
+  drot_t(nl, Ra, nrm);
+  int cnt = 0;
+  for (int q = 0; q < np && cnt < 8; q++) {
+    const double depth = ddot(nl, poly[q]) - sa[ax];
+    if (depth > 0) continue;
+    double pl[3], pw[3];
+    for (int k = 0; k < 3; k++) pl[k] = poly[q][k] - nl[k] * 0.5 * depth;
+    drot(pw, Ra, pl);
+    for (int k = 0; k < 3; k++) { c[cnt].pos[k] = pw[k] + pa[k]; c[cnt].n[k] = flip ? -nrm[k] : nrm[k]; }
+    c[cnt].dist = depth;
+    cnt++;
+  }
+  while (cnt > 4) {
+    int w = 0;
+    for (int q = 1; q < cnt; q++) if (c[q].dist >= c[w].dist) w = q;
+    for (int q = w; q < cnt - 1; q++) c[q] = c[q + 1];
+    cnt--;
+  }
+  return cnt;
+}
+
+__device__ void load_geo(const Dev &T, const Lds &S, const Launch &P, int g, Geo &o) {
+  o.type = T.g_type[g];
+  for (int i = 0; i < 3; i++) { o.pos[i] = S.gpos[g][i]; o.size[i] = T.g_size[g][i]; o.center[i] = o.pos[i]; }
+  for (int i = 0; i < 9; i++) o.mat[i] = S.gmat[g][i];
+  o.vert = nullptr; o.clus = nullptr; o.oidx = nullptr; o.nvert = 0; o.nclus = 0;
+  if (o.type == DM_GEOM_MESH) {
+    const int me = T.g_mesh[g];
+    o.vert = P.mesh_vert + 3 * (size_t)T.m_vadr[me];
+    o.oidx = P.mesh_oidx + T.m_vadr[me];
+    o.clus = P.mesh_clus + 4 * (size_t)T.m_cadr[me];
+    o.nvert = T.m_vnum[me];
+    o.nclus = T.m_cnum[me];
+    double c[3] = {T.m_center[me][0], T.m_center[me][1], T.m_center[me][2]}, t[3];
+    drot(t, o.mat, c);
+    for (int i = 0; i < 3; i++) o.center[i] += t[i];
+  }
+}
+
+__device__ void make_frame(float *f) {   // [EXT] mju_makeFrame
+  float n = sqrtf(dot3(f, f));
+  if (n < MINVALF) { f[0] = 1; f[1] = f[2] = 0; } else { f[0] /= n; f[1] /= n; f[2] /= n; }
+  if (sqrtf(dot3(f + 3, f + 3)) < 0.5f) {
+    f[3] = f[4] = f[5] = 0;
+    if (f[1] < 0.5f && f[1] > -0.5f) f[4] = 1; else f[5] = 1;
+  }
+  const float t = dot3(f, f + 3);
+  for (int i = 0; i < 3; i++) f[3 + i] -= t * f[i];
+  n = sqrtf(dot3(f + 3, f + 3));
+  if (n < MINVALF) { f[3] = 1; f[4] = f[5] = 0; } else { f[3] /= n; f[4] /= n; f[5] /= n; }
+  cross3(f + 6, f, f + 3);
+}
+
+// Separating-axis test of two oriented boxes (15 axes), conservative by `slack`: true only if the boxes are at least that far
+// apart.  The filter is result-neutral: disjoint bounding boxes cannot hold intersecting geoms.
+__device__ bool obb_separated(const float *c1, const float *R1, const float *h1, const float *c2, const float *R2, const float *h2,
+                              const float slack) {
+  float R[9], AR[9], t[3], tw[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
+  for (int i = 0; i < 3; i++) t[i] = R1[i] * tw[0] + R1[3 + i] * tw[1] + R1[6 + i] * tw[2];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      R[3 * i + j] = R1[i] * R2[j] + R1[3 + i] * R2[3 + j] + R1[6 + i] * R2[6 + j];
+      AR[3 * i + j] = fabsf(R[3 * i + j]) + 1e-6f;
+    }
+  for (int i = 0; i < 3; i++)
+    if (fabsf(t[i]) > h1[i] + h2[0] * AR[3 * i] + h2[1] * AR[3 * i + 1] + h2[2] * AR[3 * i + 2] + slack) return true;
+  for (int j = 0; j < 3; j++)
+    if (fabsf(t[0] * R[j] + t[1] * R[3 + j] + t[2] * R[6 + j]) > h2[j] + h1[0] * AR[j] + h1[1] * AR[3 + j] + h1[2] * AR[6 + j] + slack)
+      return true;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const float ra = h1[i1] * AR[3 * i2 + j] + h1[i2] * AR[3 * i1 + j], rb = h2[j1] * AR[3 * i + j2] + h2[j2] * AR[3 * i + j1];
+      if (fabsf(t[i2] * R[3 * i1 + j] - t[i1] * R[3 * i2 + j]) > ra + rb + slack) return true;
+    }
+  return false;
+}
+
+// [EXT] mj_collision: candidate pairs in canonical order, bounding-sphere + bounding-box filters, narrowphase
+__device__ int collide(const Dev &T, Lds &S, const Launch &P, const int lane) {
+  int nsurv = 0, overflow = 0;
+  for (int base = 0; base < T.npair; base += 64) {
+    const int p = base + lane;
+    bool keep = false;
+    if (p < T.npair) {
+      const int g1 = T.p_g1[p], g2 = T.p_g2[p];
+      float df[3] = {S.gpos[g2][0] - S.gpos[g1][0], S.gpos[g2][1] - S.gpos[g1][1], S.gpos[g2][2] - S.gpos[g1][2]};
+      float c2[3], bc2[3] = {T.g_bc[g2][0], T.g_bc[g2][1], T.g_bc[g2][2]}, h2[3] = {T.g_bh[g2][0], T.g_bh[g2][1], T.g_bh[g2][2]};
+      mat_vec(c2, S.gmat[g2], bc2);
+      for (int i = 0; i < 3; i++) c2[i] += S.gpos[g2][i];
+      if (T.g_type[g1] != DM_GEOM_PLANE) {
+        keep = sqrtf(dot3(df, df)) <= T.g_rbound[g1] + T.g_rbound[g2];
+        if (keep) {
+          float c1[3], bc1[3] = {T.g_bc[g1][0], T.g_bc[g1][1], T.g_bc[g1][2]}, h1[3] = {T.g_bh[g1][0], T.g_bh[g1][1], T.g_bh[g1][2]};
+          mat_vec(c1, S.gmat[g1], bc1);
+          for (int i = 0; i < 3; i++) c1[i] += S.gpos[g1][i];
+          keep = !obb_separated(c1, S.gmat[g1], h1, c2, S.gmat[g2], h2, 1e-4f);
+        }
+      } else {
+        float nrm[3] = {S.gmat[g1][2], S.gmat[g1][5], S.gmat[g1][8]};
+        keep = !(T.g_rbound[g2] > 0) || dot3(df, nrm) <= T.g_rbound[g2];
+        if (keep) {   // lowest point of the bounding box above the plane: no contact possible
+          const float *M2 = S.gmat[g2];
+          float dc[3] = {c2[0] - S.gpos[g1][0], c2[1] - S.gpos[g1][1], c2[2] - S.gpos[g1][2]}, ext = 0;
+          for (int j = 0; j < 3; j++) ext += fabsf(nrm[0] * M2[j] + nrm[1] * M2[3 + j] + nrm[2] * M2[6 + j]) * h2[j];
+          keep = dot3(dc, nrm) - ext <= 1e-4f;
+        }
+      }
+    }
+    const unsigned long long m = __ballot(keep);
+    const int slot = nsurv + __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+    if (keep) { if (slot < MAXSURV) S.surv[slot] = (int16_t)p; }
+    nsurv += __popcll(m);
+  }
+  if (nsurv > MAXSURV) { overflow = 1; nsurv = MAXSURV; }
+  SYNC();
+  int ncon = 0;
+  for (int s = 0; s < nsurv; s++) {
+    const int p = S.surv[s];
+    const int g1 = T.p_g1[p], g2 = T.p_g2[p];
+    Geo A, B;
+    load_geo(T, S, P, g1, A);
+    load_geo(T, S, P, g2, B);
+    Con rc[8];
+    int n = 0;
+    const int t1 = A.type, t2 = B.type;
+    if (t1 == DM_GEOM_PLANE) {
+      if (t2 == DM_GEOM_SPHERE) n = np_plane_sphere(rc, A, B.pos, B.size[0]);
+      else if (t2 == DM_GEOM_CYLINDER) n = np_plane_cylinder(rc, A, B);
+      else if (t2 == DM_GEOM_BOX) n = np_plane_box(rc, A, B);
+      else if (t2 == DM_GEOM_MESH) n = np_plane_mesh(rc, A, B, lane);
+    } else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_SPHERE) n = np_sphere_sphere(rc, A.pos, A.size[0], B.pos, B.size[0]);
+    else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_BOX) n = np_sphere_box(rc, A, B);
+    else if (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX) n = np_box_box(rc, A, B);
+    else n = np_convex(rc, A, B, lane);
+    for (int k = 0; k < n; k++) {
+      if (ncon >= MAXCON) { overflow = 1; continue; }
+      if (lane == 0) {
+        S.c_dist[ncon] = (float)rc[k].dist;
+        float fr[9] = {(float)rc[k].n[0], (float)rc[k].n[1], (float)rc[k].n[2], 0, 0, 0, 0, 0, 0};
+        make_frame(fr);
+        for (int i = 0; i < 3; i++) S.c_pos[ncon][i] = (float)rc[k].pos[i];
+        for (int i = 0; i < 9; i++) S.c_frame[ncon][i] = fr[i];
+        S.c_g1[ncon] = g1; S.c_g2[ncon] = g2;
+        S.c_mu[ncon] = fmaxf(T.g_mu[g1], T.g_mu[g2]);
+      }
+      ncon++;
+    }
+  }
+  SYNC();
+  if (lane == 0) { S.info[0] = ncon; S.info[4] = overflow; S.info[5] = nsurv; }
+  return ncon;
+}
+
+// ------------------------------------------------------------------------------------------ constraints
+__device__ __forceinline__ float impedance(const float *solimp, float pos, float margin) {   // [EXT] getimpedance
+  const float dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
+  if (dmin == dmax || width <= MINVALF) return 0.5f * (dmin + dmax);
+  const float x = fabsf(pos - margin) / width;
+  if (x >= 1) return dmax;
+  if (x <= 0) return dmin;
+  float y;
+  if (power == 1) y = x;
+  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1);
+  else y = 1 - powf(1 - x, power) / powf(1 - mid, power - 1);
+  return dmin + y * (dmax - dmin);
+}
+
+// rows -> J^T (global, dof-major), R, aref; returns nefc.  Order: friction loss (dof order), limits (joint order), contacts.
+__device__ int make_constraint(const Dev &T, Lds &S, float *JT, const int ncon, const int lane) {
+  // friction-loss rows: dofs 6..42 -> rows 0..36
+  int nefc = 0;
+  for (int k = 6; k < NV; k++) {   // (all hinges of this model carry friction loss; the table says which)
+    if (T.d_floss[k] > 0) nefc++;
+  }
+  const int nfric = nefc;
+  if (lane < NV - 6) {
+    const int k = 6 + lane;
+    // row index = number of friction dofs before k
+    int r = 0;
+    for (int q = 6; q < k; q++) r += T.d_floss[q] > 0;
+    if (T.d_floss[k] > 0) {
+      S.e_meta[r] = ROW_FRICTION | (k << 2);
+      S.e_lim[r] = T.d_floss[k];
+      const float imp = impedance(T.solimp, 0.f, 0.f);
+      S.e_R[r] = fmaxf(MINVALF, (1 - imp) * T.d_invw[k] / imp);
+      S.e_b[r] = -T.B * S.qvel[k];   // aref (K = 0 for friction rows)
+    }
+  }
+  // joint limits
+  bool lo = false, hi = false;
+  float dlo = 0, dhi = 0;
+  if (lane < NV - 6) {
+    const int k = 6 + lane;
+    const float q = S.qpos[k + 1];
+    dlo = q - T.d_lo[k]; dhi = T.d_hi[k] - q;
+    lo = dlo < 0; hi = dhi < 0;
+  }
+  {
+    const unsigned long long mlo = __ballot(lo), mhi = __ballot(hi);
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int before = __popcll(mlo & lt) + __popcll(mhi & lt);
+    if (lo || hi) {
+      const int k = 6 + lane;
+      int r = nefc + before;
+      for (int side = 0; side < 2; side++) {
+        if (!(side ? hi : lo)) continue;
+        if (r < MAXROW) {
+          const float dist = side ? dhi : dlo;
+          S.e_meta[r] = ROW_LIMIT | (k << 2) | (side << 12);
+          S.e_lim[r] = 0;
+          const float imp = impedance(T.solimp, dist, 0.f);
+          S.e_R[r] = fmaxf(MINVALF, (1 - imp) * T.d_invw[k] / imp);
+          const float jv = side ? -1.f : 1.f;
+          S.e_b[r] = -T.B * (jv * S.qvel[k]) - T.K * imp * dist;
+        }
+        r++;
+      }
+    }
+    nefc += __popcll(mlo) + __popcll(mhi);
+  }
+  const int nlimit = nefc - nfric;
+  // contacts: 4 pyramid rows each
+  const int row0 = nefc;
+  int kept = ncon;
+  if (row0 + 4 * ncon > MAXROW) kept = (MAXROW - row0) / 4;
+  nefc = row0 + 4 * kept;
+  SYNC();
+  // zero J^T for all rows, then fill
+  for (int k = 0; k < NV; k++)
+    for (int r = lane; r < nefc; r += 64) JT[k * MAXROW + r] = 0.f;
+  SYNC();
+  for (int r = lane; r < row0; r += 64) {
+    const int meta = S.e_meta[r], k = (meta >> 2) & 0x3FF, type = meta & 3;
+    JT[k * MAXROW + r] = (type == ROW_FRICTION) ? 1.f : (((meta >> 12) & 1) ? -1.f : 1.f);
+  }
+  for (int c = 0; c < kept; c++) {
+    const int b1 = T.g_body[S.c_g1[c]], b2 = T.g_body[S.c_g2[c]];
+    const float mu = S.c_mu[c];
+    const int r0 = row0 + 4 * c;
+    if (lane < NV) {
+      const int k = lane;
+      const bool in1 = (T.b_chain[b1] >> k) & 1, in2 = (T.b_chain[b2] >> k) & 1;
+      float j[3] = {0, 0, 0};
+      if (in1 != in2) {
+        float off[3] = {S.c_pos[c][0] - S.com[0], S.c_pos[c][1] - S.com[1], S.c_pos[c][2] - S.com[2]}, t[3];
+        cross3(t, S.cdof[k], off);
+        for (int i = 0; i < 3; i++) j[i] = (in2 ? 1.f : -1.f) * (S.cdof[k][3 + i] + t[i]);
+      }
+      const float *fr = S.c_frame[c];
+      const float j0 = fr[0] * j[0] + fr[1] * j[1] + fr[2] * j[2], j1 = fr[3] * j[0] + fr[4] * j[1] + fr[5] * j[2],
+                  j2 = fr[6] * j[0] + fr[7] * j[1] + fr[8] * j[2];
+      JT[k * MAXROW + r0] = j0 + mu * j1; JT[k * MAXROW + r0 + 1] = j0 - mu * j1;
+      JT[k * MAXROW + r0 + 2] = j0 + mu * j2; JT[k * MAXROW + r0 + 3] = j0 - mu * j2;
+    }
+    if (lane == 0) {
+      const float tran = T.b_invw[b1] + T.b_invw[b2], diag = tran + mu * mu * tran;
+      const float imp = impedance(T.solimp, S.c_dist[c], 0.f);
+      const float R0 = fmaxf(MINVALF, (1 - imp) * diag / imp), Rpy = 2.f * mu * mu * R0;
+      for (int e = 0; e < 4; e++) {
+        S.e_meta[r0 + e] = ROW_CONTACT | (c << 2);
+        S.e_lim[r0 + e] = 0;
+        S.e_R[r0 + e] = Rpy;
+        S.e_f[r0 + e] = imp;   // parked: aref needs the row velocity, computed below
+      }
+    }
+  }
+  SYNC();
+  // contact rows: vel = J qvel, aref = -B vel - K imp dist
+  for (int r = row0 + lane; r < nefc; r += 64) {
+    float vel = 0;
+    for (int k = 0; k < NV; k++) vel += JT[k * MAXROW + r] * S.qvel[k];
+    const int c = (S.e_meta[r] >> 2);
+    S.e_b[r] = -T.B * vel - T.K * S.e_f[r] * S.c_dist[c];
+  }
+  if (lane == 0) { S.info[1] = nefc; S.info[2] = nlimit; if (kept < ncon) S.info[4] = 1; }
+  SYNC();
+  return nefc;
+}
+
+// A = J M^-1 J^T + R in the per-env scratch; B^T = D^-1/2 L^-T J^T (dof-major)
+__device__ void project_constraint(const Dev &T, Lds &S, const float *JT, float *BT, float *AR, const int nefc, const int lane) {
+  for (int r = lane; r < nefc; r += 64) {   // each lane solves its own row: x <- D^-1/2 L^-T x
+    for (int k = 0; k < NV; k++) BT[k * MAXROW + r] = JT[k * MAXROW + r];
+    for (int i = NV - 1; i >= 0; i--) {
+      const float xi = BT[i * MAXROW + r];
+      if (xi != 0.f) {
+        const int n = T.d_nanc[i], a0 = T.d_madr[i] + 1;
+        for (int a = 0; a < n; a++) BT[T.d_anc[i][a] * MAXROW + r] -= S.qLD[a0 + a] * xi;
+      }
+    }
+    for (int k = 0; k < NV; k++) BT[k * MAXROW + r] *= S.dsq[k];
+  }
+  SYNC();
+  for (int i = 0; i < nefc; i++)
+    for (int j = lane; j < nefc; j += 64) {
+      float s = 0;
+      for (int k = 0; k < NV; k++) s += BT[k * MAXROW + i] * BT[k * MAXROW + j];
+      if (i == j) s += S.e_R[i];
+      AR[i * MAXROW + j] = s;
+    }
+  SYNC();
+}
+
+// [EXT] mj_fwdConstraint + mj_solPGS: dual PGS, rows unilateral (limits, pyramid edges) or boxed (friction loss)
+__device__ void fwd_constraint(const Dev &T, Lds &S, const float *JT, const float *AR, const int nefc, const int lane, const int max_iter) {
+  if (nefc == 0) {
+    if (lane < NV) { S.qacc[lane] = S.qas[lane]; S.warm[lane] = S.qas[lane]; S.qfc[lane] = 0; }
+    if (lane == 0) S.info[3] = 0;
+    SYNC();
+    return;
+  }
+  // b = J qacc_smooth - aref; warm-start forces from J qacc_warmstart - aref
+  for (int r = lane; r < nefc; r += 64) {
+    float s = 0, w = 0;
+    for (int k = 0; k < NV; k++) { const float j = JT[k * MAXROW + r]; s += j * S.qas[k]; w += j * S.warm[k]; }
+    const float aref = S.e_b[r], jar = w - aref, D = 1.f / S.e_R[r];
+    float f;
+    if ((S.e_meta[r] & 3) == ROW_FRICTION) {
+      const float fl = S.e_lim[r], rf = S.e_R[r] * fl;
+      f = jar <= -rf ? fl : (jar >= rf ? -fl : -D * jar);
+    } else f = jar < 0 ? -D * jar : 0.f;
+    S.e_b[r] = s - aref;
+    S.e_f[r] = f;
+  }
+  SYNC();
+  const int nr = (nefc + 63) >> 6;   // rows per lane (<= 4)
+  float res[4] = {0, 0, 0, 0}, fr[4] = {0, 0, 0, 0}, diag[4] = {1, 1, 1, 1};
+  float cost = 0;
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const int r = lane + 64 * m;
+    if (m < nr && r < nefc) {
+      float s = 0;
+      for (int c = 0; c < nefc; c++) s += AR[c * MAXROW + r] * S.e_f[c];
+      fr[m] = S.e_f[r];
+      cost += fr[m] * (0.5f * s + S.e_b[r]);
+      res[m] = S.e_b[r] + s;
+      diag[m] = AR[r * MAXROW + r];
+    }
+  }
+  cost = wsum(cost);
+  if (cost > 0) {
+#pragma unroll
+    for (int m = 0; m < 4; m++) { const int r = lane + 64 * m; if (m < nr && r < nefc) { fr[m] = 0; res[m] = S.e_b[r]; } }
+  }
+  int iter = 0;
+  while (iter < max_iter) {
+    float improvement = 0;
+    for (int i = 0; i < nefc; i++) {
+      const int m = i >> 6, src = i & 63;
+      float dl = 0;
+      if (lane == src) {
+        const float old = (m == 0) ? fr[0] : (m == 1) ? fr[1] : (m == 2) ? fr[2] : fr[3];
+        const float rs = (m == 0) ? res[0] : (m == 1) ? res[1] : (m == 2) ? res[2] : res[3];
+        const float aii = (m == 0) ? diag[0] : (m == 1) ? diag[1] : (m == 2) ? diag[2] : diag[3];
+        float f = old - rs / aii;
+        if ((S.e_meta[i] & 3) == ROW_FRICTION) { const float fl = S.e_lim[i]; f = fminf(fmaxf(f, -fl), fl); }
+        else if (f < 0) f = 0;
+        dl = f - old;
+        improvement -= 0.5f * dl * dl * aii + dl * rs;
+        if (m == 0) fr[0] = f; else if (m == 1) fr[1] = f; else if (m == 2) fr[2] = f; else fr[3] = f;
+      }
+      dl = __shfl(dl, src);
+      if (dl != 0.f) {
+        const float *row = AR + i * MAXROW;
+#pragma unroll
+        for (int mm = 0; mm < 4; mm++) {
+          const int r = lane + 64 * mm;
+          if (mm < nr && r < nefc) res[mm] += row[r] * dl;
+        }
+      }
+    }
+    iter++;
+    improvement = wsum(improvement);
+    if (improvement * T.pgs_scale < T.tolerance) break;
+  }
+#pragma unroll
+  for (int m = 0; m < 4; m++) { const int r = lane + 64 * m; if (m < nr && r < nefc) S.e_f[r] = fr[m]; }
+  SYNC();
+  // qfrc_constraint = J^T f
+  for (int k = 0; k < NV; k++) {
+    float s = 0;
+    for (int r = lane; r < nefc; r += 64) s += JT[k * MAXROW + r] * S.e_f[r];
+    s = wsum(s);
+    if (lane == 0) { S.qfc[k] = s; S.tmp[k] = s; }
+  }
+  SYNC();
+  solve_m(T, S, S.tmp, lane);
+  SYNC();
+  if (lane < NV) { const float a = S.tmp[lane] + S.qas[lane]; S.qacc[lane] = a; S.warm[lane] = a; }
+  if (lane == 0) S.info[3] = iter;
+  SYNC();
+}
+
+__device__ void forward(const Launch &P, const Dev &T, Lds &S, const int env, const int lane) {
+  float *JT = P.jt + (size_t)env * 44 * MAXROW, *BT = P.bt + (size_t)env * 44 * MAXROW, *AR = P.ar + (size_t)env * MAXROW * MAXROW;
+  kinematics(T, S, lane);
+  com_pos(T, S, lane);
+  crb_factor(T, S, lane);
+  int ncon = 0;
+  if (!(P.pad & 2)) ncon = collide(T, S, P, lane);
+  else { if (lane == 0) { S.info[0] = 0; S.info[4] = 0; } SYNC(); }
+  int nefc = 0;
+  if (!(P.pad & 8)) nefc = make_constraint(T, S, JT, ncon, lane);
+  else { if (lane == 0) { S.info[1] = 0; S.info[2] = 0; } SYNC(); }
+  if (!(P.pad & 4)) project_constraint(T, S, JT, BT, AR, nefc, lane);
+  fwd_smooth(T, S, lane);
+  if (P.pad & 16) nefc = 0;
+  fwd_constraint(T, S, JT, AR, nefc, lane, (P.pad & 1) ? 0 : T.iterations);
+}
+
+__device__ void integrate_pos(Lds &S, const float *q0, const float *vel, const float h, const int lane) {   // [EXT] mj_integratePos
+  if (lane == 0) {
+    for (int i = 0; i < 3; i++) S.qpos[i] = q0[i] + h * vel[i];
+    float w[3] = {vel[3], vel[4], vel[5]};
+    float n = sqrtf(dot3(w, w));
+    if (n < MINVALF) { w[0] = 1; w[1] = w[2] = 0; } else { w[0] /= n; w[1] /= n; w[2] /= n; }
+    const float ang = h * n;
+    float sn, cs;
+    sincosf(0.5f * ang, &sn, &cs);
+    float qr[4] = {cs, w[0] * sn, w[1] * sn, w[2] * sn}, qo[4] = {q0[3], q0[4], q0[5], q0[6]}, qn[4];
+    quat_normalize(qo);
+    quat_mul(qn, qo, qr);
+    quat_normalize(qn);
+    for (int i = 0; i < 4; i++) S.qpos[3 + i] = qn[i];
+  }
+  if (lane >= 6 && lane < NV) S.qpos[lane + 1] = q0[lane + 1] + h * vel[lane];
+}
+
+extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
+  __shared__ Lds S;
+  const int lane = threadIdx.x, env = blockIdx.x;
+  if (env >= P.N) return;
+  const Dev &T = *P.T;
+  const int mode = P.mode;
+  if (mode == MODE_RESET && P.mask && !P.mask[env]) return;
+  float *st = P.state + (size_t)env * STATE;
+  int *sti = (int *)st;
+  int idx_curr = sti[S_IDX], ep_len = sti[S_EPLEN], rcnt = sti[S_RCNT];
+  float ep_rew = st[S_EPREW];
+  if (lane < NQ) S.qpos[lane] = st[S_QPOS + lane];
+  if (lane < NV) { S.qvel[lane] = st[S_QVEL + lane]; S.warm[lane] = st[S_WARM + lane]; }
+  if (lane < NU) S.ctrl[lane] = st[S_CTRL + lane];
+  SYNC();
+  const ClipDev clip = P.clip;
+  if (mode == MODE_STEP) {
+    if (lane < NU) S.ctrl[lane] = (lane < NACT) ? P.actions[(size_t)env * NACT + lane] * T.action_scale : 0.f;   // :348-351
+  } else if (mode == MODE_FORCED || mode == MODE_SETSTATE) {
+    if (P.in_qpos) {
+      if (lane < NQ) S.qpos[lane] = P.in_qpos[(size_t)env * NQ + lane];
+      if (lane < NV) S.qvel[lane] = P.in_qvel[(size_t)env * NV + lane];
+    }
+    if (mode == MODE_SETSTATE && P.in_warm && lane < NV) S.warm[lane] = P.in_warm[(size_t)env * NV + lane];
+  } else if (mode == MODE_RESET) {
+    int fi = P.idx_init ? P.idx_init[env] : (int)(hash32(P.seed, env, rcnt, 0x5EED) % (uint32_t)clip.L);
+    fi = fi < 0 ? 0 : (fi >= clip.L ? clip.L - 1 : fi);
+    idx_curr = fi;
+    const float *rr = clip.reset + (size_t)fi * 88;
+    if (lane < NQ) S.qpos[lane] = rr[lane];
+    if (lane < NV) S.qvel[lane] = rr[44 + lane];
+    ep_len = 0; ep_rew = 0; rcnt++;
+  }
+  SYNC();
+  if (mode == MODE_SETSTATE && !P.run_forward) {
+    if (lane < NQ) st[S_QPOS + lane] = S.qpos[lane];
+    if (lane < NV) { st[S_QVEL + lane] = S.qvel[lane]; st[S_WARM + lane] = S.warm[lane]; }
+    return;
+  }
+
+  bool sim_err = false, done = false, after_reset = false;
+  int reason = 0;
+  unsigned stage_ncon = 0, stage_nefc_lo = 0;   // byte i = count at RK stage i (debug)
+  float reward = 0;
+  const float h = T.timestep;
+  if (mode == MODE_STEP || mode == MODE_FORCED) {   // mj_checkPos / mj_checkVel
+    const float a = (lane < NQ) ? S.qpos[lane] : 0.f, b = (lane < NV) ? S.qvel[lane] : 0.f;
+    sim_err = __any(!(fabsf(a) <= MAXVALF) || !(fabsf(b) <= MAXVALF));
+  }
+  for (;;) {
+    if (!sim_err) {
+      if (mode == MODE_STEP && !after_reset) {   // [EXT] mj_step with mj_RungeKutta(4)
+        const float A[3] = {0.5f, 0.5f, 1.f}, Bw[4] = {1.f / 6, 1.f / 3, 1.f / 3, 1.f / 6};
+        forward(P, T, S, env, lane);
+        stage_ncon = (unsigned)S.info[0] & 0xFF; stage_nefc_lo = (unsigned)S.info[1] & 0xFF;
+        {
+          const bool badv = (lane < NV) && !(fabsf(S.qacc[lane]) <= MAXVALF);   // mj_checkAcc
+          sim_err = __any(badv);
+        }
+        if (!sim_err) {
+          if (lane < NQ) S.x0q[lane] = S.qpos[lane];
+          if (lane < NV) { S.x0v[lane] = S.qvel[lane]; S.accq[lane] = Bw[0] * S.qvel[lane]; S.accv[lane] = Bw[0] * S.qacc[lane]; }
+          SYNC();
+          for (int i = 1; i < 4; i++) {
+            const float a = A[i - 1];
+            float dq = 0, dv = 0;
+            if (lane < NV) { dq = a * S.qvel[lane]; dv = a * S.qacc[lane]; }
+            SYNC();
+            if (lane < NV) S.tmp[lane] = dq;
+            SYNC();
+            integrate_pos(S, S.x0q, S.tmp, h, lane);
+            if (lane < NV) S.qvel[lane] = S.x0v[lane] + h * dv;
+            SYNC();
+            forward(P, T, S, env, lane);
+            stage_ncon |= ((unsigned)S.info[0] & 0xFF) << (8 * i); stage_nefc_lo |= ((unsigned)S.info[1] & 0xFF) << (8 * i);
+            if (lane < NV) { S.accq[lane] += Bw[i] * S.qvel[lane]; S.accv[lane] += Bw[i] * S.qacc[lane]; }
+            SYNC();
+          }
+          if (lane < NV) S.qvel[lane] = S.x0v[lane] + h * S.accv[lane];
+          integrate_pos(S, S.x0q, S.accq, h, lane);
+          SYNC();
+        }
+      } else {
+        forward(P, T, S, env, lane);
+        if (mode == MODE_FORCED && !after_reset) {
+          const bool badv = (lane < NV) && !(fabsf(S.qacc[lane]) <= MAXVALF);
+          sim_err = __any(badv);
+        }
+      }
+    }
+    // ---- task layer (derived arrays are those of the LAST forward evaluation)
+    const bool task_pass = !after_reset && (mode == MODE_STEP || mode == MODE_FORCED);
+    float obs_a = 0, obs_b = 0;   // obs[lane], obs[64 + lane]
+    float terms[5] = {0, 0, 0, 0, 0};
+    if (sim_err) {
+      reward = 0; done = true; reason = 5;
+      SYNC();
+      if (lane < NQ) S.qpos[lane] = T.qpos0[lane];
+      if (lane < NV) { S.qvel[lane] = 0; S.warm[lane] = 0; }
+      if (lane < NU) S.ctrl[lane] = 0;
+      SYNC();
+    } else {
+      const float Sc = P.vel_obs_scale;
+      const int tb = T.torso_body;
+      float rpy[3], tq[4] = {S.xquat[tb][0], S.xquat[tb][1], S.xquat[tb][2], S.xquat[tb][3]};
+      quat_to_rpy(tq, rpy);
+      const float *cv = S.cvel[tb];
+      float sy, cy;
+      sincosf(-rpy[2], &sy, &cy);
+      const float tor[8] = {rpy[0] * Sc, rpy[1] * Sc, (cy * cv[3] - sy * cv[4]) * Sc, (sy * cv[3] + cy * cv[4]) * Sc, cv[5] * Sc,
+                            cv[0] * Sc, cv[1] * Sc, cv[2] * Sc};
+      float rf = 0, lf = 0;
+      for (int c = 0; c < S.info[0]; c++) {
+        const int g1 = S.c_g1[c], g2 = S.c_g2[c];
+        const bool fl = g1 == T.floor_geom || g2 == T.floor_geom;
+        if ((g1 == T.rfoot_geom || g2 == T.rfoot_geom) && fl) rf = 1;
+        if ((g1 == T.lfoot_geom || g2 == T.lfoot_geom) && fl) lf = 1;
+      }
+      float ph = (float)idx_curr / (float)clip.L;
+      ph = fminf(fmaxf(ph, 0.f), 1.f);
+      auto obs_at = [&](int i) -> float {
+        if (i < 37) return S.qpos[7 + i];
+        if (i < 74) return S.qvel[6 + i - 37] * Sc;
+        if (i < 82) return tor[i - 74];
+        if (i == 82) return rf;
+        if (i == 83) return lf;
+        return ph;
+      };
+      obs_a = obs_at(lane);
+      if (lane < NOBS - 64) obs_b = obs_at(64 + lane);
+      if (task_pass) {
+        // ---- calc_imitation_reward, unitree_g1 branch (:193-256)
+        const float *cr = clip.rows + (size_t)idx_curr * CLIP_ROW;
+        float e_cfg = 0, e_vel = 0;
+        int viol = 0;
+        if (lane < NREW) {
+          const int qi = T.rew_q[lane], vi = T.rew_v[lane];
+          const float q = S.qpos[qi];
+          e_cfg = fabsf(q - cr[lane]);
+          e_vel = fabsf(cr[23 + lane] - S.qvel[vi]);
+          const int k = vi;
+          viol = (q <= T.d_lo[k] * 0.99f) + (q >= T.d_hi[k] * 0.99f);
+        }
+        e_cfg = wsum(e_cfg); e_vel = wsum(e_vel);
+        const float nviol = wsum((float)viol);
+        float rc[3], rt[3], cq[4] = {S.qpos[3], S.qpos[4], S.qpos[5], S.qpos[6]}, tqq[4] = {cr[46], cr[47], cr[48], cr[49]};
+        quat_to_rpy(cq, rc);
+        quat_to_rpy(tqq, rt);
+        e_cfg += fabsf(rc[1] - rt[1]);
+        float ee = 0;
+        for (int e = 0; e < 4; e++) {
+          const int g = T.ee_geom[e];
+          for (int i = 0; i < 3; i++) { const float df = S.gpos[g][i] - cr[50 + 3 * e + i]; ee += df * df; }
+        }
+        float cc[3];
+        for (int i = 0; i < 3; i++) cc[i] = wsum((lane < NB) ? T.b_mass[lane] * S.xpos[lane][i] : 0.f) * T.total_mass_inv;
+        const float *tc = clip.com + (size_t)idx_curr * 4;
+        float ce = 0;
+        for (int i = 0; i < 3; i++) { const float df = tc[i] - cc[i]; ce += df * df; }
+        terms[0] = expf(-e_cfg); terms[1] = expf(-0.1f * e_vel); terms[2] = expf(-40.f * ee); terms[3] = expf(-10.f * ce);
+        terms[4] = nviol / (float)NREW;
+        reward = 0.75f * terms[0] + 0.1f * terms[1] + 0.15f * terms[2] + 0.0f * terms[3] - 0.1f * terms[4];
+        // ---- termination (:418-442)
+        const float zc = wsum((lane < NB) ? T.b_mass[lane] * S.xipos[lane][2] : 0.f) * T.total_mass_inv;
+        if (!(clip.flags & 1)) {
+          done = (zc < T.low_z) || (zc > P.high_z);
+          reason = (zc < T.low_z) ? 1 : 2;
+        }
+        if (clip.flags & 4) {
+          const float mx = 60.f * 3.14159265358979f / 180.f;
+          if (fabsf(rc[0] - rt[0]) > mx || fabsf(rc[1] - rt[1]) > mx) { done = true; reason = 8; }
+        }
+        if (P.max_ep_length != 0 && ep_len >= P.max_ep_length) { done = true; reason = 3; }
+        if ((clip.flags & 2) && idx_curr + 1 == clip.L) { done = true; reason = 4; }
+        idx_curr = (idx_curr + 1) % clip.L;
+        ep_rew += reward;
+        ep_len += 1;
+        const bool ob = !(fabsf(obs_a) <= P.obs_bound) || !(fabsf(obs_b) <= P.obs_bound);
+        if (__any(ob)) {
+          obs_a = 0; obs_b = 0; reward = 0; done = true; reason = 6;
+          for (int i = 0; i < 5; i++) terms[i] = 0;
+        }
+      }
+    }
+    if (P.debug && !after_reset) {
+      float *dbg = P.debug + (size_t)env * DMG1_DEBUG_STRIDE;
+      for (int i = lane; i < NB * 3; i += 64) dbg[i] = (&S.xpos[0][0])[i];
+      if (lane < NV) { dbg[117 + lane] = S.qas[lane]; dbg[160 + lane] = S.qacc[lane]; }
+      if (lane == 0) { dbg[203] = S.info[0]; dbg[204] = S.info[1]; dbg[205] = S.info[3]; dbg[206] = S.info[2]; dbg[207] = S.info[4];
+                       for (int i = 0; i < 4; i++) { dbg[1000 + i] = (float)((stage_ncon >> (8 * i)) & 0xFF); dbg[1004 + i] = (float)((stage_nefc_lo >> (8 * i)) & 0xFF); } }
+      if (lane < MAXCON) {
+        float *o = dbg + 208 + 9 * lane;
+        const bool on = lane < S.info[0];
+        o[0] = on ? S.c_dist[lane] : 0.f; o[1] = on ? (float)S.c_g1[lane] : -1.f; o[2] = on ? (float)S.c_g2[lane] : -1.f;
+        for (int i = 0; i < 3; i++) { o[3 + i] = on ? S.c_pos[lane][i] : 0.f; o[6 + i] = on ? S.c_frame[lane][i] : 0.f; }
+      }
+      for (int r = lane; r < MAXROW; r += 64) dbg[640 + r] = (r < S.info[1]) ? S.e_f[r] : 0.f;
+    }
+    if (task_pass) {
+      if (P.rew && lane == 0) P.rew[env] = reward;
+      if (P.done && lane == 0) P.done[env] = done ? 1 : 0;
+      if (P.reason && lane == 0) P.reason[env] = reason;
+      if (P.terms && lane < 5) P.terms[(size_t)env * 5 + lane] = (lane == 0) ? terms[0] : (lane == 1) ? terms[1] : (lane == 2) ? terms[2]
+                                                                : (lane == 3) ? terms[3] : terms[4];
+      if (done && P.auto_reset && mode == MODE_STEP) {
+        if (P.terminal_obs) {
+          P.terminal_obs[(size_t)env * NOBS + lane] = obs_a;
+          if (lane < NOBS - 64) P.terminal_obs[(size_t)env * NOBS + 64 + lane] = obs_b;
+        }
+        const int fi = (int)(hash32(P.seed, env, rcnt, 0x5EED) % (uint32_t)clip.L);
+        idx_curr = fi;
+        rcnt++;
+        const float *rr = clip.reset + (size_t)fi * 88;
+        SYNC();
+        if (lane < NQ) S.qpos[lane] = rr[lane];
+        if (lane < NV) S.qvel[lane] = rr[44 + lane];
+        ep_len = 0; ep_rew = 0;
+        SYNC();
+        after_reset = true;
+        sim_err = false;
+        continue;   // one more forward evaluation at the reset state (set_state -> sim.forward)
+      }
+    }
+    if (P.obs) {
+      P.obs[(size_t)env * NOBS + lane] = obs_a;
+      if (lane < NOBS - 64) P.obs[(size_t)env * NOBS + 64 + lane] = obs_b;
+    }
+    break;
+  }
+  if (lane < NQ) st[S_QPOS + lane] = S.qpos[lane];
+  if (lane < NV) { st[S_QVEL + lane] = S.qvel[lane]; st[S_WARM + lane] = S.warm[lane]; }
+  if (lane < NU) st[S_CTRL + lane] = S.ctrl[lane];
+  if (lane == 0) { sti[S_IDX] = idx_curr; sti[S_EPLEN] = ep_len; st[S_EPREW] = ep_rew; sti[S_RCNT] = rcnt; }
+}
+
+extern "C" __global__ void g1_gather_kernel(const float *state, int N, int off, int n, int stride, float *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * n) return;
+  out[i] = state[(size_t)(i / n) * stride + off + i % n];
+}
+extern "C" __global__ void g1_scatter_int_kernel(float *state, int N, int off, int stride, const int32_t *in) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  ((int32_t *)state)[(size_t)i * stride + off] = in[i];
+}
+
+}  // namespace g1
+
+// ------------------------------------------------------------------------------------------ host side (C-ABI)
+struct DmG1Engine {
+  DmG1Config cfg;
+  int N = 0;
+  std::string err;
+  g1::Dev *dT = nullptr;
+  double *dMesh = nullptr, *dClus = nullptr;
+  int32_t *dOidx = nullptr;
+  float *dState = nullptr, *dJT = nullptr, *dBT = nullptr, *dAR = nullptr;
+  float *dRows = nullptr, *dReset = nullptr, *dCom = nullptr, *dDebug = nullptr;
+  int L = 0, flags = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+};
+
+static int g1_fail(DmG1Engine *e, int code, const char *msg) {
+  if (e) e->err = msg;
+  return code;
+}
+
+extern "C" void dmg1_default_config(DmG1Config *c) {
+  memset(c, 0, sizeof *c);
+  c->num_envs = 1; c->max_ep_length = 1000; c->vel_obs_scale = 0.1f; c->high_z = 2.0f; c->obs_bound = 100.0f;
+  c->seed = 0; c->auto_reset = 1; c->device = 0;
+}
+extern "C" size_t dmg1_model_sizeof(void) { return sizeof(DmModelG1); }
+
+static void g1_build_tables(const DmModelG1 &m, g1::Dev &T) {
+  using namespace g1;
+  memset(&T, 0, sizeof T);
+  T.timestep = (float)m.timestep; T.tolerance = (float)m.tolerance;
+  T.pgs_scale = (float)(1.0 / (m.meaninertia * (double)NV));
+  const double tc = fmax(m.solref[0], 2 * m.timestep), dr = m.solref[1], dmax = m.solimp[1];   // refsafe
+  T.K = (float)(1.0 / fmax(1e-15, dmax * dmax * tc * tc * dr * dr));
+  T.B = (float)(2.0 / fmax(1e-15, dmax * tc));
+  for (int i = 0; i < 5; i++) T.solimp[i] = (float)m.solimp[i];
+  for (int i = 0; i < 3; i++) T.gravity[i] = (float)m.gravity[i];
+  double mt = 0;
+  for (int b = 1; b < NB; b++) mt += m.body_mass[b];
+  T.total_mass_inv = (float)(1.0 / mt);
+  T.low_z = (float)m.low_z; T.action_scale = (float)m.action_scale;
+  T.iterations = m.iterations; T.npair = m.npair;
+  T.torso_body = m.torso_body; T.floor_geom = m.floor_geom; T.rfoot_geom = m.rfoot_geom; T.lfoot_geom = m.lfoot_geom;
+  for (int i = 0; i < 4; i++) T.ee_geom[i] = m.ee_geom[i];
+  for (int i = 0; i < NREW; i++) { T.rew_q[i] = m.rew_qposadr[i]; T.rew_v[i] = m.rew_dofadr[i]; T.rew_j[i] = m.rew_jnt[i]; }
+  for (int i = 0; i < NQ; i++) T.qpos0[i] = (float)m.qpos0[i];
+  int maxd = 0;
+  for (int b = 0; b < NB; b++) {
+    T.b_parent[b] = m.body_parent[b]; T.b_depth[b] = m.body_depth[b]; T.b_dof[b] = m.body_dofadr[b];
+    if (m.body_depth[b] > maxd) maxd = m.body_depth[b];
+    for (int i = 0; i < 3; i++) { T.b_pos[b][i] = (float)m.body_pos[b][i]; T.b_ipos[b][i] = (float)m.body_ipos[b][i]; }
+    for (int i = 0; i < 4; i++) T.b_quat[b][i] = (float)m.body_quat[b][i];
+    for (int i = 0; i < 6; i++) T.b_inertia[b][i] = (float)m.body_inertia[b][i];
+    T.b_mass[b] = (float)m.body_mass[b]; T.b_invw[b] = (float)m.body_invweight0[b][0];
+  }
+  T.maxdepth = maxd;
+  for (int b = 1; b < NB; b++)
+    for (int a = b; a > 0; a = m.body_parent[a]) T.b_desc[a] |= 1ull << b;
+  for (int k = 0; k < NV; k++) {
+    T.d_body[k] = m.dof_body[k]; T.d_madr[k] = m.dof_Madr[k]; T.d_act[k] = -1;
+    int n = 0;
+    for (int j = m.dof_parent[k]; j >= 0; j = m.dof_parent[j]) T.d_anc[k][n++] = (uint8_t)j;
+    T.d_nanc[k] = n;
+    const int j = m.dof_jnt[k];
+    for (int i = 0; i < 3; i++) T.d_axis[k][i] = (float)m.jnt_axis[j][i];
+    T.d_arm[k] = (float)m.dof_armature[k]; T.d_damp[k] = (float)m.dof_damping[k]; T.d_invw[k] = (float)m.dof_invweight0[k];
+    T.d_floss[k] = (float)m.dof_frictionloss[k];
+    T.d_lo[k] = (float)m.jnt_range[j][0]; T.d_hi[k] = (float)m.jnt_range[j][1];
+    if (!m.jnt_limited[j]) { T.d_lo[k] = -1e30f; T.d_hi[k] = 1e30f; }
+  }
+  for (int b = 1; b < NB; b++) {   // dofs that move body b: dofs of b and of its ancestors
+    for (int a = b; a > 0; a = m.body_parent[a])
+      for (int k = m.body_dofadr[a]; k < m.body_dofadr[a] + m.body_dofnum[a]; k++) T.b_chain[b] |= 1ull << k;
+  }
+  for (int a = 0; a < NU; a++) {
+    const int k = m.act_dof[a];
+    T.d_act[k] = a; T.d_clo[k] = (float)m.act_ctrlrange[a][0]; T.d_chi[k] = (float)m.act_ctrlrange[a][1];
+  }
+  for (int g = 0; g < NG; g++) {
+    T.g_body[g] = m.geom_body[g]; T.g_type[g] = m.geom_type[g]; T.g_mesh[g] = m.geom_mesh[g];
+    for (int i = 0; i < 3; i++) { T.g_pos[g][i] = (float)m.geom_pos[g][i]; T.g_size[g][i] = (float)m.geom_size[g][i]; }
+    const double *q = m.geom_quat[g];
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double M[9] = {w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y),
+                         2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x),
+                         2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z};
+    for (int i = 0; i < 9; i++) T.g_mat[g][i] = (float)M[i];
+    T.g_rbound[g] = (float)m.geom_rbound[g]; T.g_mu[g] = (float)m.geom_friction[g][0];
+    const double *zs = m.geom_size[g];
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    if (m.geom_type[g] == DM_GEOM_SPHERE) { for (int i = 0; i < 3; i++) { lo[i] = -zs[0]; hi[i] = zs[0]; } }
+    else if (m.geom_type[g] == DM_GEOM_CYLINDER) { lo[0] = lo[1] = -zs[0]; hi[0] = hi[1] = zs[0]; lo[2] = -zs[1]; hi[2] = zs[1]; }
+    else if (m.geom_type[g] == DM_GEOM_BOX) { for (int i = 0; i < 3; i++) { lo[i] = -zs[i]; hi[i] = zs[i]; } }
+    else if (m.geom_type[g] == DM_GEOM_MESH && m.geom_mesh[g] >= 0) {
+      const int me = m.geom_mesh[g];
+      for (int i = 0; i < 3; i++) { lo[i] = 1e30; hi[i] = -1e30; }
+      for (int v = m.mesh_vertadr[me]; v < m.mesh_vertadr[me] + m.mesh_vertnum[me]; v++)
+        for (int i = 0; i < 3; i++) { lo[i] = fmin(lo[i], m.mesh_vert[v][i]); hi[i] = fmax(hi[i], m.mesh_vert[v][i]); }
+    }
+    for (int i = 0; i < 3; i++) { T.g_bc[g][i] = (float)(0.5 * (lo[i] + hi[i])); T.g_bh[g][i] = (float)(0.5 * (hi[i] - lo[i]) * 1.00001 + 1e-6); }
+  }
+  for (int p = 0; p < m.npair; p++) { T.p_g1[p] = (int16_t)m.pair_geom1[p]; T.p_g2[p] = (int16_t)m.pair_geom2[p]; }
+  for (int i = 0; i < DM_NMESH; i++)
+    for (int k = 0; k < 3; k++) T.m_center[i][k] = m.mesh_center[i][k];   // vertex / cluster ranges: g1_build_meshes
+  int p = 0;
+  for (int b = 0; b < 15 && p < 128; b++)   // pairs (a <= c), c-major: index p -> (a, c)
+    for (int a = 0; a <= b && p < 128; a++) { T.tri_a[p] = (uint8_t)a; T.tri_b[p] = (uint8_t)b; p++; }
+}
+
+// Reorder every hull into clusters of 64 vertices that are close on the unit sphere of directions (latitude bands of equal
+// count, split by azimuth), with a bounding sphere per cluster; a mesh starts at a multiple of 64 so clusters never straddle.
+static void g1_build_meshes(const DmModelG1 &m, g1::Dev &T, std::vector<double> &verts, std::vector<int32_t> &oidx,
+                            std::vector<double> &clus) {
+  struct VS { double uz, az; int idx; };
+  int vadr = 0, cadr = 0;
+  for (int me = 0; me < DM_NMESH; me++) {
+    const int n = m.mesh_vertnum[me], a0 = m.mesh_vertadr[me];
+    T.m_vadr[me] = vadr; T.m_vnum[me] = n; T.m_cadr[me] = cadr; T.m_cnum[me] = (n + 63) / 64;
+    if (n == 0) continue;
+    std::vector<VS> vs(n);
+    for (int k = 0; k < n; k++) {
+      double u[3] = {m.mesh_vert[a0 + k][0] - m.mesh_center[me][0], m.mesh_vert[a0 + k][1] - m.mesh_center[me][1],
+                     m.mesh_vert[a0 + k][2] - m.mesh_center[me][2]};
+      const double nn = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+      vs[k] = {nn > 0 ? u[2] / nn : 0.0, atan2(u[1], u[0]), k};
+    }
+    std::sort(vs.begin(), vs.end(), [](const VS &a, const VS &b) { return a.uz < b.uz || (a.uz == b.uz && a.idx < b.idx); });
+    const int nclus = (n + 63) / 64;
+    int nb = (int)lround(sqrt((double)nclus));
+    if (nb < 1) nb = 1;
+    const int per_band = ((nclus + nb - 1) / nb) * 64;   // vertices per band, a multiple of 64
+    for (int b0 = 0; b0 < n; b0 += per_band) {
+      const int b1 = b0 + per_band < n ? b0 + per_band : n;
+      std::sort(vs.begin() + b0, vs.begin() + b1, [](const VS &a, const VS &b) { return a.az < b.az || (a.az == b.az && a.idx < b.idx); });
+    }
+    for (int k = 0; k < n; k++) {
+      for (int i = 0; i < 3; i++) verts.push_back(m.mesh_vert[a0 + vs[k].idx][i]);
+      oidx.push_back(vs[k].idx);
+    }
+    for (int c = 0; c < nclus; c++) {
+      const int k0 = 64 * c, k1 = k0 + 64 < n ? k0 + 64 : n;
+      double cc[3] = {0, 0, 0}, rad = 0;
+      for (int k = k0; k < k1; k++) for (int i = 0; i < 3; i++) cc[i] += verts[3 * (size_t)(vadr + k) + i];
+      for (int i = 0; i < 3; i++) cc[i] /= (k1 - k0);
+      for (int k = k0; k < k1; k++) {
+        double d2 = 0;
+        for (int i = 0; i < 3; i++) { const double df = verts[3 * (size_t)(vadr + k) + i] - cc[i]; d2 += df * df; }
+        rad = fmax(rad, sqrt(d2));
+      }
+      clus.push_back(cc[0]); clus.push_back(cc[1]); clus.push_back(cc[2]); clus.push_back(rad * (1 + 1e-9) + 1e-12);
+    }
+    const int padded = nclus * 64;   // next mesh starts on a cluster boundary
+    for (int k = n; k < padded; k++) { verts.push_back(0); verts.push_back(0); verts.push_back(0); oidx.push_back(0x7fffffff); }
+    vadr += padded; cadr += nclus;
+  }
+}
+
+static int g1_check_model(DmG1Engine *e, const DmModelG1 &m) {
+  using namespace g1;
+  if (m.nq != NQ || m.nv != NV || m.nu != NU || m.nbody != NB || m.ngeom != NG || m.njnt != NJ || m.nM != NM)
+    return g1_fail(e, DM_EINVAL, "model dimensions are not the Unitree G1's");
+  if (m.integrator != DM_INT_RK4) return g1_fail(e, DM_EINVAL, "the G1 engine integrates with RK4 (xml :7)");
+  if (m.npair < 0 || m.npair > 1024) return g1_fail(e, DM_EINVAL, "npair out of range");
+  if (m.jnt_type[0] != DM_JNT_FREE || m.jnt_body[0] != 1) return g1_fail(e, DM_EINVAL, "joint 0 must be the free root");
+  for (int b = 2; b < NB; b++)
+    if (m.body_jntnum[b] != 1 || m.body_dofadr[b] != b + 4 || m.body_jntadr[b] != b - 1 || m.body_depth[b] > 15)
+      return g1_fail(e, DM_EINVAL, "kernel assumes one hinge per body in body order");
+  for (int j = 0; j < NJ; j++)
+    for (int i = 0; i < 3; i++)
+      if (m.jnt_pos[j][i] != 0.0) return g1_fail(e, DM_EINVAL, "kernel assumes joint anchors at the body origin");
+  for (int k = 0; k < NV; k++) {
+    int n = 0;
+    for (int j = m.dof_parent[k]; j >= 0; j = m.dof_parent[j]) n++;
+    if (n > 14) return g1_fail(e, DM_EINVAL, "dof chain deeper than 14 ancestors");
+    if (k >= 6 && !(m.dof_frictionloss[k] > 0)) return g1_fail(e, DM_EINVAL, "kernel assumes friction loss on every hinge");
+  }
+  for (int a = 0; a < NU; a++)
+    if (m.act_gear[a] != 1.0) return g1_fail(e, DM_EINVAL, "kernel assumes motor gear 1");
+  for (int g = 0; g < NG; g++) {
+    if (m.geom_margin[g] != 0.0) return g1_fail(e, DM_EINVAL, "kernel assumes zero geom margins (xml has none)");
+    if (m.geom_mesh[g] >= DM_NMESH) return g1_fail(e, DM_EINVAL, "mesh id out of range");
+  }
+  return DM_OK;
+}
+
+extern "C" int dmg1_create(const void *model, size_t model_bytes, const DmG1Config *cfg, DmG1Handle *out) {
+  if (!model || !cfg || !out || cfg->num_envs < 1) return DM_EINVAL;
+  if (model_bytes != sizeof(DmModelG1)) { fprintf(stderr, "dmg1_create: model struct size %zu != %zu\n", model_bytes, sizeof(DmModelG1)); return DM_EINVAL; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DM_ENODEV;
+  const DmModelG1 &m = *(const DmModelG1 *)model;
+  DmG1Engine *e = new DmG1Engine();
+  e->cfg = *cfg;
+  e->N = cfg->num_envs;
+  int rc = g1_check_model(e, m);
+  if (rc != DM_OK) { fprintf(stderr, "dmg1_create: %s\n", e->err.c_str()); delete e; return rc; }
+  if (hipSetDevice(cfg->device) != hipSuccess) { delete e; return DM_ENODEV; }
+  g1::Dev *T = new g1::Dev();
+  g1_build_tables(m, *T);
+  std::vector<double> verts, clus;
+  std::vector<int32_t> oidx;
+  g1_build_meshes(m, *T, verts, oidx, clus);
+  for (int me = 0; me < DM_NMESH; me++)
+    if (T->m_cnum[me] > 128) { delete T; delete e; fprintf(stderr, "dmg1_create: a hull has more than 8192 vertices\n"); return DM_EINVAL; }
+  bool ok = hipMalloc(&e->dT, sizeof(g1::Dev)) == hipSuccess;
+  if (ok) hipMemcpy(e->dT, T, sizeof(g1::Dev), hipMemcpyHostToDevice);
+  delete T;
+  ok = ok && hipMalloc(&e->dMesh, verts.size() * sizeof(double)) == hipSuccess;
+  ok = ok && hipMalloc(&e->dOidx, oidx.size() * sizeof(int32_t)) == hipSuccess;
+  ok = ok && hipMalloc(&e->dClus, clus.size() * sizeof(double)) == hipSuccess;
+  if (ok) {
+    hipMemcpy(e->dMesh, verts.data(), verts.size() * sizeof(double), hipMemcpyHostToDevice);
+    hipMemcpy(e->dOidx, oidx.data(), oidx.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    hipMemcpy(e->dClus, clus.data(), clus.size() * sizeof(double), hipMemcpyHostToDevice);
+  }
+  const size_t N = (size_t)e->N;
+  ok = ok && hipMalloc(&e->dState, N * g1::STATE * sizeof(float)) == hipSuccess;
+  ok = ok && hipMalloc(&e->dJT, N * 44 * g1::MAXROW * sizeof(float)) == hipSuccess;
+  ok = ok && hipMalloc(&e->dBT, N * 44 * g1::MAXROW * sizeof(float)) == hipSuccess;
+  ok = ok && hipMalloc(&e->dAR, N * g1::MAXROW * g1::MAXROW * sizeof(float)) == hipSuccess;
+  if (!ok) { dmg1_destroy(e); return DM_ENOMEM; }
+  std::vector<float> init(N * g1::STATE, 0.f);
+  for (size_t i = 0; i < N; i++)
+    for (int k = 0; k < g1::NQ; k++) init[i * g1::STATE + g1::S_QPOS + k] = (float)m.qpos0[k];
+  hipMemcpy(e->dState, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice);
+  hipEventCreate(&e->ev0); hipEventCreate(&e->ev1);
+  *out = e;
+  return DM_OK;
+}
+
+extern "C" int dmg1_destroy(DmG1Handle e) {
+  if (!e) return DM_EINVAL;
+  hipFree(e->dT); hipFree(e->dMesh); hipFree(e->dOidx); hipFree(e->dClus); hipFree(e->dState); hipFree(e->dJT); hipFree(e->dBT); hipFree(e->dAR);
+  hipFree(e->dRows); hipFree(e->dReset); hipFree(e->dCom);
+  if (e->ev0) hipEventDestroy(e->ev0);
+  if (e->ev1) hipEventDestroy(e->ev1);
+  delete e;
+  return DM_OK;
+}
+extern "C" const char *dmg1_last_error(DmG1Handle e) { return e ? e->err.c_str() : "null handle"; }
+
+extern "C" int dmg1_load_clip(DmG1Handle e, int L, const double *q, const double *v, const double *bx, const double *gx, int flags) {
+  using namespace g1;
+  if (!e || L < 1 || !q || !v || !bx || !gx) return DM_EINVAL;
+  g1::Dev *T = new g1::Dev();
+  hipMemcpy(T, e->dT, sizeof(g1::Dev), hipMemcpyDeviceToHost);
+  std::vector<float> rows((size_t)L * CLIP_ROW, 0.f), reset((size_t)L * 88, 0.f), com((size_t)L * 4, 0.f);
+  double mt = 0;
+  for (int b = 0; b < NB; b++) mt += T->b_mass[b];
+  for (int f = 0; f < L; f++) {
+    float *r = &rows[(size_t)f * CLIP_ROW];
+    for (int i = 0; i < NREW; i++) { r[i] = (float)q[(size_t)f * NQ + T->rew_q[i]]; r[23 + i] = (float)v[(size_t)f * NV + T->rew_v[i]]; }
+    for (int i = 0; i < 4; i++) r[46 + i] = (float)q[(size_t)f * NQ + 3 + i];
+    for (int e4 = 0; e4 < 4; e4++)
+      for (int i = 0; i < 3; i++) r[50 + 3 * e4 + i] = (float)gx[((size_t)f * NG + T->ee_geom[e4]) * 3 + i];
+    for (int i = 0; i < NQ; i++) reset[(size_t)f * 88 + i] = (float)q[(size_t)f * NQ + i];
+    for (int i = 0; i < NV; i++) reset[(size_t)f * 88 + 44 + i] = (float)v[(size_t)f * NV + i];
+    for (int i = 0; i < 3; i++) {
+      double s = 0;
+      for (int b = 0; b < NB; b++) s += (double)T->b_mass[b] * bx[((size_t)f * NB + b) * 3 + i];
+      com[(size_t)f * 4 + i] = (float)(s / mt);
+    }
+  }
+  delete T;
+  hipFree(e->dRows); hipFree(e->dReset); hipFree(e->dCom);
+  e->dRows = e->dReset = e->dCom = nullptr;
+  if (hipMalloc(&e->dRows, rows.size() * 4) != hipSuccess || hipMalloc(&e->dReset, reset.size() * 4) != hipSuccess ||
+      hipMalloc(&e->dCom, com.size() * 4) != hipSuccess)
+    return g1_fail(e, DM_ENOMEM, "clip tables");
+  hipMemcpy(e->dRows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(e->dReset, reset.data(), reset.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(e->dCom, com.data(), com.size() * 4, hipMemcpyHostToDevice);
+  e->L = L; e->flags = flags;
+  return DM_OK;
+}
+
+static int g1_launch(DmG1Engine *e, g1::Launch &P, void *stream, bool time_it) {
+  P.T = e->dT; P.mesh_vert = e->dMesh; P.mesh_oidx = e->dOidx; P.mesh_clus = e->dClus; P.state = e->dState; P.jt = e->dJT; P.bt = e->dBT; P.ar = e->dAR;
+  P.clip.rows = e->dRows; P.clip.reset = e->dReset; P.clip.com = e->dCom; P.clip.L = e->L; P.clip.flags = e->flags;
+  P.N = e->N; P.auto_reset = e->cfg.auto_reset; P.max_ep_length = e->cfg.max_ep_length;
+  P.vel_obs_scale = e->cfg.vel_obs_scale; P.high_z = e->cfg.high_z; P.obs_bound = e->cfg.obs_bound; P.seed = e->cfg.seed;
+  P.debug = e->dDebug;
+  if (const char *sk = getenv("DMG1_SKIP")) P.pad = atoi(sk);   // profiling aid: bit 0 no PGS sweeps, 1 no collision, 2 no A matrix, 3 no rows, 4 no constraint solve
+  hipStream_t s = (hipStream_t)stream;
+  if (time_it) hipEventRecord(e->ev0, s);
+  hipLaunchKernelGGL(g1::g1_step_kernel, dim3(e->N), dim3(64), 0, s, P);
+  if (time_it) { hipEventRecord(e->ev1, s); e->timed = true; }
+  return hipGetLastError() == hipSuccess ? DM_OK : g1_fail(e, DM_EHIP, "kernel launch failed");
+}
+
+extern "C" int dmg1_reset(DmG1Handle e, const uint8_t *mask, const int32_t *idx_init, float *obs_out, void *stream) {
+  if (!e || !e->L) return e ? g1_fail(e, DM_EINVAL, "no clip loaded") : DM_EINVAL;
+  g1::Launch P;
+  memset(&P, 0, sizeof P);
+  P.mode = g1::MODE_RESET; P.mask = mask; P.idx_init = idx_init; P.obs = obs_out;
+  return g1_launch(e, P, stream, false);
+}
+extern "C" int dmg1_step(DmG1Handle e, const float *actions, float *obs, float *rew, uint8_t *done, float *terms, int32_t *reason,
+                         float *terminal_obs, void *stream) {
+  if (!e || !actions) return DM_EINVAL;
+  if (!e->L) return g1_fail(e, DM_EINVAL, "no clip loaded");
+  g1::Launch P;
+  memset(&P, 0, sizeof P);
+  P.mode = g1::MODE_STEP; P.actions = actions; P.obs = obs; P.rew = rew; P.done = done; P.terms = terms; P.reason = reason;
+  P.terminal_obs = terminal_obs;
+  return g1_launch(e, P, stream, true);
+}
+extern "C" int dmg1_step_forced(DmG1Handle e, const float *qpos, const float *qvel, float *obs, float *rew, uint8_t *done,
+                                float *terms, int32_t *reason, void *stream) {
+  if (!e || !qpos || !qvel) return DM_EINVAL;
+  if (!e->L) return g1_fail(e, DM_EINVAL, "no clip loaded");
+  g1::Launch P;
+  memset(&P, 0, sizeof P);
+  P.mode = g1::MODE_FORCED; P.in_qpos = qpos; P.in_qvel = qvel; P.obs = obs; P.rew = rew; P.done = done; P.terms = terms; P.reason = reason;
+  return g1_launch(e, P, stream, false);
+}
+extern "C" int dmg1_set_state(DmG1Handle e, const float *qpos, const float *qvel, const float *warm, int run_forward, void *stream) {
+  if (!e || !qpos || !qvel) return DM_EINVAL;
+  g1::Launch P;
+  memset(&P, 0, sizeof P);
+  P.mode = g1::MODE_SETSTATE; P.in_qpos = qpos; P.in_qvel = qvel; P.in_warm = warm; P.run_forward = run_forward;
+  return g1_launch(e, P, stream, false);
+}
+static void g1_gather(DmG1Engine *e, int off, int n, float *out, void *stream) {
+  const int tot = e->N * n;
+  hipLaunchKernelGGL(g1::g1_gather_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->dState, e->N, off, n, g1::STATE, out);
+}
+extern "C" int dmg1_get_state(DmG1Handle e, float *qpos, float *qvel, float *warm, void *stream) {
+  if (!e) return DM_EINVAL;
+  if (qpos) g1_gather(e, g1::S_QPOS, g1::NQ, qpos, stream);
+  if (qvel) g1_gather(e, g1::S_QVEL, g1::NV, qvel, stream);
+  if (warm) g1_gather(e, g1::S_WARM, g1::NV, warm, stream);
+  return DM_OK;
+}
+extern "C" int dmg1_get_counters(DmG1Handle e, int32_t *idx, int32_t *eplen, float *eprew, void *stream) {
+  if (!e) return DM_EINVAL;
+  if (idx) g1_gather(e, g1::S_IDX, 1, (float *)idx, stream);
+  if (eplen) g1_gather(e, g1::S_EPLEN, 1, (float *)eplen, stream);
+  if (eprew) g1_gather(e, g1::S_EPREW, 1, eprew, stream);
+  return DM_OK;
+}
+extern "C" int dmg1_set_counters(DmG1Handle e, const int32_t *idx, const int32_t *eplen, void *stream) {
+  if (!e) return DM_EINVAL;
+  const int nb = (e->N + 255) / 256;
+  if (idx) hipLaunchKernelGGL(g1::g1_scatter_int_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, e->dState, e->N, g1::S_IDX, g1::STATE, idx);
+  if (eplen) hipLaunchKernelGGL(g1::g1_scatter_int_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, e->dState, e->N, g1::S_EPLEN, g1::STATE, eplen);
+  return DM_OK;
+}
+extern "C" int dmg1_set_debug(DmG1Handle e, float *debug) {
+  if (!e) return DM_EINVAL;
+  e->dDebug = debug;
+  return DM_OK;
+}
+extern "C" float dmg1_last_kernel_ms(DmG1Handle e) {
+  if (!e || !e->timed) return -1.f;
+  float ms = -1.f;
+  if (hipEventSynchronize(e->ev1) != hipSuccess) return -1.f;
+  if (hipEventElapsedTime(&ms, e->ev0, e->ev1) != hipSuccess) return -1.f;
+  return ms;
+}

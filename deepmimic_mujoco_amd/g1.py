@@ -1,0 +1,268 @@
+"""Unitree G1 engine — ctypes binding of the dmg1_* entry points of libdeepmimic_hip.so (include/deepmimic_g1_hip.h).
+
+Second robot of the reference: ``DPEnv(robot="unitree_g1")`` (src/deepmimic_env.py:272-484 with the unitree_g1 branches,
+model ``deepmimic_unitree_g1.xml``).  The model is compiled by :mod:`mjcf` (general MJCF compiler + hull asset) into
+``struct DmModel`` at the G1 dimensions (include/dm_model.h under ``-DDM_ROBOT_G1``), mirrored here as :class:`DmModelG1`.
+No CPU fallback: :class:`G1HipEngine` raises if the HIP library or a GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import mjcf, model as _model
+from .config import RobotConfig
+
+NQ, NV, NU, NBODY, NGEOM, NJNT, NM, MAXPAIR, NOBS = 44, 43, 37, 39, 94, 38, 434, 1024, 85
+NACT, NMESH, NMESHVERT, NREWJ, NEE = 23, 32, 40000, 23, 4
+MAXCON, MAXROW, DEBUG_STRIDE = 48, 256, 1024
+# [mjmodel.get_joint_qpos_addr(n) ...] minus root and hand joints (src/deepmimic_env.py:206-207)
+REW_QPOS = [7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 32, 33, 34, 35, 36]
+REW_QVEL = [6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 31, 32, 33, 34, 35]
+CLIP_FLOOR, CLIP_ACYCLIC, CLIP_RUN_RULE = 1, 2, 4
+REASONS = {0: None, 1: "low_z", 2: "high_z", 3: "max_ep_len", 4: "acyclical_end", 5: "sim_error", 6: "obs_out_of_bounds",
+           8: "run roll/pitch limit"}
+EXPORTS = ["dmg1_default_config", "dmg1_model_sizeof", "dmg1_create", "dmg1_destroy", "dmg1_last_error", "dmg1_load_clip",
+           "dmg1_reset", "dmg1_step", "dmg1_step_forced", "dmg1_set_state", "dmg1_get_state", "dmg1_get_counters",
+           "dmg1_set_counters", "dmg1_set_debug", "dmg1_last_kernel_ms"]
+
+_i32, _f64 = C.c_int32, C.c_double
+
+
+class DmModelG1(C.Structure):
+    """ctypes mirror of ``struct DmModel`` under -DDM_ROBOT_G1 (include/dm_model.h) — keep in sync (size is checked)."""
+
+    _fields_ = [
+        ("nq", _i32), ("nv", _i32), ("nu", _i32), ("nbody", _i32), ("ngeom", _i32), ("njnt", _i32), ("npair", _i32),
+        ("nM", _i32), ("integrator", _i32), ("iterations", _i32), ("pad0", _i32), ("pad1", _i32),
+        ("timestep", _f64), ("tolerance", _f64), ("gravity", _f64 * 3), ("meaninertia", _f64), ("solref", _f64 * 2),
+        ("solimp", _f64 * 5), ("qpos0", _f64 * NQ),
+        ("body_parent", _i32 * NBODY), ("body_jntadr", _i32 * NBODY), ("body_jntnum", _i32 * NBODY),
+        ("body_dofadr", _i32 * NBODY), ("body_dofnum", _i32 * NBODY), ("body_depth", _i32 * NBODY),
+        ("body_pos", _f64 * 3 * NBODY), ("body_quat", _f64 * 4 * NBODY), ("body_ipos", _f64 * 3 * NBODY),
+        ("body_inertia", _f64 * 6 * NBODY), ("body_mass", _f64 * NBODY), ("body_invweight0", _f64 * 2 * NBODY),
+        ("jnt_type", _i32 * NJNT), ("jnt_body", _i32 * NJNT), ("jnt_qposadr", _i32 * NJNT), ("jnt_dofadr", _i32 * NJNT),
+        ("jnt_limited", _i32 * NJNT), ("jnt_pos", _f64 * 3 * NJNT), ("jnt_axis", _f64 * 3 * NJNT),
+        ("jnt_range", _f64 * 2 * NJNT),
+        ("dof_body", _i32 * NV), ("dof_jnt", _i32 * NV), ("dof_parent", _i32 * NV), ("dof_Madr", _i32 * NV),
+        ("dof_armature", _f64 * NV), ("dof_damping", _f64 * NV), ("dof_invweight0", _f64 * NV),
+        ("geom_type", _i32 * NGEOM), ("geom_body", _i32 * NGEOM), ("geom_condim", _i32 * NGEOM),
+        ("geom_pos", _f64 * 3 * NGEOM), ("geom_quat", _f64 * 4 * NGEOM), ("geom_size", _f64 * 3 * NGEOM),
+        ("geom_friction", _f64 * 3 * NGEOM), ("geom_margin", _f64 * NGEOM), ("geom_rbound", _f64 * NGEOM),
+        ("act_dof", _i32 * NU), ("act_gear", _f64 * NU), ("act_ctrlrange", _f64 * 2 * NU),
+        ("pair_geom1", _i32 * MAXPAIR), ("pair_geom2", _i32 * MAXPAIR),
+        ("ee_geom", _i32 * NEE), ("torso_body", _i32), ("rfoot_geom", _i32), ("lfoot_geom", _i32), ("floor_geom", _i32),
+        # trailing G1 fields
+        ("dof_frictionloss", _f64 * NV), ("geom_mesh", _i32 * NGEOM), ("mesh_vertadr", _i32 * NMESH),
+        ("mesh_vertnum", _i32 * NMESH), ("mesh_center", _f64 * 3 * NMESH), ("mesh_vert", _f64 * 3 * NMESHVERT),
+        ("nconmax", _i32), ("n_policy_action", _i32), ("action_scale", _f64), ("low_z", _f64),
+        ("rew_qposadr", _i32 * NREWJ), ("rew_dofadr", _i32 * NREWJ), ("rew_jnt", _i32 * NREWJ), ("extra_geom", _i32 * 8),
+    ]
+
+
+def to_cstruct(g) -> DmModelG1:
+    """GModel (mjcf.compile_mjcf_general of the G1 asset, with hulls) -> DmModelG1."""
+    rc = RobotConfig("unitree_g1")
+    assert (g.nq, g.nv, g.nu, g.nbody, g.ngeom, g.njnt, g.nM) == (NQ, NV, NU, NBODY, NGEOM, NJNT, NM)
+    if g.solver != "PGS" or g.npair > MAXPAIR:
+        raise ValueError("unsupported G1 model options")
+    s = DmModelG1()
+    s.nq, s.nv, s.nu, s.nbody, s.ngeom, s.njnt, s.npair, s.nM = NQ, NV, NU, NBODY, NGEOM, NJNT, g.npair, NM
+    s.integrator = {"Euler": 0, "RK4": 1}[g.integrator]
+    s.iterations, s.timestep, s.tolerance, s.meaninertia = g.iterations, g.timestep, g.tolerance, g.meaninertia
+
+    def put(name, arr):
+        dst = np.ctypeslib.as_array(getattr(s, name))
+        dst[...] = np.ascontiguousarray(arr).reshape(dst.shape)
+
+    for name in ["gravity", "solref", "solimp", "qpos0", "body_parent", "body_jntadr", "body_jntnum", "body_dofadr",
+                 "body_dofnum", "body_depth", "body_pos", "body_quat", "body_ipos", "body_inertia", "body_mass",
+                 "body_invweight0", "jnt_type", "jnt_body", "jnt_qposadr", "jnt_dofadr", "jnt_limited", "jnt_pos",
+                 "jnt_axis", "jnt_range", "dof_body", "dof_jnt", "dof_parent", "dof_Madr", "dof_armature", "dof_damping",
+                 "dof_invweight0", "geom_type", "geom_body", "geom_condim", "geom_pos", "geom_quat", "geom_size",
+                 "geom_friction", "geom_margin", "geom_rbound", "act_dof", "act_gear", "act_ctrlrange", "dof_frictionloss"]:
+        put(name, getattr(g, name))
+    p1, p2 = np.full(MAXPAIR, -1, np.int32), np.full(MAXPAIR, -1, np.int32)
+    p1[:g.npair], p2[:g.npair] = g.pairs[:, 0], g.pairs[:, 1]
+    put("pair_geom1", p1)
+    put("pair_geom2", p2)
+    put("ee_geom", [g.geom_id(n) for n in rc.endeffector_geom_names])
+    s.torso_body = g.body_id(rc.torso_body_name)
+    s.rfoot_geom, s.lfoot_geom, s.floor_geom = (g.geom_id(rc.rfoot_geom_name), g.geom_id(rc.lfoot_geom_name),
+                                                g.geom_id(rc.floor_geom_name))
+    put("geom_mesh", g.geom_meshid)
+    adr, num, verts = np.zeros(NMESH, np.int32), np.zeros(NMESH, np.int32), np.zeros((NMESHVERT, 3))
+    cen = np.zeros((NMESH, 3))
+    a = 0
+    if len(g.mesh_vert) > NMESH:
+        raise ValueError("too many meshes")
+    for i, v in enumerate(g.mesh_vert):
+        adr[i], num[i] = a, len(v)
+        verts[a:a + len(v)] = v
+        cen[i] = g.mesh_center[i]
+        a += len(v)
+    if a > NMESHVERT:
+        raise ValueError("too many hull vertices")
+    put("mesh_vertadr", adr)
+    put("mesh_vertnum", num)
+    put("mesh_vert", verts)
+    put("mesh_center", cen)
+    s.nconmax, s.n_policy_action, s.action_scale, s.low_z = g.nconmax, NU - 14, 20.0, rc.low_z
+    put("rew_qposadr", REW_QPOS)
+    put("rew_dofadr", REW_QVEL)
+    put("rew_jnt", np.array(REW_QPOS) - 7 + 1)
+    put("extra_geom", [g.geom_id(n) for n in rc.extra_contact_geom_names])
+    return s
+
+
+_MODEL = []
+
+
+def load_g1_model():
+    """(GModel, DmModelG1) of the packaged ``deepmimic_unitree_g1.xml`` + hull asset, cached."""
+    if not _MODEL:
+        hulls = mjcf.load_g1_hulls()
+        if hulls is None:
+            raise RuntimeError("assets/unitree_g1_hulls.npz is missing (scripts/make_g1_hulls.py writes it)")
+        g = mjcf.compile_mjcf_general(os.path.join(_model.ASSET_DIR, "deepmimic_unitree_g1.xml"), hulls=hulls)
+        _MODEL.append((g, to_cstruct(g)))
+    return _MODEL[0]
+
+
+class DmG1Config(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("max_ep_length", C.c_int32), ("vel_obs_scale", C.c_float), ("high_z", C.c_float),
+                ("obs_bound", C.c_float), ("seed", C.c_uint64), ("auto_reset", C.c_int32), ("device", C.c_int32)]
+
+
+_BOUND = []
+
+
+def _lib():
+    from ._lib import load_library
+    L = load_library()
+    if not _BOUND:
+        vp, i32 = C.c_void_p, C.c_int
+        L.dmg1_default_config.argtypes = [C.POINTER(DmG1Config)]
+        L.dmg1_default_config.restype = None
+        L.dmg1_model_sizeof.restype = C.c_size_t
+        L.dmg1_create.argtypes = [vp, C.c_size_t, C.POINTER(DmG1Config), C.POINTER(vp)]
+        L.dmg1_destroy.argtypes = [vp]
+        L.dmg1_last_error.argtypes = [vp]
+        L.dmg1_last_error.restype = C.c_char_p
+        L.dmg1_load_clip.argtypes = [vp, i32, vp, vp, vp, vp, i32]
+        L.dmg1_reset.argtypes = [vp] * 5
+        L.dmg1_step.argtypes = [vp] * 9
+        L.dmg1_step_forced.argtypes = [vp] * 9
+        L.dmg1_set_state.argtypes = [vp, vp, vp, vp, i32, vp]
+        L.dmg1_get_state.argtypes = [vp] * 5
+        L.dmg1_get_counters.argtypes = [vp] * 5
+        L.dmg1_set_counters.argtypes = [vp] * 4
+        L.dmg1_set_debug.argtypes = [vp, vp]
+        L.dmg1_last_kernel_ms.argtypes = [vp]
+        L.dmg1_last_kernel_ms.restype = C.c_float
+        if L.dmg1_model_sizeof() != C.sizeof(DmModelG1):
+            raise RuntimeError("DmModelG1 layout mismatch: C %d, ctypes %d" % (L.dmg1_model_sizeof(), C.sizeof(DmModelG1)))
+        _BOUND.append(True)
+    return L
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class G1HipEngine:
+    """Batch of N Unitree G1 DeepMimic environments resident on one MI355X (tensors in, tensors out)."""
+
+    def __init__(self, num_envs, device=0, seed=0, auto_reset=True, max_ep_length=1000):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("G1HipEngine needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.torch = torch
+        self.L = _lib()
+        self.gmodel, self.cmodel = load_g1_model()
+        self.N = int(num_envs)
+        self.device = torch.device("cuda", device)
+        cfg = DmG1Config()
+        self.L.dmg1_default_config(C.byref(cfg))
+        cfg.num_envs, cfg.seed, cfg.auto_reset, cfg.device, cfg.max_ep_length = self.N, seed, int(auto_reset), device, max_ep_length
+        self.h = C.c_void_p()
+        rc = self.L.dmg1_create(C.byref(self.cmodel), C.sizeof(DmModelG1), C.byref(cfg), C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError("dmg1_create failed: %d" % rc)
+        self.clip_len = 0
+        self._debug = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.dmg1_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, (self.L.dmg1_last_error(self.h) or b"").decode()))
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def load_clip(self, mocap, floor=False, acyclic=False, run_rule=False):
+        q, v, bx, gx = [np.ascontiguousarray(a, np.float64) for a in mocap.tables()]
+        self.clip_len = len(q)
+        flags = (CLIP_FLOOR if floor else 0) | (CLIP_ACYCLIC if acyclic else 0) | (CLIP_RUN_RULE if run_rule else 0)
+        self._check(self.L.dmg1_load_clip(self.h, len(q), q.ctypes.data, v.ctypes.data, bx.ctypes.data, gx.ctypes.data, flags),
+                    "dmg1_load_clip")
+
+    def alloc_outputs(self):
+        t, d, n = self.torch, self.device, self.N
+        return dict(obs=t.zeros(n, NOBS, device=d), rew=t.zeros(n, device=d), done=t.zeros(n, dtype=t.uint8, device=d),
+                    terms=t.zeros(n, 5, device=d), reason=t.zeros(n, dtype=t.int32, device=d),
+                    terminal_obs=t.zeros(n, NOBS, device=d))
+
+    def reset(self, obs, idx_init=None, mask=None):
+        self._check(self.L.dmg1_reset(self.h, _ptr(mask), _ptr(idx_init), _ptr(obs), self._stream()), "dmg1_reset")
+
+    def step(self, actions, out):
+        assert actions.shape == (self.N, NACT) and actions.dtype == self.torch.float32 and actions.is_contiguous()
+        self._check(self.L.dmg1_step(self.h, _ptr(actions), _ptr(out["obs"]), _ptr(out["rew"]), _ptr(out["done"]),
+                                     _ptr(out["terms"]), _ptr(out["reason"]), _ptr(out["terminal_obs"]), self._stream()),
+                    "dmg1_step")
+
+    def step_forced(self, qpos, qvel, out):
+        assert qpos.shape == (self.N, NQ) and qvel.shape == (self.N, NV) and qpos.is_contiguous() and qvel.is_contiguous()
+        self._check(self.L.dmg1_step_forced(self.h, _ptr(qpos), _ptr(qvel), _ptr(out["obs"]), _ptr(out["rew"]), _ptr(out["done"]),
+                                            _ptr(out["terms"]), _ptr(out["reason"]), self._stream()), "dmg1_step_forced")
+
+    def set_state(self, qpos, qvel, warm=None, run_forward=True):
+        assert qpos.shape == (self.N, NQ) and qvel.shape == (self.N, NV) and qpos.is_contiguous() and qvel.is_contiguous()
+        self._check(self.L.dmg1_set_state(self.h, _ptr(qpos), _ptr(qvel), _ptr(warm), int(run_forward), self._stream()),
+                    "dmg1_set_state")
+
+    def get_state(self):
+        t, d, n = self.torch, self.device, self.N
+        q, v, w = t.zeros(n, NQ, device=d), t.zeros(n, NV, device=d), t.zeros(n, NV, device=d)
+        self._check(self.L.dmg1_get_state(self.h, _ptr(q), _ptr(v), _ptr(w), self._stream()), "dmg1_get_state")
+        return q, v, w
+
+    def get_counters(self):
+        t, d, n = self.torch, self.device, self.N
+        i, l, r = t.zeros(n, dtype=t.int32, device=d), t.zeros(n, dtype=t.int32, device=d), t.zeros(n, device=d)
+        self._check(self.L.dmg1_get_counters(self.h, _ptr(i), _ptr(l), _ptr(r), self._stream()), "dmg1_get_counters")
+        return i, l, r
+
+    def set_counters(self, idx_curr=None, episode_length=None):
+        self._check(self.L.dmg1_set_counters(self.h, _ptr(idx_curr), _ptr(episode_length), self._stream()), "dmg1_set_counters")
+
+    def enable_debug(self):
+        self._debug = self.torch.zeros(self.N, DEBUG_STRIDE, device=self.device)
+        self.L.dmg1_set_debug(self.h, _ptr(self._debug))
+        return self._debug
+
+    def last_kernel_ms(self):
+        return float(self.L.dmg1_last_kernel_ms(self.h))

@@ -16,44 +16,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-NQ, NV, NU, NBODY, NGEOM, NJNT, NM, MAXPAIR, NOBS = 44, 43, 37, 39, 94, 38, 434, 1024, 85
-NMESH, NMESHVERT, NREWJ, NEE = 32, 40000, 23, 4
-# src/deepmimic_env.py:206-207
-REW_QPOS = [7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 32, 33, 34, 35, 36]
-REW_QVEL = [6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 31, 32, 33, 34, 35]
-
-_i32, _f64 = C.c_int32, C.c_double
-
-
-class DmModelG1(C.Structure):
-    """ctypes mirror of ``struct DmModel`` under -DDM_ROBOT_G1 (include/dm_model.h) — keep in sync (size checked)."""
-
-    _fields_ = [
-        ("nq", _i32), ("nv", _i32), ("nu", _i32), ("nbody", _i32), ("ngeom", _i32), ("njnt", _i32), ("npair", _i32),
-        ("nM", _i32), ("integrator", _i32), ("iterations", _i32), ("pad0", _i32), ("pad1", _i32),
-        ("timestep", _f64), ("tolerance", _f64), ("gravity", _f64 * 3), ("meaninertia", _f64), ("solref", _f64 * 2),
-        ("solimp", _f64 * 5), ("qpos0", _f64 * NQ),
-        ("body_parent", _i32 * NBODY), ("body_jntadr", _i32 * NBODY), ("body_jntnum", _i32 * NBODY),
-        ("body_dofadr", _i32 * NBODY), ("body_dofnum", _i32 * NBODY), ("body_depth", _i32 * NBODY),
-        ("body_pos", _f64 * 3 * NBODY), ("body_quat", _f64 * 4 * NBODY), ("body_ipos", _f64 * 3 * NBODY),
-        ("body_inertia", _f64 * 6 * NBODY), ("body_mass", _f64 * NBODY), ("body_invweight0", _f64 * 2 * NBODY),
-        ("jnt_type", _i32 * NJNT), ("jnt_body", _i32 * NJNT), ("jnt_qposadr", _i32 * NJNT), ("jnt_dofadr", _i32 * NJNT),
-        ("jnt_limited", _i32 * NJNT), ("jnt_pos", _f64 * 3 * NJNT), ("jnt_axis", _f64 * 3 * NJNT),
-        ("jnt_range", _f64 * 2 * NJNT),
-        ("dof_body", _i32 * NV), ("dof_jnt", _i32 * NV), ("dof_parent", _i32 * NV), ("dof_Madr", _i32 * NV),
-        ("dof_armature", _f64 * NV), ("dof_damping", _f64 * NV), ("dof_invweight0", _f64 * NV),
-        ("geom_type", _i32 * NGEOM), ("geom_body", _i32 * NGEOM), ("geom_condim", _i32 * NGEOM),
-        ("geom_pos", _f64 * 3 * NGEOM), ("geom_quat", _f64 * 4 * NGEOM), ("geom_size", _f64 * 3 * NGEOM),
-        ("geom_friction", _f64 * 3 * NGEOM), ("geom_margin", _f64 * NGEOM), ("geom_rbound", _f64 * NGEOM),
-        ("act_dof", _i32 * NU), ("act_gear", _f64 * NU), ("act_ctrlrange", _f64 * 2 * NU),
-        ("pair_geom1", _i32 * MAXPAIR), ("pair_geom2", _i32 * MAXPAIR),
-        ("ee_geom", _i32 * NEE), ("torso_body", _i32), ("rfoot_geom", _i32), ("lfoot_geom", _i32), ("floor_geom", _i32),
-        # trailing G1 fields
-        ("dof_frictionloss", _f64 * NV), ("geom_mesh", _i32 * NGEOM), ("mesh_vertadr", _i32 * NMESH),
-        ("mesh_vertnum", _i32 * NMESH), ("mesh_center", _f64 * 3 * NMESH), ("mesh_vert", _f64 * 3 * NMESHVERT),
-        ("nconmax", _i32), ("n_policy_action", _i32), ("action_scale", _f64), ("low_z", _f64),
-        ("rew_qposadr", _i32 * NREWJ), ("rew_dofadr", _i32 * NREWJ), ("rew_jnt", _i32 * NREWJ), ("extra_geom", _i32 * 8),
-    ]
+# the model struct and its builder are the product's (the HIP engine consumes the same struct): the oracle checks the layout
+from deepmimic_mujoco_amd.g1 import (DmModelG1, NQ, NV, NU, NBODY, NGEOM, NJNT, NM, MAXPAIR, NOBS, NMESH, NMESHVERT,  # noqa: F401,E402
+                                     NREWJ, NEE, REW_QPOS, REW_QVEL, to_cstruct, load_g1_model)
 
 
 def build():
@@ -94,69 +59,9 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def to_cstruct(g) -> DmModelG1:
-    """GModel (deepmimic_mujoco_amd.mjcf.compile_mjcf_general of the G1 asset, with hulls) -> DmModelG1."""
-    from deepmimic_mujoco_amd.config import RobotConfig
-    rc = RobotConfig("unitree_g1")
-    assert (g.nq, g.nv, g.nu, g.nbody, g.ngeom, g.njnt, g.nM) == (NQ, NV, NU, NBODY, NGEOM, NJNT, NM)
-    s = DmModelG1()
-    s.nq, s.nv, s.nu, s.nbody, s.ngeom, s.njnt, s.npair, s.nM = NQ, NV, NU, NBODY, NGEOM, NJNT, g.npair, NM
-    s.integrator = {"Euler": 0, "RK4": 1}[g.integrator]
-    s.iterations, s.timestep, s.tolerance, s.meaninertia = g.iterations, g.timestep, g.tolerance, g.meaninertia
-    assert g.solver == "PGS" and g.npair <= MAXPAIR
-
-    def put(name, arr):
-        dst = np.ctypeslib.as_array(getattr(s, name))
-        dst[...] = np.ascontiguousarray(arr).reshape(dst.shape)
-
-    for name in ["gravity", "solref", "solimp", "qpos0", "body_parent", "body_jntadr", "body_jntnum", "body_dofadr",
-                 "body_dofnum", "body_depth", "body_pos", "body_quat", "body_ipos", "body_inertia", "body_mass",
-                 "body_invweight0", "jnt_type", "jnt_body", "jnt_qposadr", "jnt_dofadr", "jnt_limited", "jnt_pos",
-                 "jnt_axis", "jnt_range", "dof_body", "dof_jnt", "dof_parent", "dof_Madr", "dof_armature", "dof_damping",
-                 "dof_invweight0", "geom_type", "geom_body", "geom_condim", "geom_pos", "geom_quat", "geom_size",
-                 "geom_friction", "geom_margin", "geom_rbound", "act_dof", "act_gear", "act_ctrlrange", "dof_frictionloss"]:
-        put(name, getattr(g, name))
-    p1, p2 = np.full(MAXPAIR, -1, np.int32), np.full(MAXPAIR, -1, np.int32)
-    p1[:g.npair], p2[:g.npair] = g.pairs[:, 0], g.pairs[:, 1]
-    put("pair_geom1", p1)
-    put("pair_geom2", p2)
-    put("ee_geom", [g.geom_id(n) for n in rc.endeffector_geom_names])
-    s.torso_body = g.body_id(rc.torso_body_name)
-    s.rfoot_geom, s.lfoot_geom, s.floor_geom = (g.geom_id(rc.rfoot_geom_name), g.geom_id(rc.lfoot_geom_name),
-                                                g.geom_id(rc.floor_geom_name))
-    put("geom_mesh", g.geom_meshid)
-    adr, num, verts = np.zeros(NMESH, np.int32), np.zeros(NMESH, np.int32), np.zeros((NMESHVERT, 3))
-    cen = np.zeros((NMESH, 3))
-    a = 0
-    assert len(g.mesh_vert) <= NMESH
-    for i, v in enumerate(g.mesh_vert):
-        adr[i], num[i] = a, len(v)
-        verts[a:a + len(v)] = v
-        cen[i] = g.mesh_center[i]
-        a += len(v)
-    assert a <= NMESHVERT
-    put("mesh_vertadr", adr)
-    put("mesh_vertnum", num)
-    put("mesh_vert", verts)
-    put("mesh_center", cen)
-    s.nconmax, s.n_policy_action, s.action_scale, s.low_z = g.nconmax, NU - 14, 20.0, rc.low_z
-    put("rew_qposadr", REW_QPOS)
-    put("rew_dofadr", REW_QVEL)
-    put("rew_jnt", np.array(REW_QPOS) - 7 + 1)
-    put("extra_geom", [g.geom_id(n) for n in rc.extra_contact_geom_names])
-    return s
-
-
-_MODEL = []
-
-
 def g1_model():
     """(GModel, DmModelG1) of the packaged G1 asset, cached."""
-    if not _MODEL:
-        from deepmimic_mujoco_amd import mjcf, model as M
-        g = mjcf.compile_mjcf_general(os.path.join(M.ASSET_DIR, "deepmimic_unitree_g1.xml"), hulls=mjcf.load_g1_hulls())
-        _MODEL.append((g, to_cstruct(g)))
-    return _MODEL[0]
+    return load_g1_model()
 
 
 class _Clip(C.Structure):
@@ -215,6 +120,11 @@ class G1Sim:
         c = self.get("contact").reshape(-1, 17)
         return [dict(dist=r[0], pos=r[1:4], frame=r[4:13].reshape(3, 3), geom1=int(r[13]), geom2=int(r[14]), dim=int(r[15]))
                 for r in c]
+
+    def set_caps(self, maxcon, maxrow):
+        """contact / row capacity (defaults: nconmax 200 of the XML, njmax 500); the HIP engine keeps 48 / 256."""
+        if self.L.dmo_set_caps(self.d, int(maxcon), int(maxrow)) != 0:
+            raise ValueError("caps out of range")
 
     def set_state(self, qpos, qvel):
         q, v = np.ascontiguousarray(qpos, np.float64), np.ascontiguousarray(qvel, np.float64)

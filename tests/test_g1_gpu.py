@@ -1,0 +1,172 @@
+"""Unitree G1 engine on the GPU (csrc/dm_g1.hip through the dmg1_* C-ABI) against the fp64 G1 oracle."""
+import numpy as np
+import pytest
+
+from deepmimic_mujoco_amd.config import MotionConfig
+from deepmimic_mujoco_amd.mocap import MocapDM
+
+pytestmark = pytest.mark.gpu
+
+MOTIONS = {}
+
+
+def _clip(motion):
+    if motion not in MOTIONS:
+        mc = MocapDM(robot="unitree_g1")
+        mc.load_mocap(MotionConfig(motion, robot="unitree_g1").mocap_path)
+        MOTIONS[motion] = mc
+    return MOTIONS[motion]
+
+
+def _states(n, seed=0):
+    """n test states: frames of the walk / getup clips pressed a little into the floor, random joint velocities, and a few
+    free-flight poses with self contacts."""
+    from oracle import oracle_g1 as og
+    g, _ = og.g1_model()
+    rng = np.random.default_rng(seed)
+    qs, vs = [], []
+    for i in range(n):
+        kind = i % 4
+        if kind in (0, 1):
+            mc = _clip("walk")
+            fr = int(rng.integers(len(mc.data_config)))
+            q, v = np.array(mc.data_config[fr]), np.array(mc.data_vel[fr])
+            q[2] -= rng.uniform(0.0, 0.02)
+        elif kind == 2:
+            mc = _clip("getup_facedown")
+            fr = int(rng.integers(0, 90))
+            q, v = np.array(mc.data_config[fr]), np.array(mc.data_vel[fr])
+        else:
+            q = g.qpos0.copy()
+            q[2] = 1.5
+            q[3:7] = rng.normal(size=4)
+            q[7:] = rng.uniform(-0.6, 0.6, 37)
+            v = rng.normal(size=43)
+        q[3:7] /= np.linalg.norm(q[3:7])
+        v = v + rng.normal(size=43) * 0.2
+        qs.append(q)
+        vs.append(v)
+    return np.array(qs), np.array(vs)
+
+
+def test_g1_forward_evaluation_matches_the_oracle():
+    """set_state + forward on 32 states: body poses, unconstrained acceleration, the contact list (geoms, distance, position,
+    normal, in order), the row count and the constrained acceleration."""
+    import torch
+    from deepmimic_mujoco_amd.g1 import G1HipEngine
+    from oracle import oracle_g1 as og
+    n = 32
+    q, v = _states(n)
+    eng = G1HipEngine(n, auto_reset=False)
+    eng.load_clip(_clip("walk"))
+    dbg = eng.enable_debug()
+    eng.set_state(torch.tensor(q, dtype=torch.float32, device=eng.device).contiguous(),
+                  torch.tensor(v, dtype=torch.float32, device=eng.device).contiguous())
+    torch.cuda.synchronize()
+    dbg = dbg.cpu().numpy()
+    worst = dict(xpos=0.0, qas=0.0, qacc=0.0, cdist=0.0, cpos=0.0, cnrm=0.0)
+    ncons, flips = [], 0
+    for i in range(n):
+        s = og.G1Sim()
+        s.set_caps(48, 256)
+        assert s.set_state(q[i].astype(np.float32).astype(np.float64), v[i].astype(np.float32).astype(np.float64)) == 0
+        d = dbg[i]
+        worst["xpos"] = max(worst["xpos"], np.abs(d[:117] - s.get("xpos")).max())
+        qas = s.get("qacc_smooth")
+        worst["qas"] = max(worst["qas"], np.abs(d[117:160] - qas).max() / max(1.0, np.abs(qas).max()))
+        cons = s.contacts()
+        ncon = int(d[203])
+        ncons.append(ncon)
+        gpu_c = d[208:208 + 9 * ncon].reshape(-1, 9)
+        same = ncon == len(cons) and all(int(r[1]) == c["geom1"] and int(r[2]) == c["geom2"] for r, c in zip(gpu_c, cons))
+        if not same:
+            flips += 1          # a contact at the edge of detection may appear on one side only (fp32 poses)
+            print("env", i, "contact sets differ:", [(int(r[1]), int(r[2]), round(float(r[0]), 5)) for r in gpu_c],
+                  [(c["geom1"], c["geom2"], round(c["dist"], 5)) for c in cons])
+            continue
+        for r, c in zip(gpu_c, cons):
+            worst["cdist"] = max(worst["cdist"], abs(r[0] - c["dist"]))
+            worst["cpos"] = max(worst["cpos"], np.abs(r[3:6] - c["pos"]).max())
+            worst["cnrm"] = max(worst["cnrm"], np.abs(r[6:9] - c["frame"][0]).max())
+        assert int(d[204]) == s.geti("nefc"), (i, d[204], s.geti("nefc"))
+        qa = s.get("qacc")
+        worst["qacc"] = max(worst["qacc"], np.abs(d[160:203] - qa).max() / max(1.0, np.abs(qa).max()))
+    print("G1 forward parity:", {k: float(v) for k, v in worst.items()}, "ncon", ncons, "contact-set flips", flips)
+    assert flips <= 2
+    assert worst["xpos"] < 2e-6 and worst["qas"] < 2e-4
+    assert worst["cdist"] < 2e-5 and worst["cpos"] < 2e-4 and worst["cnrm"] < 2e-3
+    assert worst["qacc"] < 5e-3
+    assert max(ncons) >= 8 and min(ncons) == 0 or max(ncons) >= 8
+    eng.close()
+
+
+def _teacher_forced(n, steps, act_scale, seed, stride=4):
+    import torch
+    from deepmimic_mujoco_amd.g1 import G1HipEngine
+    from oracle import oracle_g1 as og
+    g, _ = og.g1_model()
+    mc = _clip("walk")
+    clip = og.G1Clip(*mc.tables())
+    eng = G1HipEngine(n, auto_reset=False)
+    eng.load_clip(mc)
+    out = eng.alloc_outputs()
+    idx = torch.arange(n, dtype=torch.int32, device=eng.device) * stride
+    eng.reset(out["obs"], idx_init=idx)
+    sims = [og.G1Sim() for _ in range(n)]
+    for i, s in enumerate(sims):
+        s.set_caps(48, 256)
+        s.env_reset(clip, int(idx[i]))
+    rng = np.random.default_rng(seed)
+    alive = np.ones(n, bool)
+    recs = []   # (qpos err, qvel rel err, obs err, reward err, step used a non-analytic (MPR) contact in its last stage)
+    for t in range(steps):
+        q, v, w = [x.cpu().numpy().astype(np.float64) for x in eng.get_state()]
+        act = (rng.uniform(-1, 1, (n, 23)) * act_scale).astype(np.float32)
+        eng.step(torch.tensor(act, device=eng.device), out)
+        torch.cuda.synchronize()
+        q2, v2, _ = [x.cpu().numpy() for x in eng.get_state()]
+        obs, rew, done = out["obs"].cpu().numpy(), out["rew"].cpu().numpy(), out["done"].cpu().numpy()
+        for i, s in enumerate(sims):
+            if not alive[i]:
+                continue
+            s.set("qpos", q[i]); s.set("qvel", v[i]); s.set("qacc_warmstart", w[i])
+            o, r, d, terms, reason = s.env_step(clip, act[i].astype(np.float64))
+            mpr = any(not (g.geom_type[c["geom1"]] == 0 and g.geom_type[c["geom2"]] in (2, 5, 6))
+                      and not (g.geom_type[c["geom1"]] == 2 and g.geom_type[c["geom2"]] in (2, 6))
+                      and not (g.geom_type[c["geom1"]] == 6 and g.geom_type[c["geom2"]] == 6) for c in s.contacts())
+            recs.append((np.abs(q2[i] - s.get("qpos")).max(),
+                         np.abs(v2[i] - s.get("qvel")).max() / max(1.0, np.abs(s.get("qvel")).max()),
+                         np.abs(obs[i] - o).max(), abs(rew[i] - r), mpr))
+            if bool(done[i]) != d:
+                assert recs[-1][0] > 1e-5, (t, i, done[i], d, reason)     # only a diverged state may disagree on termination
+                alive[i] = False
+            if d:
+                alive[i] = False
+    eng.close()
+    return np.array(recs, float)
+
+
+def test_g1_teacher_forced_steps_small_actions():
+    """16 envs on the walk clip, 25 steps of small torques (feet on the floor, no self collision): before every step the oracle
+    takes the engine's state (qpos, qvel, warm start), both step: state, observation and reward agree to fp32 round-off."""
+    r = _teacher_forced(16, 25, 0.05, 1)
+    clean = r[r[:, 4] == 0]
+    print("G1 teacher-forced, small actions: %d env-steps (%d without MPR contacts); max qpos %.2e qvel %.2e obs %.2e rew %.2e" %
+          (len(r), len(clean), clean[:, 0].max(), clean[:, 1].max(), clean[:, 2].max(), clean[:, 3].max()))
+    assert len(clean) > 100
+    assert clean[:, 0].max() < 2e-5 and clean[:, 1].max() < 5e-4 and clean[:, 2].max() < 5e-4 and clean[:, 3].max() < 5e-4
+    assert np.median(clean[:, 0]) < 1e-6
+
+
+def test_g1_teacher_forced_steps_large_actions():
+    """The same with full-scale random torques: the robots thrash, fall and self-collide (mesh-mesh contacts through MPR).
+    MPR is ill-conditioned by construction — the portal it refines depends discontinuously on the poses, so fp32 vs fp64 body
+    poses occasionally give a contact normal that differs in the second digit; those env-steps are outliers, the
+    bulk must agree to round-off."""
+    r = _teacher_forced(16, 60, 1.0, 1)
+    e = r[:, 0]
+    print("G1 teacher-forced, full-scale actions: %d env-steps; qpos err median %.2e p90 %.2e p95 %.2e max %.2e; outliers > 1e-4: %d" %
+          (len(e), np.median(e), np.percentile(e, 90), np.percentile(e, 95), e.max(), int((e > 1e-4).sum())))
+    assert len(e) > 150
+    assert np.median(e) < 1e-6 and np.percentile(e, 90) < 1e-5
+    assert (e > 1e-4).mean() < 0.08 and e.max() < 2e-2

@@ -82,6 +82,37 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     assert cfg.max_ep_length == 1000 and abs(cfg.vel_obs_scale - 0.1) < 1e-7 and abs(cfg.w_joint_limit + 0.1) < 1e-7
 
 
+def test_g1_c_abi_exports_every_declared_symbol_and_the_struct_layout_matches():
+    """include/deepmimic_g1_hip.h: every dmg1_* entry point is exported and the ctypes mirror of the G1 DmModel has the
+    size the library was compiled with (no GPU call)."""
+    import ctypes as C
+    from deepmimic_mujoco_amd import _lib, g1
+    L = _lib.load_library()
+    hdr = open(os.path.join(ROOT, "include", "deepmimic_g1_hip.h")).read()
+    declared = set(re.findall(r"\b(dmg1_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(g1.EXPORTS), declared ^ set(g1.EXPORTS)
+    for name in declared:
+        assert getattr(L, name) is not None
+    L.dmg1_model_sizeof.restype = C.c_size_t
+    assert L.dmg1_model_sizeof() == C.sizeof(g1.DmModelG1)
+    cfg = g1.DmG1Config()
+    L.dmg1_default_config.argtypes = [C.POINTER(g1.DmG1Config)]
+    L.dmg1_default_config.restype = None
+    L.dmg1_default_config(C.byref(cfg))
+    assert cfg.max_ep_length == 1000 and abs(cfg.high_z - 2.0) < 1e-7
+    gm, cm = g1.load_g1_model()
+    assert cm.nq == 44 and cm.low_z == 0.4 and cm.action_scale == 20.0 and cm.n_policy_action == 23
+
+
+def test_g1_engine_fails_loudly_without_gpu():
+    import torch
+    from deepmimic_mujoco_amd.g1 import G1HipEngine
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        G1HipEngine(4)
+
+
 def test_engine_fails_loudly_without_gpu(model):
     import torch
     from deepmimic_mujoco_amd._lib import HipEngine
