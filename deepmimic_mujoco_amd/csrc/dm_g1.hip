@@ -82,6 +82,11 @@ struct Lds {   // per-env working set (one wave)
   int32_t e_meta[MAXROW];                                        // type | id << 2
   int16_t surv[MAXSURV];
   int32_t info[8];   // ncon, nefc, nlimit, solver_iter, overflow, nsurv
+  // narrowphase staging (fp64, wave-uniform): the two geoms of the pair being processed, its contacts, box-box polygons
+  double geo[2][18];     // pos 3 | mat 9 | size 3 | centre 3
+  int32_t geoi[2][6];    // type, nvert, nclus, vertex start, cluster start, pad
+  double rc[8][7];       // dist, pos 3, normal 3
+  double poly[2][16][3];
 };
 
 struct ClipDev {
@@ -430,11 +435,13 @@ __device__ void fwd_smooth(const Dev &T, Lds &S, const int lane) {   // mj_comVe
 }
 
 // ------------------------------------------------------------------------------------------ narrowphase (fp64, wave-uniform)
+// one contact of the pair being processed, and the view of one of its two geoms — both live in LDS (Lds::rc, Lds::geo):
+// the narrowphase is wave-uniform scalar code, and per-lane copies of these would sit in scratch memory
 struct Con { double dist, pos[3], n[3]; };
 struct Geo {
   int type, nvert, nclus;
-  double pos[3], mat[9], size[3], center[3];
-  const double *vert, *clus;
+  const double *pos, *mat, *size, *center;   // into Lds::geo
+  const double *vert, *clus;                 // global: clustered hull vertices, cluster bounds
   const int32_t *oidx;
 };
 __device__ __forceinline__ double ddot(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
@@ -466,7 +473,7 @@ __device__ __forceinline__ void dsub(double *r, const double *a, const double *b
 // the wave scans the cluster whose centre is furthest along dl, then only the clusters whose bound
 // (centre . dl + radius |dl|) can still reach the best value found — exact, ~6 passes instead of one per 64 vertices.
 // Equal support values resolve to the lowest ORIGINAL vertex index, as a serial first-maximum scan would.
-__device__ int mesh_support_index(const Geo &g, const double *dl, const int lane) {
+__device__ __forceinline__ int mesh_support_index(const Geo &g, const double *dl, const int lane) {
   const double dn = sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
   const int nc = g.nclus;
   double ub[2] = {-1e300, -1e300};   // bounds of clusters lane, lane + 64 (a hull has at most 128 clusters)
@@ -516,7 +523,7 @@ __device__ int mesh_support_index(const Geo &g, const double *dl, const int lane
   return bi;
 }
 
-__device__ void support(const Geo &g, const double *dir, double *out, const int lane) {   // [EXT] mjccd_support
+__device__ __forceinline__ void support(const Geo &g, const double *dir, double *out, const int lane) {   // [EXT] mjccd_support
   double dl[3], p[3] = {0, 0, 0};
   drot_t(dl, g.mat, dir);
   if (g.type == DM_GEOM_SPHERE) {
@@ -548,7 +555,7 @@ __device__ __forceinline__ bool ccd_eq(double a, double b) {
   a = fabs(a); b = fabs(b);
   return b > a ? ab < CCD_EPS * b : ab < CCD_EPS * a;
 }
-__device__ void mpr_support(const Geo &a, const Geo &b, const double *dir, Sup &s, const int lane) {
+__device__ __forceinline__ void mpr_support(const Geo &a, const Geo &b, const double *dir, Sup &s, const int lane) {
   double nd[3] = {-dir[0], -dir[1], -dir[2]};
   support(a, dir, s.v1, lane);
   support(b, nd, s.v2, lane);
@@ -572,7 +579,7 @@ __device__ __forceinline__ void expand_portal(Sup *ps, const Sup &v4) {
   if (ddot(ps[1].v, c) > 0) { if (ddot(ps[2].v, c) > 0) ps[1] = v4; else ps[3] = v4; }
   else { if (ddot(ps[3].v, c) > 0) ps[2] = v4; else ps[1] = v4; }
 }
-__device__ double tri_closest_origin(const double *a, const double *b, const double *c, double *w) {
+__device__ __forceinline__ double tri_closest_origin(const double *a, const double *b, const double *c, double *w) {
   double ab[3], ac[3], ap[3] = {-a[0], -a[1], -a[2]};
   dsub(ab, b, a); dsub(ac, c, a);
   const double d1 = ddot(ab, ap), d2 = ddot(ac, ap);
@@ -606,7 +613,7 @@ __device__ double tri_closest_origin(const double *a, const double *b, const dou
   return ddot(w, w);
 }
 // 0 = penetration (depth, dir a -> b, pos), -1 = none
-__device__ int mpr_penetration(const Geo &a, const Geo &b, double *depth, double *dir, double *pos, const int lane) {
+__device__ __noinline__ int mpr_penetration(const Geo &a, const Geo &b, double *depth, double *dir, double *pos, const int lane) {
   Sup ps[4], v4;
   double d[3], va[3], vb[3], dot;
   for (int i = 0; i < 3; i++) { ps[0].v1[i] = a.center[i]; ps[0].v2[i] = b.center[i]; ps[0].v[i] = a.center[i] - b.center[i]; }
@@ -693,7 +700,7 @@ __device__ int mpr_penetration(const Geo &a, const Geo &b, double *depth, double
 }
 
 // [EXT] mjc_Convex at margin 0; spheres get their analytic normal afterwards (mjc_fixNormal)
-__device__ int np_convex(Con *c, const Geo &a, const Geo &b, const int lane) {
+__device__ __noinline__ int np_convex(Con *c, const Geo &a, const Geo &b, const int lane) {
   double depth, dir[3], pos[3];
   if (mpr_penetration(a, b, &depth, dir, pos, lane) != 0) return 0;
   if (dir[0] == 0 && dir[1] == 0 && dir[2] == 0) return 0;
@@ -709,7 +716,7 @@ __device__ int np_convex(Con *c, const Geo &a, const Geo &b, const int lane) {
   return 1;
 }
 
-__device__ int np_plane_sphere(Con *c, const Geo &p, const double *spos, double r) {
+__device__ __forceinline__ int np_plane_sphere(Con *c, const Geo &p, const double *spos, double r) {
   double n[3] = {p.mat[2], p.mat[5], p.mat[8]}, df[3];
   dsub(df, spos, p.pos);
   const double dist = ddot(df, n) - r;
@@ -718,7 +725,7 @@ __device__ int np_plane_sphere(Con *c, const Geo &p, const double *spos, double 
   for (int i = 0; i < 3; i++) { c->n[i] = n[i]; c->pos[i] = spos[i] - n[i] * (r + 0.5 * dist); }
   return 1;
 }
-__device__ int np_plane_box(Con *c, const Geo &p, const Geo &b) {
+__device__ __forceinline__ int np_plane_box(Con *c, const Geo &p, const Geo &b) {
   double n[3] = {p.mat[2], p.mat[5], p.mat[8]}, df[3];
   dsub(df, b.pos, p.pos);
   const double dist = ddot(df, n);
@@ -734,7 +741,7 @@ __device__ int np_plane_box(Con *c, const Geo &p, const Geo &b) {
   }
   return cnt;
 }
-__device__ int np_plane_cylinder(Con *c, const Geo &p, const Geo &cy) {   // [EXT] mjc_PlaneCylinder
+__device__ __forceinline__ int np_plane_cylinder(Con *c, const Geo &p, const Geo &cy) {   // [EXT] mjc_PlaneCylinder
   double normal[3] = {p.mat[2], p.mat[5], p.mat[8]}, axis[3] = {cy.mat[2], cy.mat[5], cy.mat[8]};
   double prjaxis = ddot(normal, axis);
   if (prjaxis > 0) { for (int i = 0; i < 3; i++) axis[i] = -axis[i]; prjaxis = -prjaxis; }
@@ -773,7 +780,7 @@ __device__ int np_plane_cylinder(Con *c, const Geo &p, const Geo &cy) {   // [EX
 }
 // [EXT] mjc_PlaneConvex for a mesh: support vertex towards the plane + three directions tilted by 0.3 (low-confidence
 // restatement of the multi-contact rule, identical to the oracle's)
-__device__ int np_plane_mesh(Con *c, const Geo &p, const Geo &g, const int lane) {
+__device__ __noinline__ int np_plane_mesh(Con *c, const Geo &p, const Geo &g, const int lane) {
   double normal[3] = {p.mat[2], p.mat[5], p.mat[8]}, t1[3] = {p.mat[0], p.mat[3], p.mat[6]}, t2[3] = {p.mat[1], p.mat[4], p.mat[7]};
   int used[4], n = 0;
   for (int k = 0; k < 4; k++) {
@@ -801,7 +808,7 @@ __device__ int np_plane_mesh(Con *c, const Geo &p, const Geo &g, const int lane)
   }
   return n;
 }
-__device__ int np_sphere_sphere(Con *c, const double *p1, double r1, const double *p2, double r2) {
+__device__ __forceinline__ int np_sphere_sphere(Con *c, const double *p1, double r1, const double *p2, double r2) {
   double df[3];
   dsub(df, p2, p1);
   const double cd = dnorm(df), dist = cd - r1 - r2;
@@ -812,7 +819,7 @@ __device__ int np_sphere_sphere(Con *c, const double *p1, double r1, const doubl
   for (int i = 0; i < 3; i++) c->pos[i] = p1[i] + c->n[i] * (r1 + 0.5 * dist);
   return 1;
 }
-__device__ int np_sphere_box(Con *c, const Geo &s, const Geo &b) {
+__device__ __forceinline__ int np_sphere_box(Con *c, const Geo &s, const Geo &b) {
   double t[3], ctr[3], cl[3], nl[3];
   const double r = s.size[0];
   dsub(t, s.pos, b.pos);
@@ -843,7 +850,7 @@ __device__ int np_sphere_box(Con *c, const Geo &s, const Geo &b) {
   return 1;
 }
 // box-box (SAT + face clipping), same construction as the humanoid3d path (own construction, not MuJoCo's code)
-__device__ int np_box_box(Con *c, const Geo &A, const Geo &Bx) {
+__device__ __noinline__ int np_box_box(Con *c, const Geo &A, const Geo &Bx, double (*poly)[3], double (*tmp)[3]) {
   const double *p1 = A.pos, *R1 = A.mat, *s1 = A.size, *p2 = Bx.pos, *R2 = Bx.mat, *s2 = Bx.size;
   double R[9], AR[9], t[3], tw[3];
   dsub(tw, p2, p1);
@@ -924,7 +931,6 @@ __device__ int np_box_box(Con *c, const Geo &A, const Geo &Bx) {
   for (int k = 0; k < 3; k++) if (fabs(nb[k]) > bestd) { bestd = fabs(nb[k]); ib = k; }
   const double sgn = (nb[ib] > 0) ? -1.0 : 1.0;
   const int u = (ib + 1) % 3, v = (ib + 2) % 3;
-  double poly[16][3], tmp[16][3];
   int np = 4;
   for (int q = 0; q < 4; q++) {
     const double su = (q == 0 || q == 3) ? -sb[u] : sb[u], sv = (q < 2) ? -sb[v] : sb[v];
@@ -976,25 +982,36 @@ __device__ int np_box_box(Con *c, const Geo &A, const Geo &Bx) {
   return cnt;
 }
 
-__device__ void load_geo(const Dev &T, const Lds &S, const Launch &P, int g, Geo &o) {
-  o.type = T.g_type[g];
-  for (int i = 0; i < 3; i++) { o.pos[i] = S.gpos[g][i]; o.size[i] = T.g_size[g][i]; o.center[i] = o.pos[i]; }
-  for (int i = 0; i < 9; i++) o.mat[i] = S.gmat[g][i];
-  o.vert = nullptr; o.clus = nullptr; o.oidx = nullptr; o.nvert = 0; o.nclus = 0;
-  if (o.type == DM_GEOM_MESH) {
-    const int me = T.g_mesh[g];
-    o.vert = P.mesh_vert + 3 * (size_t)T.m_vadr[me];
-    o.oidx = P.mesh_oidx + T.m_vadr[me];
-    o.clus = P.mesh_clus + 4 * (size_t)T.m_cadr[me];
-    o.nvert = T.m_vnum[me];
-    o.nclus = T.m_cnum[me];
-    double c[3] = {T.m_center[me][0], T.m_center[me][1], T.m_center[me][2]}, t[3];
-    drot(t, o.mat, c);
-    for (int i = 0; i < 3; i++) o.center[i] += t[i];
+// stage geom g of the current pair in LDS slot `slot` (lanes 0..17 write one double each)
+__device__ __forceinline__ void stage_geo(const Dev &T, Lds &S, int g, int slot, const int lane) {
+  const int type = T.g_type[g], me = T.g_mesh[g];
+  double v = 0;
+  if (lane < 3) v = S.gpos[g][lane];
+  else if (lane < 12) v = S.gmat[g][lane - 3];
+  else if (lane < 15) v = T.g_size[g][lane - 12];
+  else if (lane < 18) {
+    const int i = lane - 15;
+    v = S.gpos[g][i];
+    if (type == DM_GEOM_MESH)
+      v += (double)S.gmat[g][3 * i] * T.m_center[me][0] + (double)S.gmat[g][3 * i + 1] * T.m_center[me][1] +
+           (double)S.gmat[g][3 * i + 2] * T.m_center[me][2];
+  }
+  if (lane < 18) S.geo[slot][lane] = v;
+  if (lane == 0) {
+    const bool mesh = type == DM_GEOM_MESH;
+    S.geoi[slot][0] = type; S.geoi[slot][1] = mesh ? T.m_vnum[me] : 0; S.geoi[slot][2] = mesh ? T.m_cnum[me] : 0;
+    S.geoi[slot][3] = mesh ? T.m_vadr[me] : 0; S.geoi[slot][4] = mesh ? T.m_cadr[me] : 0;
   }
 }
+__device__ __forceinline__ void view_geo(const Lds &S, const Launch &P, int slot, Geo &o) {
+  o.type = S.geoi[slot][0]; o.nvert = S.geoi[slot][1]; o.nclus = S.geoi[slot][2];
+  o.pos = &S.geo[slot][0]; o.mat = &S.geo[slot][3]; o.size = &S.geo[slot][12]; o.center = &S.geo[slot][15];
+  o.vert = P.mesh_vert + 3 * (size_t)S.geoi[slot][3];
+  o.oidx = P.mesh_oidx + S.geoi[slot][3];
+  o.clus = P.mesh_clus + 4 * (size_t)S.geoi[slot][4];
+}
 
-__device__ void make_frame(float *f) {   // [EXT] mju_makeFrame
+__device__ __forceinline__ void make_frame(float *f) {   // [EXT] mju_makeFrame
   float n = sqrtf(dot3(f, f));
   if (n < MINVALF) { f[0] = 1; f[1] = f[2] = 0; } else { f[0] /= n; f[1] /= n; f[2] /= n; }
   if (sqrtf(dot3(f + 3, f + 3)) < 0.5f) {
@@ -1010,7 +1027,7 @@ __device__ void make_frame(float *f) {   // [EXT] mju_makeFrame
 
 // Separating-axis test of two oriented boxes (15 axes), conservative by `slack`: true only if the boxes are at least that far
 // apart.  The filter is result-neutral: disjoint bounding boxes cannot hold intersecting geoms.
-__device__ bool obb_separated(const float *c1, const float *R1, const float *h1, const float *c2, const float *R2, const float *h2,
+__device__ __forceinline__ bool obb_separated(const float *c1, const float *R1, const float *h1, const float *c2, const float *R2, const float *h2,
                               const float slack) {
   float R[9], AR[9], t[3], tw[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
   for (int i = 0; i < 3; i++) t[i] = R1[i] * tw[0] + R1[3 + i] * tw[1] + R1[6 + i] * tw[2];
@@ -1034,7 +1051,7 @@ __device__ bool obb_separated(const float *c1, const float *R1, const float *h1,
 }
 
 // [EXT] mj_collision: candidate pairs in canonical order, bounding-sphere + bounding-box filters, narrowphase
-__device__ int collide(const Dev &T, Lds &S, const Launch &P, const int lane) {
+__device__ __forceinline__ int collide(const Dev &T, Lds &S, const Launch &P, const int lane) {
   int nsurv = 0, overflow = 0;
   for (int base = 0; base < T.npair; base += 64) {
     const int p = base + lane;
@@ -1070,26 +1087,31 @@ __device__ int collide(const Dev &T, Lds &S, const Launch &P, const int lane) {
     nsurv += __popcll(m);
   }
   if (nsurv > MAXSURV) { overflow = 1; nsurv = MAXSURV; }
+  if (P.pad & 32) nsurv = 0;
   SYNC();
   int ncon = 0;
+  Con *rc = reinterpret_cast<Con *>(&S.rc[0][0]);
   for (int s = 0; s < nsurv; s++) {
     const int p = S.surv[s];
     const int g1 = T.p_g1[p], g2 = T.p_g2[p];
+    stage_geo(T, S, g1, 0, lane);
+    stage_geo(T, S, g2, 1, lane);
+    SYNC();
     Geo A, B;
-    load_geo(T, S, P, g1, A);
-    load_geo(T, S, P, g2, B);
-    Con rc[8];
+    view_geo(S, P, 0, A);
+    view_geo(S, P, 1, B);
     int n = 0;
     const int t1 = A.type, t2 = B.type;
     if (t1 == DM_GEOM_PLANE) {
       if (t2 == DM_GEOM_SPHERE) n = np_plane_sphere(rc, A, B.pos, B.size[0]);
       else if (t2 == DM_GEOM_CYLINDER) n = np_plane_cylinder(rc, A, B);
       else if (t2 == DM_GEOM_BOX) n = np_plane_box(rc, A, B);
-      else if (t2 == DM_GEOM_MESH) n = np_plane_mesh(rc, A, B, lane);
+      else if (t2 == DM_GEOM_MESH && !(P.pad & 128)) n = np_plane_mesh(rc, A, B, lane);
     } else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_SPHERE) n = np_sphere_sphere(rc, A.pos, A.size[0], B.pos, B.size[0]);
     else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_BOX) n = np_sphere_box(rc, A, B);
-    else if (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX) n = np_box_box(rc, A, B);
-    else n = np_convex(rc, A, B, lane);
+    else if (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX) n = np_box_box(rc, A, B, S.poly[0], S.poly[1]);
+    else if (!(P.pad & 64)) n = np_convex(rc, A, B, lane);
+    SYNC();
     for (int k = 0; k < n; k++) {
       if (ncon >= MAXCON) { overflow = 1; continue; }
       if (lane == 0) {
@@ -1103,6 +1125,7 @@ __device__ int collide(const Dev &T, Lds &S, const Launch &P, const int lane) {
       }
       ncon++;
     }
+    SYNC();
   }
   SYNC();
   if (lane == 0) { S.info[0] = ncon; S.info[4] = overflow; S.info[5] = nsurv; }
@@ -1350,7 +1373,7 @@ __device__ void fwd_constraint(const Dev &T, Lds &S, const float *JT, const floa
   SYNC();
 }
 
-__device__ void forward(const Launch &P, const Dev &T, Lds &S, const int env, const int lane) {
+__device__ __noinline__ void forward(const Launch &P, const Dev &T, Lds &S, const int env, const int lane) {
   float *JT = P.jt + (size_t)env * 44 * MAXROW, *BT = P.bt + (size_t)env * 44 * MAXROW, *AR = P.ar + (size_t)env * MAXROW * MAXROW;
   kinematics(T, S, lane);
   com_pos(T, S, lane);
@@ -1434,45 +1457,45 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
     const float a = (lane < NQ) ? S.qpos[lane] : 0.f, b = (lane < NV) ? S.qvel[lane] : 0.f;
     sim_err = __any(!(fabsf(a) <= MAXVALF) || !(fabsf(b) <= MAXVALF));
   }
+  int stage = 0;   // RK4 stage of the evaluation about to run (MODE_STEP); every other mode runs one evaluation
   for (;;) {
     if (!sim_err) {
-      if (mode == MODE_STEP && !after_reset) {   // [EXT] mj_step with mj_RungeKutta(4)
-        const float A[3] = {0.5f, 0.5f, 1.f}, Bw[4] = {1.f / 6, 1.f / 3, 1.f / 3, 1.f / 6};
-        forward(P, T, S, env, lane);
-        stage_ncon = (unsigned)S.info[0] & 0xFF; stage_nefc_lo = (unsigned)S.info[1] & 0xFF;
-        {
+      forward(P, T, S, env, lane);   // the only call site: the evaluation is ~20 k instructions
+      if (mode == MODE_STEP && !after_reset) {   // [EXT] mj_step with mj_RungeKutta(4): A = (1/2, 1/2, 1), B = (1/6, 1/3, 1/3, 1/6)
+        const float Bw = (stage == 0 || stage == 3) ? 1.f / 6 : 1.f / 3;
+        stage_ncon |= ((unsigned)S.info[0] & 0xFF) << (8 * stage); stage_nefc_lo |= ((unsigned)S.info[1] & 0xFF) << (8 * stage);
+        if (stage == 0) {
           const bool badv = (lane < NV) && !(fabsf(S.qacc[lane]) <= MAXVALF);   // mj_checkAcc
           sim_err = __any(badv);
+          if (!sim_err) {
+            if (lane < NQ) S.x0q[lane] = S.qpos[lane];
+            if (lane < NV) { S.x0v[lane] = S.qvel[lane]; S.accq[lane] = 0.f; S.accv[lane] = 0.f; }
+          }
         }
         if (!sim_err) {
-          if (lane < NQ) S.x0q[lane] = S.qpos[lane];
-          if (lane < NV) { S.x0v[lane] = S.qvel[lane]; S.accq[lane] = Bw[0] * S.qvel[lane]; S.accv[lane] = Bw[0] * S.qacc[lane]; }
+          float dq = 0, dv = 0;
+          if (lane < NV) {
+            S.accq[lane] += Bw * S.qvel[lane]; S.accv[lane] += Bw * S.qacc[lane];
+            const float a = (stage == 2) ? 1.f : 0.5f;
+            dq = a * S.qvel[lane]; dv = a * S.qacc[lane];
+          }
           SYNC();
-          for (int i = 1; i < 4; i++) {
-            const float a = A[i - 1];
-            float dq = 0, dv = 0;
-            if (lane < NV) { dq = a * S.qvel[lane]; dv = a * S.qacc[lane]; }
-            SYNC();
+          if (stage < 3) {
             if (lane < NV) S.tmp[lane] = dq;
             SYNC();
             integrate_pos(S, S.x0q, S.tmp, h, lane);
             if (lane < NV) S.qvel[lane] = S.x0v[lane] + h * dv;
             SYNC();
-            forward(P, T, S, env, lane);
-            stage_ncon |= ((unsigned)S.info[0] & 0xFF) << (8 * i); stage_nefc_lo |= ((unsigned)S.info[1] & 0xFF) << (8 * i);
-            if (lane < NV) { S.accq[lane] += Bw[i] * S.qvel[lane]; S.accv[lane] += Bw[i] * S.qacc[lane]; }
-            SYNC();
+            stage++;
+            continue;
           }
           if (lane < NV) S.qvel[lane] = S.x0v[lane] + h * S.accv[lane];
           integrate_pos(S, S.x0q, S.accq, h, lane);
           SYNC();
         }
-      } else {
-        forward(P, T, S, env, lane);
-        if (mode == MODE_FORCED && !after_reset) {
-          const bool badv = (lane < NV) && !(fabsf(S.qacc[lane]) <= MAXVALF);
-          sim_err = __any(badv);
-        }
+      } else if (mode == MODE_FORCED && !after_reset) {
+        const bool badv = (lane < NV) && !(fabsf(S.qacc[lane]) <= MAXVALF);
+        sim_err = __any(badv);
       }
     }
     // ---- task layer (derived arrays are those of the LAST forward evaluation)

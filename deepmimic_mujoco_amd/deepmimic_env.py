@@ -115,6 +115,12 @@ class DPEnv:
     ENV_CFG = DPEnvConfig()
     metadata = {"render.modes": []}
 
+    def __new__(cls, motion=None, load_mocap=True, robot="humanoid3d", _profile=False, device=0):
+        if robot == "unitree_g1" and cls is DPEnv:   # the second robot has its own engine (g1.py, csrc/dm_g1.hip)
+            from .g1 import G1DPEnv
+            return G1DPEnv(motion=motion, load_mocap=load_mocap, robot=robot, _profile=_profile, device=device)
+        return super().__new__(cls)
+
     def __init__(self, motion=None, load_mocap=True, robot="humanoid3d", _profile=False, device=0):
         import torch
         self.PROFILE = _profile
@@ -306,6 +312,12 @@ class HipDeepMimicVecEnv(_SB3VecEnv):
     ``motion`` may be one clip name or a list (per-env clip id = env index mod len(list): BASELINE
     config 5).  ``step_tensor`` is the zero-copy path used by deepmimic_mujoco_amd.ppo.
     """
+
+    def __new__(cls, num_envs, motion=None, robot="humanoid3d", device=0, seed=1234, auto_reset=True, sub_batches=1):
+        if robot == "unitree_g1" and cls is HipDeepMimicVecEnv:
+            from .g1 import HipG1VecEnv
+            return HipG1VecEnv(num_envs, motion=motion, device=device, seed=seed, auto_reset=auto_reset)
+        return super().__new__(cls)
 
     def __init__(self, num_envs, motion=None, robot="humanoid3d", device=0, seed=1234, auto_reset=True, sub_batches=1):
         import torch

@@ -266,3 +266,182 @@ class G1HipEngine:
 
     def last_kernel_ms(self):
         return float(self.L.dmg1_last_kernel_ms(self.h))
+
+
+# ------------------------------------------------------------------------------------------ Gym / VecEnv surfaces
+def _g1_mocap(motion):
+    from .config import MotionConfig
+    from .mocap import MocapDM
+    mcfg = MotionConfig(motion, robot="unitree_g1")
+    mc = MocapDM(robot="unitree_g1")
+    mc.load_mocap(mcfg.mocap_path)
+    return mcfg, mc
+
+
+def _load(engine, mcfg, mc):
+    engine.load_clip(mc, floor=mcfg.motion in mcfg.floor_motions, acyclic=mcfg.motion in mcfg.acyclical_motions,
+                     run_rule=mcfg.motion == "run")                                  # src/deepmimic_env.py:426
+
+
+class HipG1VecEnv:
+    """N ``DPEnv(robot="unitree_g1")`` instances as one HIP batch with SubprocVecEnv semantics (auto-reset,
+    ``terminal_observation``): the G1 counterpart of :class:`deepmimic_env.HipDeepMimicVecEnv`, which constructs this class
+    when asked for ``robot="unitree_g1"``.  Actions are the policy's 23 values (src/deepmimic_env.py:303-307)."""
+
+    def __init__(self, num_envs, motion=None, device=0, seed=1234, auto_reset=True):
+        import torch
+        from .deepmimic_env import Box, DPEnvConfig
+        self._torch = torch
+        self.num_envs = int(num_envs)
+        self.robot_config = RobotConfig("unitree_g1")
+        self.motion_config, self.mocap = _g1_mocap(motion)
+        self.engine = G1HipEngine(self.num_envs, device=device, seed=seed, auto_reset=auto_reset,
+                                  max_ep_length=DPEnvConfig().MAX_EP_LENGTH)
+        _load(self.engine, self.motion_config, self.mocap)
+        self.model = self.engine.gmodel
+        self.device = self.engine.device
+        self.out = self.engine.alloc_outputs()
+        lo, hi = self.model.act_ctrlrange[:NACT, 0].astype(np.float32), self.model.act_ctrlrange[:NACT, 1].astype(np.float32)
+        self.action_space = Box(lo, hi, dtype=np.float32)            # the first N - 14 actuators (src/deepmimic_env.py:305-307)
+        self.observation_space = Box(-np.inf, np.inf, (NOBS,), np.float32)
+        self._actions = torch.zeros(self.num_envs, NACT, device=self.device)
+        self.render_mode = None
+        self.reset_infos = [{} for _ in range(self.num_envs)]
+
+    def reset_tensor(self, idx_init=None):
+        self.engine.reset(self.out["obs"], idx_init=idx_init)
+        return self.out["obs"]
+
+    def step_tensor(self, actions):
+        self.engine.step(actions.contiguous(), self.out)
+        return self.out
+
+    def reset(self):
+        return self.reset_tensor().cpu().numpy()
+
+    def step_async(self, actions):
+        t = self._torch
+        self._actions.copy_(t.as_tensor(np.ascontiguousarray(actions, dtype=np.float32)).reshape(self._actions.shape))
+
+    def step_wait(self):
+        from .deepmimic_env import LazyInfos
+        t = self._torch
+        out = self.step_tensor(self._actions)
+        packed = t.cat([out["obs"], out["terminal_obs"], out["terms"], out["rew"][:, None], out["done"][:, None].float(),
+                        out["reason"][:, None].float()], dim=1).cpu().numpy()
+        d, k = NOBS, 5
+        obs, tobs, terms = (np.ascontiguousarray(packed[:, 0:d]), np.ascontiguousarray(packed[:, d:2 * d]),
+                            np.ascontiguousarray(packed[:, 2 * d:2 * d + k]))
+        rew = packed[:, 2 * d + k].copy()
+        done = packed[:, 2 * d + k + 1] != 0
+        reason = packed[:, 2 * d + k + 2].astype(np.int32)
+        return obs, rew, done, LazyInfos(terms, reason, done, tobs)
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        self.engine.close()
+
+    def seed(self, seed=None):
+        return [None if seed is None else int(seed) + i for i in range(self.num_envs)]
+
+    def get_attr(self, attr_name, indices=None):
+        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
+        return [getattr(self, attr_name)] * n
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
+        return [False] * n
+
+
+class G1DPEnv:
+    """``DPEnv(motion, robot="unitree_g1")`` (src/deepmimic_env.py:272-510): one environment of the batch engine behind the
+    reference's Gym surface; ``deepmimic_env.DPEnv`` constructs this class for the G1 robot."""
+
+    version = "v1.0"
+
+    def __init__(self, motion=None, load_mocap=True, robot="unitree_g1", _profile=False, device=0):
+        import random
+        import torch
+        from .deepmimic_env import Box, DPEnvConfig
+        if robot != "unitree_g1":
+            raise ValueError("G1DPEnv is the unitree_g1 environment")
+        if not load_mocap:
+            raise NotImplementedError("the mocap-less probing instance (src/deepmimic_env.py:287-293) is only used by MocapDM's "
+                                      "own kinematics pass, which mjcf.forward_kinematics_general replaces")
+        self._torch, self._random = torch, random
+        self.ENV_CFG = DPEnvConfig()
+        self.robot_config = RobotConfig("unitree_g1")
+        self.motion_config, self.mocap = _g1_mocap(motion)
+        self._eng = G1HipEngine(1, device=device, auto_reset=False, max_ep_length=self.ENV_CFG.MAX_EP_LENGTH)
+        _load(self._eng, self.motion_config, self.mocap)
+        self.model = self._eng.gmodel
+        self._out = self._eng.alloc_outputs()
+        self.mocap_dt, self.mocap_data_len = self.mocap.dt, len(self.mocap.data_config)
+        self.idx_curr, self.episode_reward, self.episode_length = -1, 0, 0
+        lo, hi = self.model.act_ctrlrange[:NACT, 0].astype(np.float32), self.model.act_ctrlrange[:NACT, 1].astype(np.float32)
+        self.action_space = Box(lo, hi, dtype=np.float32)
+        self.observation_space = Box(-np.inf, np.inf, (NOBS,), np.float64)
+        self.reference_state_init()
+
+    def reference_state_init(self, idx_init=None):
+        self.idx_init = self._random.randint(0, self.mocap_data_len - 1) if idx_init is None else idx_init
+        self.idx_curr = self.idx_init
+
+    def _push(self):
+        t = self._torch
+        self._eng.set_counters(t.tensor([max(self.idx_curr, 0)], dtype=t.int32, device=self._eng.device),
+                               t.tensor([self.episode_length], dtype=t.int32, device=self._eng.device))
+
+    def step(self, action, force_state=None):
+        from .deepmimic_env import _make_info
+        t, dev = self._torch, self._eng.device
+        action = np.asarray(action, np.float64)
+        if action.shape == (NU,):          # the full action vector MujocoEnv.__init__ probes with (:349): hands are dropped
+            action = action[:NACT]
+        assert action.shape == (NACT,)
+        self._push()
+        if force_state is not None:
+            q, v = force_state
+            self._eng.step_forced(t.tensor(np.asarray(q)[None], dtype=t.float32, device=dev),
+                                  t.tensor(np.asarray(v)[None], dtype=t.float32, device=dev), self._out)
+        else:
+            self._eng.step(t.tensor(action[None], dtype=t.float32, device=dev), self._out)
+        obs = self._out["obs"][0].double().cpu().numpy()
+        reason, done = int(self._out["reason"][0].item()), bool(self._out["done"][0].item())
+        if reason in (5, 6):
+            if reason == 6:
+                self.idx_curr = (self.idx_curr + 1) % self.mocap_data_len
+                self.episode_reward = float(self._eng.get_counters()[2][0].item())
+                self.episode_length += 1
+            return obs, 0, True, {}
+        reward = float(self._out["rew"][0].item())
+        info = _make_info(self._out["terms"][0].cpu().numpy(), reason)
+        if reason == 8:
+            info["done_reason"] = REASONS[8]
+        self.idx_curr = (self.idx_curr + 1) % self.mocap_data_len
+        self.episode_reward += reward
+        self.episode_length += 1
+        return obs, reward, done, info
+
+    def reset(self):
+        self.episode_reward, self.episode_length = 0, 0
+        return self.reset_model()
+
+    def reset_model(self, idx_init=None):
+        t = self._torch
+        self.reference_state_init(idx_init=idx_init)
+        obs = t.zeros(1, NOBS, device=self._eng.device)
+        self._eng.reset(obs, idx_init=t.tensor([self.idx_init], dtype=t.int32, device=self._eng.device))
+        self._eng.set_counters(None, t.tensor([self.episode_length], dtype=t.int32, device=self._eng.device))
+        return obs[0].double().cpu().numpy()
+
+    def set_state(self, qpos, qvel):
+        t = self._torch
+        self._eng.set_state(t.tensor(np.asarray(qpos)[None], dtype=t.float32, device=self._eng.device),
+                            t.tensor(np.asarray(qvel)[None], dtype=t.float32, device=self._eng.device))
+
+    def close(self):
+        self._eng.close()

@@ -170,3 +170,39 @@ def test_g1_teacher_forced_steps_large_actions():
     assert len(e) > 150
     assert np.median(e) < 1e-6 and np.percentile(e, 90) < 1e-5
     assert (e > 1e-4).mean() < 0.08 and e.max() < 2e-2
+
+
+def test_g1_gym_and_vecenv_surfaces():
+    """DPEnv(robot="unitree_g1") and HipDeepMimicVecEnv(robot="unitree_g1") construct the G1 classes; reset / step shapes,
+    the 23-dim action space, force_state teacher-forcing (imitation terms exactly 1) and auto-reset with terminal_observation."""
+    from deepmimic_mujoco_amd.deepmimic_env import DPEnv, HipDeepMimicVecEnv
+    from deepmimic_mujoco_amd import g1
+    env = DPEnv("walk", robot="unitree_g1")
+    assert isinstance(env, g1.G1DPEnv) and env.action_space.shape == (23,) and env.observation_space.shape == (85,)
+    obs = env.reset_model(idx_init=5)
+    assert obs.shape == (85,) and abs(obs[84] - 5 / env.mocap_data_len) < 1e-6
+    mc = env.mocap
+    o, r, d, info = env.step(np.zeros(23), force_state=(np.array(mc.get_qpos(5)), np.array(mc.get_qvel(5))))
+    assert not d and abs(info["reward_config"] - 1) < 1e-5 and abs(info["reward_end_eff"] - 1) < 1e-5 and abs(r - 1.0) < 1e-3
+    assert env.idx_curr == 6 and env.episode_length == 1
+    steps = 0
+    while True:
+        o, r, d, info = env.step(np.zeros(23))
+        steps += 1
+        if d:
+            break
+    assert info["done_reason"] == "low_z" and 5 < steps < 80
+    env.close()
+    venv = HipDeepMimicVecEnv(8, motion="walk", robot="unitree_g1", seed=3)
+    assert isinstance(venv, g1.HipG1VecEnv)
+    obs = venv.reset()
+    assert obs.shape == (8, 85)
+    ndone = 0
+    for t in range(60):
+        obs, rew, done, infos = venv.step(np.zeros((8, 23), np.float32))
+        assert obs.shape == (8, 85) and rew.shape == (8,) and len(infos) == 8 and np.isfinite(obs).all()
+        for i in np.nonzero(done)[0]:
+            ndone += 1
+            assert infos[i]["terminal_observation"].shape == (85,) and infos[i]["done_reason"] in ("low_z", "high_z")
+    assert ndone >= 8
+    venv.close()
