@@ -84,6 +84,38 @@ def _mlp_flops_per_step(B, D, H1, H2, A):
     return trunk(A) + trunk(1)
 
 
+def g1_record(local_rank, n=4096, steps=20, warmup=5):
+    """Auxiliary record: the second robot of the reference, DPEnv(robot="unitree_g1") — the robot its published figure
+    (~1 390 env-steps/s, src/plot_profiling.py:486) was measured on.  Full step() with auto-reset, random actions in [-1, 1]
+    (x 20 torque scale inside), walk clip, dmg1_step through the C-ABI; kernel time from HIP events inside the library."""
+    import torch
+    from deepmimic_mujoco_amd.g1 import G1HipEngine, NACT
+    from deepmimic_mujoco_amd.config import MotionConfig as MC
+    from deepmimic_mujoco_amd.mocap import MocapDM as MD
+    mc = MD(robot="unitree_g1")
+    mc.load_mocap(MC("walk", robot="unitree_g1").mocap_path)
+    eng = G1HipEngine(n, device=local_rank, auto_reset=True, seed=3)
+    eng.load_clip(mc)
+    out = eng.alloc_outputs()
+    eng.reset(out["obs"])
+    g = torch.Generator(device=eng.device).manual_seed(0)
+    acts = [torch.rand(n, NACT, device=eng.device, generator=g) * 2 - 1 for _ in range(8)]
+    for t in range(warmup):
+        eng.step(acts[t % 8], out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(steps):
+        eng.step(acts[t % 8], out)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rec = {"robot": "unitree_g1 (43 DoF, 32 convex meshes, friction loss)", "envs_per_gpu": n, "steps": steps,
+           "env_steps_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3, "kernel": "g1_step_kernel",
+           "kernel_ms_last": eng.last_kernel_ms(), "done_fraction_last_step": float(out["done"].float().mean()),
+           "reference_published_env_steps_per_s": 1390, "note": "auxiliary: SURVEY 8f-2 (next row), not the headline metric"}
+    eng.close()
+    return rec
+
+
 def ppo_loop_record(args, dev, local_rank, rank, world, launched, barrier):
     """PPO loop of BASELINE configs 3 (one GPU: 4096 envs `walk`) / 4 (per-GPU share: 4096 envs `spinkick`): rollout incl.
     policy inference, GAE, 20 epochs x 32 minibatches of 4096 with ONE all-reduce of the flat gradient per optimizer step
@@ -214,6 +246,7 @@ def main():
     ap.add_argument("--integrator", default="model", choices=["model", "RK4", "Euler"],
                     help="model = the XML's (RK4, the headline); Euler = north_star's semi-implicit Euler option (auxiliary figure)")
     ap.add_argument("--no-ppo-loop", action="store_true", help="skip the auxiliary PPO-loop record (configs 3 / 4)")
+    ap.add_argument("--no-g1", action="store_true", help="skip the auxiliary Unitree G1 record")
     ap.add_argument("--ppo-iters", type=int, default=2, help="timed PPO iterations per net in the ppo_loop record")
     args = ap.parse_args()
 
@@ -325,6 +358,13 @@ def main():
         except Exception as e:  # noqa: BLE001
             ppo_loop = {"error": repr(e)[:300]}
 
+    g1 = None
+    if rank == 0 and not args.no_g1 and args.actions == "random" and N == 4096 and args.integrator != "Euler":
+        try:
+            g1 = g1_record(local_rank)
+        except Exception as e:  # noqa: BLE001
+            g1 = {"error": repr(e)[:300]}
+
     if rank == 0:
         total_steps = args.steps * N * world
         value = total_steps / dt
@@ -351,6 +391,8 @@ def main():
         }
         if ppo_loop is not None:
             line["ppo_loop"] = ppo_loop
+        if g1 is not None:
+            line["g1"] = g1
         if pipelined is not None:
             line["pipelined"] = pipelined
         if world == 1 and not args.no_cpu_baseline:

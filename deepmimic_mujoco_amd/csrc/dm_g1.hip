@@ -13,6 +13,7 @@
 #include "../../include/dm_model.h"
 #undef DmModel
 #include "../../include/deepmimic_g1_hip.h"
+#include "dm_g1_topology.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -33,7 +34,7 @@
 namespace g1 {
 
 constexpr int NQ = 44, NV = 43, NU = 37, NB = 39, NG = 94, NJ = 38, NM = 434, NACT = 23, NOBS = 85, NREW = 23;
-constexpr int MAXCON = DMG1_MAXCON, MAXROW = DMG1_MAXROW, MAXANC = 16, MAXSURV = 384;
+constexpr int MAXCON = DMG1_MAXCON, MAXROW = DMG1_MAXROW, MAXANC = 16, MAXSURV = 384, NCG = 48;   // NCG: geoms that collide (47)
 constexpr int STATE = 176;   // floats per env in the HBM state row
 constexpr int S_QPOS = 0, S_QVEL = 44, S_WARM = 87, S_CTRL = 130, S_IDX = 167, S_EPLEN = 168, S_EPREW = 169, S_RCNT = 170;
 constexpr int CLIP_ROW = 64;  // per frame: 23 reward qpos | 23 reward qvel | root quat 4 | ee geom xpos 12
@@ -55,7 +56,7 @@ struct Dev {   // read-only model tables (global memory, fp32)
   int32_t d_body[44], d_nanc[44], d_madr[44], d_act[44];
   uint8_t d_anc[44][MAXANC];   // ancestors of dof k: parent, grand-parent, ...
   float d_axis[44][3], d_arm[44], d_damp[44], d_invw[44], d_floss[44], d_lo[44], d_hi[44], d_clo[44], d_chi[44];
-  int32_t g_body[96], g_type[96], g_mesh[96];
+  int32_t g_body[96], g_type[96], g_mesh[96], g_ci[96];   // g_ci: index into Lds::gmat, -1 for visual geoms
   float g_pos[96][3], g_mat[96][9], g_size[96][3], g_rbound[96], g_mu[96];
   float g_bc[96][3], g_bh[96][3];   // local bounding box of the geom (centre, half extents) for the OBB filter
   int16_t p_g1[1024], p_g2[1024];
@@ -64,30 +65,41 @@ struct Dev {   // read-only model tables (global memory, fp32)
   uint8_t tri_a[128], tri_b[128];
 };
 
-struct Lds {   // per-env working set (one wave)
+struct Lds {   // per-env working set (one wave): 19.2 KB, eight waves per CU
   float qpos[NQ], qvel[44], warm[44], ctrl[40];
   float xpos[40][3], xquat[40][4], xmat[40][9], xipos[40][3];
   float xaxis[44][3];
-  float gpos[96][3], gmat[96][9];
+  float gpos[96][3], gmat[NCG][9];   // rotation only of the geoms that collide (Dev::g_ci)
   float com[4];
-  float cinert[40][10], crb[40][10];
-  float cdof[44][6], cdofdot[44][6];
-  float cvel[40][6], cacc[40][6], cfrc[40][6];
-  float qM[NM + 2], qLD[NM + 2], dinv[44], dsq[44];
+  float cdof[44][6];
+  float cvel[40][6];
+  float qLD[NM + 2], dinv[44], dsq[44];
   float bias[44], fsm[44], qas[44], qacc[44], qfc[44], tmp[44];
   float x0q[NQ], x0v[44], accq[44], accv[44];
-  float c_dist[MAXCON], c_pos[MAXCON][3], c_frame[MAXCON][9], c_mu[MAXCON];
-  int32_t c_g1[MAXCON], c_g2[MAXCON];
-  float e_R[MAXROW], e_b[MAXROW], e_f[MAXROW], e_lim[MAXROW];   // regulariser, aref then b, force, friction-loss bound
-  int32_t e_meta[MAXROW];                                        // type | id << 2
-  int16_t surv[MAXSURV];
   int32_t info[8];   // ncon, nefc, nlimit, solver_iter, overflow, nsurv
-  // narrowphase staging (fp64, wave-uniform): the two geoms of the pair being processed, its contacts, box-box polygons
-  double geo[2][18];     // pos 3 | mat 9 | size 3 | centre 3
-  int32_t geoi[2][6];    // type, nvert, nclus, vertex start, cluster start, pad
-  double rc[8][7];       // dist, pos 3, normal 3
-  double poly[2][16][3];
+#ifdef G1_PROFILE
+  long long prof_t; unsigned prof[16];
+#endif
+  union {
+    struct {   // smooth-dynamics scratch: dead once qacc_smooth is known
+      float cinert[40][10], crb[40][10], cdofdot[44][6], cacc[40][6], cfrc[40][6];
+    } sm;
+    struct {   // contacts of the evaluation (kept for the observation) and the narrowphase staging (fp64, wave-uniform)
+      float c_dist[MAXCON], c_pos[MAXCON][3], c_frame[MAXCON][9], c_mu[MAXCON];
+      int32_t c_g1[MAXCON], c_g2[MAXCON];
+      int16_t surv[MAXSURV];
+      double geo[2][18];     // the two geoms of the pair being processed: pos 3 | mat 9 | size 3 | centre 3
+      int32_t geoi[2][6];    // type, nvert, nclus, vertex start, cluster start, pad
+      double rc[8][7];       // its contacts: dist, pos 3, normal 3
+      double poly[2][16][3]; // box-box polygons
+    } co;
+  } u;
 };
+
+// The per-env working set is a file-scope __shared__ object: every phase is its own (out-of-line) function with its own
+// register allocation, and all of them address it as LDS (ds_* instructions), not through generic pointers.
+__shared__ Lds g_S;
+#define S g_S
 
 struct ClipDev {
   const float *rows;    // L x CLIP_ROW
@@ -103,6 +115,7 @@ struct Launch {
   const double *mesh_clus;   // per cluster: bounding-sphere centre xyz, radius
   float *state;              // N x STATE
   float *jt, *bt, *ar;       // per-env scratch: J^T [44][MAXROW], (D^-1/2 L^-T J^T) [44][MAXROW], A [MAXROW][MAXROW]
+  float *rows;               // per-env scratch: R, aref -> b, force, friction-loss bound, meta (type | id << 2): [5][MAXROW]
   ClipDev clip;
   int32_t N, mode, auto_reset, max_ep_length, run_forward, pad;
   float vel_obs_scale, high_z, obs_bound;
@@ -196,9 +209,14 @@ __device__ __host__ __forceinline__ uint32_t hash32(uint64_t seed, uint32_t env,
 }
 
 #define SYNC() __syncthreads()
+#ifdef G1_PROFILE
+#define PROF(k) do { const long long t_ = clock64(); if (threadIdx.x == 0) { S.prof[k] += (unsigned)(t_ - S.prof_t); } S.prof_t = t_; } while (0)
+#else
+#define PROF(k) do {} while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------ position stage
-__device__ void kinematics(const Dev &T, Lds &S, const int lane) {   // [EXT] mj_kinematics
+__device__ __noinline__ void kinematics(const Dev &T, const int lane) {   // [EXT] mj_kinematics
   if (lane == 0) {
     S.xpos[0][0] = S.xpos[0][1] = S.xpos[0][2] = 0;
     S.xquat[0][0] = 1; S.xquat[0][1] = S.xquat[0][2] = S.xquat[0][3] = 0;
@@ -250,21 +268,23 @@ __device__ void kinematics(const Dev &T, Lds &S, const int lane) {   // [EXT] mj
     float gp[3] = {T.g_pos[g][0], T.g_pos[g][1], T.g_pos[g][2]}, t[3];
     mat_vec(t, S.xmat[b], gp);
     for (int i = 0; i < 3; i++) S.gpos[g][i] = S.xpos[b][i] + t[i];
+    const int ci = T.g_ci[g];
+    if (ci >= 0)
     for (int i = 0; i < 3; i++)
       for (int j = 0; j < 3; j++)
-        S.gmat[g][3 * i + j] = S.xmat[b][3 * i] * T.g_mat[g][j] + S.xmat[b][3 * i + 1] * T.g_mat[g][3 + j] +
+        S.gmat[ci][3 * i + j] = S.xmat[b][3 * i] * T.g_mat[g][j] + S.xmat[b][3 * i + 1] * T.g_mat[g][3 + j] +
                                S.xmat[b][3 * i + 2] * T.g_mat[g][6 + j];
   }
   SYNC();
 }
 
-__device__ void com_pos(const Dev &T, Lds &S, const int lane) {   // [EXT] mj_comPos
+__device__ __noinline__ void com_pos(const Dev &T, const int lane) {   // [EXT] mj_comPos
   float m = (lane >= 1 && lane < NB) ? T.b_mass[lane] : 0.f, c[3];
   for (int i = 0; i < 3; i++) c[i] = wsum(m * ((lane < NB) ? S.xipos[lane][i] : 0.f)) * T.total_mass_inv;
   if (lane == 0) for (int i = 0; i < 3; i++) S.com[i] = c[i];
   if (lane < NB) {
     const int b = lane;
-    float *ci = S.cinert[b];
+    float *ci = S.u.sm.cinert[b];
     if (b == 0) { for (int i = 0; i < 10; i++) ci[i] = 0; }
     else {
       const float *I = T.b_inertia[b], *R = S.xmat[b];
@@ -297,7 +317,7 @@ __device__ void com_pos(const Dev &T, Lds &S, const int lane) {   // [EXT] mj_co
   SYNC();
 }
 
-__device__ void crb_factor(const Dev &T, Lds &S, const int lane) {   // [EXT] mj_crb + mj_factorM
+__device__ __noinline__ void crb_factor(const Dev &T, const int lane) {   // [EXT] mj_crb + mj_factorM
   if (lane < NB) {
     float acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t mk = T.b_desc[lane];
@@ -305,26 +325,26 @@ __device__ void crb_factor(const Dev &T, Lds &S, const int lane) {   // [EXT] mj
     while (mk) {
       const int d = __ffsll((long long)mk) - 1;
       mk &= mk - 1;
-      for (int i = 0; i < 10; i++) acc[i] += S.cinert[d][i];
+      for (int i = 0; i < 10; i++) acc[i] += S.u.sm.cinert[d][i];
     }
-    for (int i = 0; i < 10; i++) S.crb[lane][i] = acc[i];
+    for (int i = 0; i < 10; i++) S.u.sm.crb[lane][i] = acc[i];
   }
   SYNC();
   if (lane < NV) {
     const int i = lane;
     float buf[6], cd[6];
     for (int q = 0; q < 6; q++) cd[q] = S.cdof[i][q];
-    mul_inert_vec(buf, S.crb[T.d_body[i]], cd);
+    mul_inert_vec(buf, S.u.sm.crb[T.d_body[i]], cd);
     int adr = T.d_madr[i];
     float v = T.d_arm[i];
     for (int q = 0; q < 6; q++) v += cd[q] * buf[q];
-    S.qM[adr] = v; S.qLD[adr] = v;
+    S.qLD[adr] = v;
     const int n = T.d_nanc[i];
     for (int a = 0; a < n; a++) {
       const int j = T.d_anc[i][a];
       float s = 0;
       for (int q = 0; q < 6; q++) s += S.cdof[j][q] * buf[q];
-      S.qM[adr + 1 + a] = s; S.qLD[adr + 1 + a] = s;
+      S.qLD[adr + 1 + a] = s;
     }
   }
   SYNC();
@@ -349,7 +369,7 @@ __device__ void crb_factor(const Dev &T, Lds &S, const int lane) {   // [EXT] mj
 }
 
 // x <- M^-1 x for an LDS vector
-__device__ void solve_m(const Dev &T, Lds &S, float *x, const int lane) {
+__device__ __noinline__ void solve_m(const Dev &T, float *x, const int lane) {
   for (int i = NV - 1; i >= 0; i--) {
     const int n = T.d_nanc[i];
     if (lane < n) x[T.d_anc[i][lane]] -= S.qLD[T.d_madr[i] + 1 + lane] * x[i];
@@ -369,24 +389,24 @@ __device__ void solve_m(const Dev &T, Lds &S, float *x, const int lane) {
 }
 
 // ------------------------------------------------------------------------------------------ velocity stage
-__device__ void fwd_smooth(const Dev &T, Lds &S, const int lane) {   // mj_comVel, mj_passive, mj_rne, mj_fwdActuation
-  if (lane == 0) for (int i = 0; i < 6; i++) { S.cvel[0][i] = 0; S.cacc[0][i] = (i == 5) ? -T.gravity[2] : 0.f; }
+__device__ __noinline__ void fwd_smooth(const Dev &T, const int lane) {   // mj_comVel, mj_passive, mj_rne, mj_fwdActuation
+  if (lane == 0) for (int i = 0; i < 6; i++) { S.cvel[0][i] = 0; S.u.sm.cacc[0][i] = (i == 5) ? -T.gravity[2] : 0.f; }
   SYNC();
   for (int L = 1; L <= T.maxdepth; L++) {
     if (lane >= 1 && lane < NB && T.b_depth[lane] == L) {
       const int b = lane, p = T.b_parent[b];
       float cv[6], ca[6];
-      for (int i = 0; i < 6; i++) { cv[i] = S.cvel[p][i]; ca[i] = S.cacc[p][i]; }
+      for (int i = 0; i < 6; i++) { cv[i] = S.cvel[p][i]; ca[i] = S.u.sm.cacc[p][i]; }
       if (b == 1) {
         for (int k = 0; k < 3; k++) {
-          for (int i = 0; i < 6; i++) S.cdofdot[k][i] = 0;
+          for (int i = 0; i < 6; i++) S.u.sm.cdofdot[k][i] = 0;
           for (int i = 0; i < 6; i++) cv[i] += S.cdof[k][i] * S.qvel[k];
         }
         for (int k = 3; k < 6; k++) {
           float dd[6], cd[6];
           for (int i = 0; i < 6; i++) cd[i] = S.cdof[k][i];
           cross_motion(dd, cv, cd);
-          for (int i = 0; i < 6; i++) { S.cdofdot[k][i] = dd[i]; ca[i] += dd[i] * S.qvel[k]; }
+          for (int i = 0; i < 6; i++) { S.u.sm.cdofdot[k][i] = dd[i]; ca[i] += dd[i] * S.qvel[k]; }
         }
         for (int k = 3; k < 6; k++)
           for (int i = 0; i < 6; i++) cv[i] += S.cdof[k][i] * S.qvel[k];
@@ -396,13 +416,13 @@ __device__ void fwd_smooth(const Dev &T, Lds &S, const int lane) {   // mj_comVe
         for (int i = 0; i < 6; i++) cd[i] = S.cdof[k][i];
         cross_motion(dd, cv, cd);
         const float qv = S.qvel[k];
-        for (int i = 0; i < 6; i++) { S.cdofdot[k][i] = dd[i]; ca[i] += dd[i] * qv; cv[i] += cd[i] * qv; }
+        for (int i = 0; i < 6; i++) { S.u.sm.cdofdot[k][i] = dd[i]; ca[i] += dd[i] * qv; cv[i] += cd[i] * qv; }
       }
       float t[6], t1[6], f[6];
-      mul_inert_vec(f, S.cinert[b], ca);
-      mul_inert_vec(t, S.cinert[b], cv);
+      mul_inert_vec(f, S.u.sm.cinert[b], ca);
+      mul_inert_vec(t, S.u.sm.cinert[b], cv);
       cross_force(t1, cv, t);
-      for (int i = 0; i < 6; i++) { S.cvel[b][i] = cv[i]; S.cacc[b][i] = ca[i]; S.cfrc[b][i] = f[i] + t1[i]; }
+      for (int i = 0; i < 6; i++) { S.cvel[b][i] = cv[i]; S.u.sm.cacc[b][i] = ca[i]; S.u.sm.cfrc[b][i] = f[i] + t1[i]; }
     }
     SYNC();
   }
@@ -413,15 +433,15 @@ __device__ void fwd_smooth(const Dev &T, Lds &S, const int lane) {   // mj_comVe
     while (mk) {
       const int d = __ffsll((long long)mk) - 1;
       mk &= mk - 1;
-      for (int i = 0; i < 6; i++) acc[i] += S.cfrc[d][i];
+      for (int i = 0; i < 6; i++) acc[i] += S.u.sm.cfrc[d][i];
     }
-    for (int i = 0; i < 6; i++) S.crb[lane][i] = acc[i];
+    for (int i = 0; i < 6; i++) S.u.sm.crb[lane][i] = acc[i];
   }
   SYNC();
   if (lane < NV) {
     const int k = lane;
     float bias = 0;
-    for (int i = 0; i < 6; i++) bias += S.cdof[k][i] * S.crb[T.d_body[k]][i];
+    for (int i = 0; i < 6; i++) bias += S.cdof[k][i] * S.u.sm.crb[T.d_body[k]][i];
     const float passive = -T.d_damp[k] * S.qvel[k];
     float act = 0;
     const int a = T.d_act[k];
@@ -430,7 +450,7 @@ __device__ void fwd_smooth(const Dev &T, Lds &S, const int lane) {   // mj_comVe
     S.bias[k] = bias; S.fsm[k] = fs; S.qas[k] = fs;
   }
   SYNC();
-  solve_m(T, S, S.qas, lane);
+  solve_m(T, S.qas, lane);
   SYNC();
 }
 
@@ -469,63 +489,110 @@ __device__ __forceinline__ void drot_t(double *r, const double *m, const double 
 __device__ __forceinline__ double dclamp(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 __device__ __forceinline__ void dsub(double *r, const double *a, const double *b) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
 
-// Support vertex of a hull in local direction dl.  The vertices are stored in clusters of 64 with a bounding sphere each:
-// the wave scans the cluster whose centre is furthest along dl, then only the clusters whose bound
-// (centre . dl + radius |dl|) can still reach the best value found — exact, ~6 passes instead of one per 64 vertices.
-// Equal support values resolve to the lowest ORIGINAL vertex index, as a serial first-maximum scan would.
-__device__ __forceinline__ int mesh_support_index(const Geo &g, const double *dl, const int lane) {
-  const double dn = sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
-  const int nc = g.nclus;
-  double ub[2] = {-1e300, -1e300};   // bounds of clusters lane, lane + 64 (a hull has at most 128 clusters)
-  double cbest = -1e300;
-  int cidx = 0x7fffffff;
+// Support vertices of up to two hulls at once, in local directions dlA / dlB.  The vertices are stored in clusters of 64
+// with a bounding sphere each.  Two dependent memory round trips for BOTH hulls together (the narrowphase is one wave's
+// latency chain, so round trips are what it costs): (1) every cluster's centre . d: the largest is a lower bound of the
+// support value (a cluster's centre is the mean of its vertices), centre . d + radius |d| an upper bound per cluster;
+// (2) all clusters whose upper bound reaches the lower bound are scanned, every lane keeping its own best — no cross-lane
+// step between the loads — and one wave reduction ends it.  Exact; equal support values resolve to the lowest ORIGINAL
+// vertex index, as a serial first-maximum scan would.
+struct MeshPick { double best; int bo, bk; };
+__device__ __forceinline__ void pick_update(MeshPick &p, double sv, int so, int sk) {
+  if (sv > p.best || (sv == p.best && so < p.bo)) { p.best = sv; p.bo = so; p.bk = sk; }
+}
+// every lane scans vertex `lane` of up to four clusters (-1: none): independent loads, no cross-lane step
+__device__ __forceinline__ void scan4(const Geo &g, const double *dl, const int (&c)[4], MeshPick &p, const int lane) {
+  double x[4], y[4], z[4];
+  int o[4];
 #pragma unroll
-  for (int m = 0; m < 2; m++) {
+  for (int q = 0; q < 4; q++) {
+    const int k = 64 * (c[q] < 0 ? 0 : c[q]) + lane;
+    const bool ok = c[q] >= 0;
+    x[q] = ok ? g.vert[3 * k] : 0.0; y[q] = ok ? g.vert[3 * k + 1] : 0.0; z[q] = ok ? g.vert[3 * k + 2] : 0.0;
+    o[q] = ok ? g.oidx[k] : 0x7fffffff;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+    if (o[q] != 0x7fffffff) pick_update(p, x[q] * dl[0] + y[q] * dl[1] + z[q] * dl[2], o[q], 64 * c[q] + lane);
+}
+__device__ __forceinline__ void wave_pick(MeshPick &p) {
+  for (int o = 32; o > 0; o >>= 1) {
+    const double v = __shfl_xor(p.best, o);
+    const int bo = __shfl_xor(p.bo, o), bk = __shfl_xor(p.bk, o);
+    pick_update(p, v, bo, bk);
+  }
+}
+__device__ __forceinline__ void scan_candidates(const Geo &g, const double *dl, const double (&ub)[3], const double bound, const int skip,
+                                                MeshPick &p, const int lane) {
+#pragma unroll
+  for (int m = 0; m < 3; m++) {
+    unsigned long long todo = __ballot(ub[m] >= bound && (lane + 64 * m) != skip);
+    while (todo) {
+      int c[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        c[q] = todo ? (__ffsll((long long)todo) - 1 + 64 * m) : -1;
+        todo &= todo - 1;
+      }
+      scan4(g, dl, c, p, lane);
+    }
+  }
+}
+// cluster bounds of one hull: ub[m] for clusters lane + 64 m, the cluster with the largest centre . d
+__device__ __forceinline__ void cluster_bounds(const Geo &g, const double *dl, const bool on, double (&ub)[3], int &top, const int lane) {
+  const double dn = sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
+  double best = -1e300;
+  top = 0x7fffffff;
+#pragma unroll
+  for (int m = 0; m < 3; m++) {
     const int c = lane + 64 * m;
-    if (c < nc) {
+    ub[m] = -1e300;
+    if (on && c < g.nclus) {
       const double *cl = g.clus + 4 * c;
       const double dc = cl[0] * dl[0] + cl[1] * dl[1] + cl[2] * dl[2];
       ub[m] = dc + cl[3] * dn;
-      if (dc > cbest) { cbest = dc; cidx = c; }
+      if (dc > best) { best = dc; top = c; }
     }
   }
   for (int o = 32; o > 0; o >>= 1) {
-    const double ob = __shfl_xor(cbest, o);
-    const int oi = __shfl_xor(cidx, o);
-    if (ob > cbest || (ob == cbest && oi < cidx)) { cbest = ob; cidx = oi; }
+    const double ob = __shfl_xor(best, o);
+    const int oc = __shfl_xor(top, o);
+    if (ob > best || (ob == best && oc < top)) { best = ob; top = oc; }
   }
-  double best = -1e300;
-  int bi = 0, bo = 0x7fffffff;
-  auto scan = [&](int c) {
-    const int k = 64 * c + lane;
-    double sv = -1e300;
-    int so = 0x7fffffff;
-    if (k < g.nvert) { sv = g.vert[3 * k] * dl[0] + g.vert[3 * k + 1] * dl[1] + g.vert[3 * k + 2] * dl[2]; so = g.oidx[k]; }
-    int sk = k;
-    for (int o = 32; o > 0; o >>= 1) {
-      const double ob = __shfl_xor(sv, o);
-      const int oo = __shfl_xor(so, o), ok = __shfl_xor(sk, o);
-      if (ob > sv || (ob == sv && oo < so)) { sv = ob; so = oo; sk = ok; }
-    }
-    if (sv > best || (sv == best && so < bo)) { best = sv; bo = so; bi = sk; }
-  };
-  scan(cidx);
-#pragma unroll
-  for (int m = 0; m < 2; m++) {
-    unsigned long long todo = __ballot(ub[m] >= best && (lane + 64 * m) != cidx && (lane + 64 * m) < nc);
-    while (todo) {
-      const int l = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      const double u = __shfl(ub[m], l);
-      if (u >= best) scan(l + 64 * m);
-    }
-  }
-  return bi;
+}
+// Support vertices of up to two hulls at once, in local directions dlA / dlB.  The vertices are stored in compact clusters
+// (k-d leaves, padded to 64 slots) with a bounding sphere each.  Three dependent memory round trips for BOTH hulls together
+// (the narrowphase is one wave's latency chain: round trips are what it costs): (1) every cluster's centre . d and bound
+// centre . d + radius |d|; (2) the cluster with the largest centre . d is scanned: a true support value to prune with;
+// (3) the clusters whose bound still reaches it are scanned together, every lane keeping its own best, one wave reduction
+// at the end.  Exact; equal support values resolve to the lowest ORIGINAL vertex index, like a serial first-maximum scan.
+__device__ __noinline__ void mesh_support_pair(const Geo &A, const double *dlA, const bool meshA, int &iA, const Geo &B,
+                                                  const double *dlB, const bool meshB, int &iB, const int lane) {
+  double ubA[3], ubB[3];
+  int topA, topB;
+  cluster_bounds(A, dlA, meshA, ubA, topA, lane);
+  cluster_bounds(B, dlB, meshB, ubB, topB, lane);
+  MeshPick pa = {-1e300, 0x7fffffff, 0}, pb = {-1e300, 0x7fffffff, 0};
+  { const int ca[4] = {meshA ? topA : -1, -1, -1, -1}, cb[4] = {meshB ? topB : -1, -1, -1, -1};
+    scan4(A, dlA, ca, pa, lane);
+    scan4(B, dlB, cb, pb, lane); }
+  double ba = pa.best, bb = pb.best;
+  for (int o = 32; o > 0; o >>= 1) { ba = fmax(ba, __shfl_xor(ba, o)); bb = fmax(bb, __shfl_xor(bb, o)); }
+  if (meshA) scan_candidates(A, dlA, ubA, ba, topA, pa, lane);
+  if (meshB) scan_candidates(B, dlB, ubB, bb, topB, pb, lane);
+  wave_pick(pa);
+  wave_pick(pb);
+  iA = pa.bk; iB = pb.bk;
+}
+__device__ __forceinline__ int mesh_support_index(const Geo &g, const double *dl, const int lane) {
+  int i, j;
+  mesh_support_pair(g, dl, true, i, g, dl, false, j, lane);
+  return i;
 }
 
-__device__ __forceinline__ void support(const Geo &g, const double *dir, double *out, const int lane) {   // [EXT] mjccd_support
-  double dl[3], p[3] = {0, 0, 0};
-  drot_t(dl, g.mat, dir);
+// [EXT] mjccd_support for the analytic shapes (local direction dl -> local point p)
+__device__ __forceinline__ void support_local(const Geo &g, const double *dl, double *p) {
+  p[0] = p[1] = p[2] = 0;
   if (g.type == DM_GEOM_SPHERE) {
     const double n = dnorm(dl);
     if (n > 0) for (int i = 0; i < 3; i++) p[i] = dl[i] * g.size[0] / n;
@@ -535,12 +602,7 @@ __device__ __forceinline__ void support(const Geo &g, const double *dir, double 
     p[2] = dl[2] >= 0 ? g.size[1] : -g.size[1];
   } else if (g.type == DM_GEOM_BOX) {
     for (int i = 0; i < 3; i++) p[i] = dl[i] >= 0 ? g.size[i] : -g.size[i];
-  } else if (g.type == DM_GEOM_MESH) {
-    const int bi = mesh_support_index(g, dl, lane);
-    p[0] = g.vert[3 * bi]; p[1] = g.vert[3 * bi + 1]; p[2] = g.vert[3 * bi + 2];
   }
-  drot(out, g.mat, p);
-  for (int i = 0; i < 3; i++) out[i] += g.pos[i];
 }
 
 // ---- libccd MPR (ccdMPRPenetration), restated; tolerance / iteration cap = MuJoCo's mpr_tolerance / mpr_iterations
@@ -555,11 +617,23 @@ __device__ __forceinline__ bool ccd_eq(double a, double b) {
   a = fabs(a); b = fabs(b);
   return b > a ? ab < CCD_EPS * b : ab < CCD_EPS * a;
 }
+// support point of A - B in direction dir: both supports together, so the two hull scans share their memory round trips
 __device__ __forceinline__ void mpr_support(const Geo &a, const Geo &b, const double *dir, Sup &s, const int lane) {
-  double nd[3] = {-dir[0], -dir[1], -dir[2]};
-  support(a, dir, s.v1, lane);
-  support(b, nd, s.v2, lane);
-  dsub(s.v, s.v1, s.v2);
+  double nd[3] = {-dir[0], -dir[1], -dir[2]}, dla[3], dlb[3], pa[3], pb[3];
+  drot_t(dla, a.mat, dir);
+  drot_t(dlb, b.mat, nd);
+  const bool ma = a.type == DM_GEOM_MESH, mb = b.type == DM_GEOM_MESH;
+  support_local(a, dla, pa);
+  support_local(b, dlb, pb);
+  if (ma || mb) {
+    int ia, ib;
+    mesh_support_pair(a, dla, ma, ia, b, dlb, mb, ib, lane);
+    if (ma) { pa[0] = a.vert[3 * ia]; pa[1] = a.vert[3 * ia + 1]; pa[2] = a.vert[3 * ia + 2]; }
+    if (mb) { pb[0] = b.vert[3 * ib]; pb[1] = b.vert[3 * ib + 1]; pb[2] = b.vert[3 * ib + 2]; }
+  }
+  drot(s.v1, a.mat, pa);
+  drot(s.v2, b.mat, pb);
+  for (int i = 0; i < 3; i++) { s.v1[i] += a.pos[i]; s.v2[i] += b.pos[i]; s.v[i] = s.v1[i] - s.v2[i]; }
 }
 __device__ __forceinline__ void portal_dir(const Sup *ps, double *dir) {
   double a[3], b[3];
@@ -983,32 +1057,32 @@ __device__ __noinline__ int np_box_box(Con *c, const Geo &A, const Geo &Bx, doub
 }
 
 // stage geom g of the current pair in LDS slot `slot` (lanes 0..17 write one double each)
-__device__ __forceinline__ void stage_geo(const Dev &T, Lds &S, int g, int slot, const int lane) {
+__device__ __forceinline__ void stage_geo(const Dev &T, int g, int slot, const int lane) {
   const int type = T.g_type[g], me = T.g_mesh[g];
   double v = 0;
   if (lane < 3) v = S.gpos[g][lane];
-  else if (lane < 12) v = S.gmat[g][lane - 3];
+  else if (lane < 12) v = S.gmat[T.g_ci[g]][lane - 3];
   else if (lane < 15) v = T.g_size[g][lane - 12];
   else if (lane < 18) {
     const int i = lane - 15;
     v = S.gpos[g][i];
     if (type == DM_GEOM_MESH)
-      v += (double)S.gmat[g][3 * i] * T.m_center[me][0] + (double)S.gmat[g][3 * i + 1] * T.m_center[me][1] +
-           (double)S.gmat[g][3 * i + 2] * T.m_center[me][2];
+      v += (double)S.gmat[T.g_ci[g]][3 * i] * T.m_center[me][0] + (double)S.gmat[T.g_ci[g]][3 * i + 1] * T.m_center[me][1] +
+           (double)S.gmat[T.g_ci[g]][3 * i + 2] * T.m_center[me][2];
   }
-  if (lane < 18) S.geo[slot][lane] = v;
+  if (lane < 18) S.u.co.geo[slot][lane] = v;
   if (lane == 0) {
     const bool mesh = type == DM_GEOM_MESH;
-    S.geoi[slot][0] = type; S.geoi[slot][1] = mesh ? T.m_vnum[me] : 0; S.geoi[slot][2] = mesh ? T.m_cnum[me] : 0;
-    S.geoi[slot][3] = mesh ? T.m_vadr[me] : 0; S.geoi[slot][4] = mesh ? T.m_cadr[me] : 0;
+    S.u.co.geoi[slot][0] = type; S.u.co.geoi[slot][1] = mesh ? T.m_vnum[me] : 0; S.u.co.geoi[slot][2] = mesh ? T.m_cnum[me] : 0;
+    S.u.co.geoi[slot][3] = mesh ? T.m_vadr[me] : 0; S.u.co.geoi[slot][4] = mesh ? T.m_cadr[me] : 0;
   }
 }
-__device__ __forceinline__ void view_geo(const Lds &S, const Launch &P, int slot, Geo &o) {
-  o.type = S.geoi[slot][0]; o.nvert = S.geoi[slot][1]; o.nclus = S.geoi[slot][2];
-  o.pos = &S.geo[slot][0]; o.mat = &S.geo[slot][3]; o.size = &S.geo[slot][12]; o.center = &S.geo[slot][15];
-  o.vert = P.mesh_vert + 3 * (size_t)S.geoi[slot][3];
-  o.oidx = P.mesh_oidx + S.geoi[slot][3];
-  o.clus = P.mesh_clus + 4 * (size_t)S.geoi[slot][4];
+__device__ __forceinline__ void view_geo(const Launch &P, int slot, Geo &o) {
+  o.type = S.u.co.geoi[slot][0]; o.nvert = S.u.co.geoi[slot][1]; o.nclus = S.u.co.geoi[slot][2];
+  o.pos = &S.u.co.geo[slot][0]; o.mat = &S.u.co.geo[slot][3]; o.size = &S.u.co.geo[slot][12]; o.center = &S.u.co.geo[slot][15];
+  o.vert = P.mesh_vert + 3 * (size_t)S.u.co.geoi[slot][3];
+  o.oidx = P.mesh_oidx + S.u.co.geoi[slot][3];
+  o.clus = P.mesh_clus + 4 * (size_t)S.u.co.geoi[slot][4];
 }
 
 __device__ __forceinline__ void make_frame(float *f) {   // [EXT] mju_makeFrame
@@ -1051,30 +1125,30 @@ __device__ __forceinline__ bool obb_separated(const float *c1, const float *R1, 
 }
 
 // [EXT] mj_collision: candidate pairs in canonical order, bounding-sphere + bounding-box filters, narrowphase
-__device__ __forceinline__ int collide(const Dev &T, Lds &S, const Launch &P, const int lane) {
+__device__ __noinline__ int collide(const Dev &T, const Launch &P, const int lane) {
   int nsurv = 0, overflow = 0;
   for (int base = 0; base < T.npair; base += 64) {
     const int p = base + lane;
     bool keep = false;
     if (p < T.npair) {
-      const int g1 = T.p_g1[p], g2 = T.p_g2[p];
+      const int g1 = T.p_g1[p], g2 = T.p_g2[p], ci1 = T.g_ci[g1], ci2 = T.g_ci[g2];
       float df[3] = {S.gpos[g2][0] - S.gpos[g1][0], S.gpos[g2][1] - S.gpos[g1][1], S.gpos[g2][2] - S.gpos[g1][2]};
       float c2[3], bc2[3] = {T.g_bc[g2][0], T.g_bc[g2][1], T.g_bc[g2][2]}, h2[3] = {T.g_bh[g2][0], T.g_bh[g2][1], T.g_bh[g2][2]};
-      mat_vec(c2, S.gmat[g2], bc2);
+      mat_vec(c2, S.gmat[ci2], bc2);
       for (int i = 0; i < 3; i++) c2[i] += S.gpos[g2][i];
       if (T.g_type[g1] != DM_GEOM_PLANE) {
         keep = sqrtf(dot3(df, df)) <= T.g_rbound[g1] + T.g_rbound[g2];
         if (keep) {
           float c1[3], bc1[3] = {T.g_bc[g1][0], T.g_bc[g1][1], T.g_bc[g1][2]}, h1[3] = {T.g_bh[g1][0], T.g_bh[g1][1], T.g_bh[g1][2]};
-          mat_vec(c1, S.gmat[g1], bc1);
+          mat_vec(c1, S.gmat[ci1], bc1);
           for (int i = 0; i < 3; i++) c1[i] += S.gpos[g1][i];
-          keep = !obb_separated(c1, S.gmat[g1], h1, c2, S.gmat[g2], h2, 1e-4f);
+          keep = !obb_separated(c1, S.gmat[ci1], h1, c2, S.gmat[ci2], h2, 1e-4f);
         }
       } else {
-        float nrm[3] = {S.gmat[g1][2], S.gmat[g1][5], S.gmat[g1][8]};
+        float nrm[3] = {S.gmat[ci1][2], S.gmat[ci1][5], S.gmat[ci1][8]};
         keep = !(T.g_rbound[g2] > 0) || dot3(df, nrm) <= T.g_rbound[g2];
         if (keep) {   // lowest point of the bounding box above the plane: no contact possible
-          const float *M2 = S.gmat[g2];
+          const float *M2 = S.gmat[ci2];
           float dc[3] = {c2[0] - S.gpos[g1][0], c2[1] - S.gpos[g1][1], c2[2] - S.gpos[g1][2]}, ext = 0;
           for (int j = 0; j < 3; j++) ext += fabsf(nrm[0] * M2[j] + nrm[1] * M2[3 + j] + nrm[2] * M2[6 + j]) * h2[j];
           keep = dot3(dc, nrm) - ext <= 1e-4f;
@@ -1083,25 +1157,29 @@ __device__ __forceinline__ int collide(const Dev &T, Lds &S, const Launch &P, co
     }
     const unsigned long long m = __ballot(keep);
     const int slot = nsurv + __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-    if (keep) { if (slot < MAXSURV) S.surv[slot] = (int16_t)p; }
+    if (keep) { if (slot < MAXSURV) S.u.co.surv[slot] = (int16_t)p; }
     nsurv += __popcll(m);
   }
   if (nsurv > MAXSURV) { overflow = 1; nsurv = MAXSURV; }
   if (P.pad & 32) nsurv = 0;
   SYNC();
-  int ncon = 0;
-  Con *rc = reinterpret_cast<Con *>(&S.rc[0][0]);
+  PROF(3);
+  int ncon = 0, n_pm = 0, n_an = 0, n_mpr = 0;
+  Con *rc = reinterpret_cast<Con *>(&S.u.co.rc[0][0]);
   for (int s = 0; s < nsurv; s++) {
-    const int p = S.surv[s];
+    const int p = S.u.co.surv[s];
     const int g1 = T.p_g1[p], g2 = T.p_g2[p];
-    stage_geo(T, S, g1, 0, lane);
-    stage_geo(T, S, g2, 1, lane);
+    stage_geo(T, g1, 0, lane);
+    stage_geo(T, g2, 1, lane);
     SYNC();
     Geo A, B;
-    view_geo(S, P, 0, A);
-    view_geo(S, P, 1, B);
+    view_geo(P, 0, A);
+    view_geo(P, 1, B);
     int n = 0;
     const int t1 = A.type, t2 = B.type;
+    if (t1 == DM_GEOM_PLANE && t2 == DM_GEOM_MESH) n_pm++;
+    else if (t1 == DM_GEOM_PLANE || (t1 == DM_GEOM_SPHERE && (t2 == DM_GEOM_SPHERE || t2 == DM_GEOM_BOX)) || (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX)) n_an++;
+    else n_mpr++;
     if (t1 == DM_GEOM_PLANE) {
       if (t2 == DM_GEOM_SPHERE) n = np_plane_sphere(rc, A, B.pos, B.size[0]);
       else if (t2 == DM_GEOM_CYLINDER) n = np_plane_cylinder(rc, A, B);
@@ -1109,26 +1187,27 @@ __device__ __forceinline__ int collide(const Dev &T, Lds &S, const Launch &P, co
       else if (t2 == DM_GEOM_MESH && !(P.pad & 128)) n = np_plane_mesh(rc, A, B, lane);
     } else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_SPHERE) n = np_sphere_sphere(rc, A.pos, A.size[0], B.pos, B.size[0]);
     else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_BOX) n = np_sphere_box(rc, A, B);
-    else if (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX) n = np_box_box(rc, A, B, S.poly[0], S.poly[1]);
+    else if (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX) n = np_box_box(rc, A, B, S.u.co.poly[0], S.u.co.poly[1]);
     else if (!(P.pad & 64)) n = np_convex(rc, A, B, lane);
     SYNC();
+    PROF((t1 == DM_GEOM_PLANE && t2 == DM_GEOM_MESH) ? 5 : ((t1 == DM_GEOM_PLANE || (t1 == DM_GEOM_SPHERE && (t2 == DM_GEOM_SPHERE || t2 == DM_GEOM_BOX)) || (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX)) ? 4 : 6));
     for (int k = 0; k < n; k++) {
       if (ncon >= MAXCON) { overflow = 1; continue; }
       if (lane == 0) {
-        S.c_dist[ncon] = (float)rc[k].dist;
+        S.u.co.c_dist[ncon] = (float)rc[k].dist;
         float fr[9] = {(float)rc[k].n[0], (float)rc[k].n[1], (float)rc[k].n[2], 0, 0, 0, 0, 0, 0};
         make_frame(fr);
-        for (int i = 0; i < 3; i++) S.c_pos[ncon][i] = (float)rc[k].pos[i];
-        for (int i = 0; i < 9; i++) S.c_frame[ncon][i] = fr[i];
-        S.c_g1[ncon] = g1; S.c_g2[ncon] = g2;
-        S.c_mu[ncon] = fmaxf(T.g_mu[g1], T.g_mu[g2]);
+        for (int i = 0; i < 3; i++) S.u.co.c_pos[ncon][i] = (float)rc[k].pos[i];
+        for (int i = 0; i < 9; i++) S.u.co.c_frame[ncon][i] = fr[i];
+        S.u.co.c_g1[ncon] = g1; S.u.co.c_g2[ncon] = g2;
+        S.u.co.c_mu[ncon] = fmaxf(T.g_mu[g1], T.g_mu[g2]);
       }
       ncon++;
     }
     SYNC();
   }
   SYNC();
-  if (lane == 0) { S.info[0] = ncon; S.info[4] = overflow; S.info[5] = nsurv; }
+  if (lane == 0) { S.info[0] = ncon; S.info[4] = overflow; S.info[5] = nsurv; S.info[6] = n_an | (n_pm << 8) | (n_mpr << 16); }
   return ncon;
 }
 
@@ -1147,7 +1226,9 @@ __device__ __forceinline__ float impedance(const float *solimp, float pos, float
 }
 
 // rows -> J^T (global, dof-major), R, aref; returns nefc.  Order: friction loss (dof order), limits (joint order), contacts.
-__device__ int make_constraint(const Dev &T, Lds &S, float *JT, const int ncon, const int lane) {
+__device__ __noinline__ int make_constraint(const Dev &T, float *JT, float *RW, const int ncon, const int lane) {
+  float *e_R = RW, *e_b = RW + MAXROW, *e_f = RW + 2 * MAXROW, *e_lim = RW + 3 * MAXROW;
+  int32_t *e_meta = (int32_t *)(RW + 4 * MAXROW);
   // friction-loss rows: dofs 6..42 -> rows 0..36
   int nefc = 0;
   for (int k = 6; k < NV; k++) {   // (all hinges of this model carry friction loss; the table says which)
@@ -1160,11 +1241,11 @@ __device__ int make_constraint(const Dev &T, Lds &S, float *JT, const int ncon, 
     int r = 0;
     for (int q = 6; q < k; q++) r += T.d_floss[q] > 0;
     if (T.d_floss[k] > 0) {
-      S.e_meta[r] = ROW_FRICTION | (k << 2);
-      S.e_lim[r] = T.d_floss[k];
+      e_meta[r] = ROW_FRICTION | (k << 2);
+      e_lim[r] = T.d_floss[k];
       const float imp = impedance(T.solimp, 0.f, 0.f);
-      S.e_R[r] = fmaxf(MINVALF, (1 - imp) * T.d_invw[k] / imp);
-      S.e_b[r] = -T.B * S.qvel[k];   // aref (K = 0 for friction rows)
+      e_R[r] = fmaxf(MINVALF, (1 - imp) * T.d_invw[k] / imp);
+      e_b[r] = -T.B * S.qvel[k];   // aref (K = 0 for friction rows)
     }
   }
   // joint limits
@@ -1187,12 +1268,12 @@ __device__ int make_constraint(const Dev &T, Lds &S, float *JT, const int ncon, 
         if (!(side ? hi : lo)) continue;
         if (r < MAXROW) {
           const float dist = side ? dhi : dlo;
-          S.e_meta[r] = ROW_LIMIT | (k << 2) | (side << 12);
-          S.e_lim[r] = 0;
+          e_meta[r] = ROW_LIMIT | (k << 2) | (side << 12);
+          e_lim[r] = 0;
           const float imp = impedance(T.solimp, dist, 0.f);
-          S.e_R[r] = fmaxf(MINVALF, (1 - imp) * T.d_invw[k] / imp);
+          e_R[r] = fmaxf(MINVALF, (1 - imp) * T.d_invw[k] / imp);
           const float jv = side ? -1.f : 1.f;
-          S.e_b[r] = -T.B * (jv * S.qvel[k]) - T.K * imp * dist;
+          e_b[r] = -T.B * (jv * S.qvel[k]) - T.K * imp * dist;
         }
         r++;
       }
@@ -1211,23 +1292,23 @@ __device__ int make_constraint(const Dev &T, Lds &S, float *JT, const int ncon, 
     for (int r = lane; r < nefc; r += 64) JT[k * MAXROW + r] = 0.f;
   SYNC();
   for (int r = lane; r < row0; r += 64) {
-    const int meta = S.e_meta[r], k = (meta >> 2) & 0x3FF, type = meta & 3;
+    const int meta = e_meta[r], k = (meta >> 2) & 0x3FF, type = meta & 3;
     JT[k * MAXROW + r] = (type == ROW_FRICTION) ? 1.f : (((meta >> 12) & 1) ? -1.f : 1.f);
   }
   for (int c = 0; c < kept; c++) {
-    const int b1 = T.g_body[S.c_g1[c]], b2 = T.g_body[S.c_g2[c]];
-    const float mu = S.c_mu[c];
+    const int b1 = T.g_body[S.u.co.c_g1[c]], b2 = T.g_body[S.u.co.c_g2[c]];
+    const float mu = S.u.co.c_mu[c];
     const int r0 = row0 + 4 * c;
     if (lane < NV) {
       const int k = lane;
       const bool in1 = (T.b_chain[b1] >> k) & 1, in2 = (T.b_chain[b2] >> k) & 1;
       float j[3] = {0, 0, 0};
       if (in1 != in2) {
-        float off[3] = {S.c_pos[c][0] - S.com[0], S.c_pos[c][1] - S.com[1], S.c_pos[c][2] - S.com[2]}, t[3];
+        float off[3] = {S.u.co.c_pos[c][0] - S.com[0], S.u.co.c_pos[c][1] - S.com[1], S.u.co.c_pos[c][2] - S.com[2]}, t[3];
         cross3(t, S.cdof[k], off);
         for (int i = 0; i < 3; i++) j[i] = (in2 ? 1.f : -1.f) * (S.cdof[k][3 + i] + t[i]);
       }
-      const float *fr = S.c_frame[c];
+      const float *fr = S.u.co.c_frame[c];
       const float j0 = fr[0] * j[0] + fr[1] * j[1] + fr[2] * j[2], j1 = fr[3] * j[0] + fr[4] * j[1] + fr[5] * j[2],
                   j2 = fr[6] * j[0] + fr[7] * j[1] + fr[8] * j[2];
       JT[k * MAXROW + r0] = j0 + mu * j1; JT[k * MAXROW + r0 + 1] = j0 - mu * j1;
@@ -1235,13 +1316,13 @@ __device__ int make_constraint(const Dev &T, Lds &S, float *JT, const int ncon, 
     }
     if (lane == 0) {
       const float tran = T.b_invw[b1] + T.b_invw[b2], diag = tran + mu * mu * tran;
-      const float imp = impedance(T.solimp, S.c_dist[c], 0.f);
+      const float imp = impedance(T.solimp, S.u.co.c_dist[c], 0.f);
       const float R0 = fmaxf(MINVALF, (1 - imp) * diag / imp), Rpy = 2.f * mu * mu * R0;
       for (int e = 0; e < 4; e++) {
-        S.e_meta[r0 + e] = ROW_CONTACT | (c << 2);
-        S.e_lim[r0 + e] = 0;
-        S.e_R[r0 + e] = Rpy;
-        S.e_f[r0 + e] = imp;   // parked: aref needs the row velocity, computed below
+        e_meta[r0 + e] = ROW_CONTACT | (c << 2);
+        e_lim[r0 + e] = 0;
+        e_R[r0 + e] = Rpy;
+        e_f[r0 + e] = imp;   // parked: aref needs the row velocity, computed below
       }
     }
   }
@@ -1250,16 +1331,69 @@ __device__ int make_constraint(const Dev &T, Lds &S, float *JT, const int ncon, 
   for (int r = row0 + lane; r < nefc; r += 64) {
     float vel = 0;
     for (int k = 0; k < NV; k++) vel += JT[k * MAXROW + r] * S.qvel[k];
-    const int c = (S.e_meta[r] >> 2);
-    S.e_b[r] = -T.B * vel - T.K * S.e_f[r] * S.c_dist[c];
+    const int c = (e_meta[r] >> 2);
+    e_b[r] = -T.B * vel - T.K * e_f[r] * S.u.co.c_dist[c];
   }
   if (lane == 0) { S.info[1] = nefc; S.info[2] = nlimit; if (kept < ncon) S.info[4] = 1; }
   SYNC();
   return nefc;
 }
 
-// A = J M^-1 J^T + R in the per-env scratch; B^T = D^-1/2 L^-T J^T (dof-major)
-__device__ void project_constraint(const Dev &T, Lds &S, const float *JT, float *BT, float *AR, const int nefc, const int lane) {
+// x <- L^-T x for one constraint row held in registers: the dof tree is compile-time (dm_g1_topology.h), so every index is
+// static; the factor entries are wave-uniform LDS reads
+template <int I, int J, int OFF>
+struct RowAnc {
+  static __device__ __forceinline__ void run(float (&x)[NV], const float xi, const float *L) {
+    if constexpr (J >= 0) {
+      x[J] = fmaf(-L[g1topo::MADR[I] + OFF], xi, x[J]);
+      RowAnc<I, (J >= 0 ? g1topo::PARENT[J >= 0 ? J : 0] : -1), OFF + 1>::run(x, xi, L);
+    }
+  }
+};
+template <int I>
+struct RowSolve {
+  static __device__ __forceinline__ void run(float (&x)[NV], const float *L) {
+    RowAnc<I, g1topo::PARENT[I], 1>::run(x, x[I], L);
+    if constexpr (I > 0) RowSolve<I - 1>::run(x, L);
+  }
+};
+__device__ __forceinline__ float bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// A = J M^-1 J^T + R into the per-env scratch.  Up to 128 rows: lane r (and r + 64) keeps its row of B = D^-1/2 L^-T J^T in
+// 43 registers (solved with static indices), and A[i][:] is 43 broadcasts of row i (v_readlane: scalar operands) times the
+// lanes' own rows — no memory traffic except J in and A out.  More rows: the general path through the B^T scratch.
+__device__ __noinline__ void project_constraint(const Dev &T, const float *JT, float *BT, float *AR, const float *RW,
+                                                const int nefc, const int lane) {
+  const float *e_R = RW;
+  if (nefc <= 128) {
+    float x0[NV], x1[NV];
+    const bool two = nefc > 64;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      x0[k] = (lane < nefc) ? JT[k * MAXROW + lane] : 0.f;
+      x1[k] = (two && lane + 64 < nefc) ? JT[k * MAXROW + lane + 64] : 0.f;
+    }
+    RowSolve<NV - 1>::run(x0, S.qLD);
+    if (two) RowSolve<NV - 1>::run(x1, S.qLD);
+#pragma unroll
+    for (int k = 0; k < NV; k++) { const float d = S.dsq[k]; x0[k] *= d; x1[k] *= d; }
+    const float r0 = (lane < nefc) ? e_R[lane] : 0.f, r1 = (two && lane + 64 < nefc) ? e_R[lane + 64] : 0.f;
+    for (int i = 0; i < nefc; i++) {
+      const int l = i & 63;
+      float s0 = 0, s1 = 0;
+      if (i < 64) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) { const float b = bcast(x0[k], l); s0 = fmaf(b, x0[k], s0); s1 = fmaf(b, x1[k], s1); }
+      } else {
+#pragma unroll
+        for (int k = 0; k < NV; k++) { const float b = bcast(x1[k], l); s0 = fmaf(b, x0[k], s0); s1 = fmaf(b, x1[k], s1); }
+      }
+      if (lane < nefc) AR[i * MAXROW + lane] = s0 + ((i == lane) ? r0 : 0.f);
+      if (two && lane + 64 < nefc) AR[i * MAXROW + lane + 64] = s1 + ((i == lane + 64) ? r1 : 0.f);
+    }
+    SYNC();
+    return;
+  }
   for (int r = lane; r < nefc; r += 64) {   // each lane solves its own row: x <- D^-1/2 L^-T x
     for (int k = 0; k < NV; k++) BT[k * MAXROW + r] = JT[k * MAXROW + r];
     for (int i = NV - 1; i >= 0; i--) {
@@ -1276,14 +1410,16 @@ __device__ void project_constraint(const Dev &T, Lds &S, const float *JT, float 
     for (int j = lane; j < nefc; j += 64) {
       float s = 0;
       for (int k = 0; k < NV; k++) s += BT[k * MAXROW + i] * BT[k * MAXROW + j];
-      if (i == j) s += S.e_R[i];
+      if (i == j) s += e_R[i];
       AR[i * MAXROW + j] = s;
     }
   SYNC();
 }
 
 // [EXT] mj_fwdConstraint + mj_solPGS: dual PGS, rows unilateral (limits, pyramid edges) or boxed (friction loss)
-__device__ void fwd_constraint(const Dev &T, Lds &S, const float *JT, const float *AR, const int nefc, const int lane, const int max_iter) {
+__device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const float *AR, float *RW, const int nefc, const int lane, const int max_iter) {
+  float *e_R = RW, *e_b = RW + MAXROW, *e_f = RW + 2 * MAXROW, *e_lim = RW + 3 * MAXROW;
+  const int32_t *e_meta = (const int32_t *)(RW + 4 * MAXROW);
   if (nefc == 0) {
     if (lane < NV) { S.qacc[lane] = S.qas[lane]; S.warm[lane] = S.qas[lane]; S.qfc[lane] = 0; }
     if (lane == 0) S.info[3] = 0;
@@ -1294,14 +1430,14 @@ __device__ void fwd_constraint(const Dev &T, Lds &S, const float *JT, const floa
   for (int r = lane; r < nefc; r += 64) {
     float s = 0, w = 0;
     for (int k = 0; k < NV; k++) { const float j = JT[k * MAXROW + r]; s += j * S.qas[k]; w += j * S.warm[k]; }
-    const float aref = S.e_b[r], jar = w - aref, D = 1.f / S.e_R[r];
+    const float aref = e_b[r], jar = w - aref, D = 1.f / e_R[r];
     float f;
-    if ((S.e_meta[r] & 3) == ROW_FRICTION) {
-      const float fl = S.e_lim[r], rf = S.e_R[r] * fl;
+    if ((e_meta[r] & 3) == ROW_FRICTION) {
+      const float fl = e_lim[r], rf = e_R[r] * fl;
       f = jar <= -rf ? fl : (jar >= rf ? -fl : -D * jar);
     } else f = jar < 0 ? -D * jar : 0.f;
-    S.e_b[r] = s - aref;
-    S.e_f[r] = f;
+    e_b[r] = s - aref;
+    e_f[r] = f;
   }
   SYNC();
   const int nr = (nefc + 63) >> 6;   // rows per lane (<= 4)
@@ -1312,85 +1448,131 @@ __device__ void fwd_constraint(const Dev &T, Lds &S, const float *JT, const floa
     const int r = lane + 64 * m;
     if (m < nr && r < nefc) {
       float s = 0;
-      for (int c = 0; c < nefc; c++) s += AR[c * MAXROW + r] * S.e_f[c];
-      fr[m] = S.e_f[r];
-      cost += fr[m] * (0.5f * s + S.e_b[r]);
-      res[m] = S.e_b[r] + s;
+      for (int c = 0; c < nefc; c++) s += AR[c * MAXROW + r] * e_f[c];
+      fr[m] = e_f[r];
+      cost += fr[m] * (0.5f * s + e_b[r]);
+      res[m] = e_b[r] + s;
       diag[m] = AR[r * MAXROW + r];
     }
   }
   cost = wsum(cost);
   if (cost > 0) {
 #pragma unroll
-    for (int m = 0; m < 4; m++) { const int r = lane + 64 * m; if (m < nr && r < nefc) { fr[m] = 0; res[m] = S.e_b[r]; } }
+    for (int m = 0; m < 4; m++) { const int r = lane + 64 * m; if (m < nr && r < nefc) { fr[m] = 0; res[m] = e_b[r]; } }
   }
+  // the rows' type / bound live in registers of the owning lane; A rows are fetched sixteen sweep-steps ahead (the
+  // per-env A scratch is L2-resident: one exposed round trip per block of rows instead of one per row)
+  float lm[4] = {-1, -1, -1, -1}, dinv[4] = {1, 1, 1, 1};   // friction-loss bound (< 0: unilateral row), 1 / A_ii
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const int r = lane + 64 * m;
+    if (m < nr && r < nefc) { lm[m] = ((e_meta[r] & 3) == ROW_FRICTION) ? e_lim[r] : -1.f; dinv[m] = 1.f / diag[m]; }
+  }
+  PROF(11);
+  constexpr int PF = 16;
   int iter = 0;
+  // One sweep step for a row owned by lane `src` of register set M: the owner's residual, force, A_ii, 1 / A_ii and bound
+  // are broadcast (v_readlane with a uniform lane) and EVERY lane computes the new force — no divergent branch and no LDS
+  // permute in the sweep's dependent chain; then one FMA per resident row set on the residuals.
+#define PGS_STEP(M, SRC, A0, A1)                                                                   \
+  {                                                                                                \
+    const float rs_ = bcast(res[M], SRC), old_ = bcast(fr[M], SRC), ai_ = bcast(dinv[M], SRC);     \
+    const float fl_ = bcast(lm[M], SRC), aii_ = bcast(diag[M], SRC);                               \
+    float f_ = fmaf(-rs_, ai_, old_);                                                              \
+    f_ = (fl_ >= 0.f) ? fminf(fmaxf(f_, -fl_), fl_) : fmaxf(f_, 0.f);                              \
+    const float dl_ = f_ - old_;                                                                   \
+    improvement -= dl_ * fmaf(0.5f * dl_, aii_, rs_);                                              \
+    fr[M] = (lane == (SRC)) ? f_ : fr[M];                                                          \
+    res[0] = fmaf(A0, dl_, res[0]);                                                                \
+    res[1] = fmaf(A1, dl_, res[1]);                                                                \
+    if (nr > 2 && dl_ != 0.f) {                                                                    \
+      const float *row_ = AR + ((SRC) + 64 * M) * MAXROW;                                          \
+      if (lane + 128 < nefc) res[2] += row_[lane + 128] * dl_;                                     \
+      if (nr > 3 && lane + 192 < nefc) res[3] += row_[lane + 192] * dl_;                           \
+    }                                                                                              \
+  }
+  const int n0 = nefc < 64 ? nefc : 64, n1 = nefc < 128 ? nefc : 128;
   while (iter < max_iter) {
     float improvement = 0;
-    for (int i = 0; i < nefc; i++) {
-      const int m = i >> 6, src = i & 63;
-      float dl = 0;
-      if (lane == src) {
-        const float old = (m == 0) ? fr[0] : (m == 1) ? fr[1] : (m == 2) ? fr[2] : fr[3];
-        const float rs = (m == 0) ? res[0] : (m == 1) ? res[1] : (m == 2) ? res[2] : res[3];
-        const float aii = (m == 0) ? diag[0] : (m == 1) ? diag[1] : (m == 2) ? diag[2] : diag[3];
-        float f = old - rs / aii;
-        if ((S.e_meta[i] & 3) == ROW_FRICTION) { const float fl = S.e_lim[i]; f = fminf(fmaxf(f, -fl), fl); }
-        else if (f < 0) f = 0;
-        dl = f - old;
-        improvement -= 0.5f * dl * dl * aii + dl * rs;
-        if (m == 0) fr[0] = f; else if (m == 1) fr[1] = f; else if (m == 2) fr[2] = f; else fr[3] = f;
-      }
-      dl = __shfl(dl, src);
-      if (dl != 0.f) {
-        const float *row = AR + i * MAXROW;
+    for (int i0 = 0; i0 < n0; i0 += PF) {      // rows 0..63: register set 0
+      float a0[PF], a1[PF];
 #pragma unroll
-        for (int mm = 0; mm < 4; mm++) {
-          const int r = lane + 64 * mm;
-          if (mm < nr && r < nefc) res[mm] += row[r] * dl;
-        }
+      for (int q = 0; q < PF; q++) {
+        const int i = i0 + q;
+        a0[q] = (i < n0 && lane < nefc) ? AR[i * MAXROW + lane] : 0.f;
+        a1[q] = (nr > 1 && i < n0 && lane + 64 < nefc) ? AR[i * MAXROW + lane + 64] : 0.f;
       }
+#pragma unroll
+      for (int q = 0; q < PF; q++)
+        if (i0 + q < n0) PGS_STEP(0, i0 + q, a0[q], a1[q])
+    }
+    for (int i0 = 64; i0 < n1; i0 += PF) {     // rows 64..127: register set 1
+      float a0[PF], a1[PF];
+#pragma unroll
+      for (int q = 0; q < PF; q++) {
+        const int i = i0 + q;
+        a0[q] = (i < n1) ? AR[i * MAXROW + lane] : 0.f;
+        a1[q] = (i < n1 && lane + 64 < nefc) ? AR[i * MAXROW + lane + 64] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < PF; q++)
+        if (i0 + q < n1) PGS_STEP(1, i0 + q - 64, a0[q], a1[q])
+    }
+    for (int i = 128; i < nefc; i++) {         // rows 128..255 (rare): straight from the scratch
+      const float *row = AR + i * MAXROW;
+      const float x0 = (lane < nefc) ? row[lane] : 0.f, x1 = (lane + 64 < nefc) ? row[lane + 64] : 0.f;
+      if (i < 192) PGS_STEP(2, i - 128, x0, x1) else PGS_STEP(3, i - 192, x0, x1)
     }
     iter++;
-    improvement = wsum(improvement);
-    if (improvement * T.pgs_scale < T.tolerance) break;
+    if (improvement * T.pgs_scale < T.tolerance) break;   // (uniform: every lane accumulated the same sum)
   }
+#undef PGS_STEP
+  PROF(12);
 #pragma unroll
-  for (int m = 0; m < 4; m++) { const int r = lane + 64 * m; if (m < nr && r < nefc) S.e_f[r] = fr[m]; }
+  for (int m = 0; m < 4; m++) { const int r = lane + 64 * m; if (m < nr && r < nefc) e_f[r] = fr[m]; }
   SYNC();
   // qfrc_constraint = J^T f
   for (int k = 0; k < NV; k++) {
     float s = 0;
-    for (int r = lane; r < nefc; r += 64) s += JT[k * MAXROW + r] * S.e_f[r];
+    for (int r = lane; r < nefc; r += 64) s += JT[k * MAXROW + r] * e_f[r];
     s = wsum(s);
     if (lane == 0) { S.qfc[k] = s; S.tmp[k] = s; }
   }
   SYNC();
-  solve_m(T, S, S.tmp, lane);
+  solve_m(T, S.tmp, lane);
   SYNC();
   if (lane < NV) { const float a = S.tmp[lane] + S.qas[lane]; S.qacc[lane] = a; S.warm[lane] = a; }
   if (lane == 0) S.info[3] = iter;
   SYNC();
 }
 
-__device__ __noinline__ void forward(const Launch &P, const Dev &T, Lds &S, const int env, const int lane) {
+__device__ __noinline__ void forward(const Launch &P, const Dev &T, const int env, const int lane) {
   float *JT = P.jt + (size_t)env * 44 * MAXROW, *BT = P.bt + (size_t)env * 44 * MAXROW, *AR = P.ar + (size_t)env * MAXROW * MAXROW;
-  kinematics(T, S, lane);
-  com_pos(T, S, lane);
-  crb_factor(T, S, lane);
+  float *RW = P.rows + (size_t)env * 5 * MAXROW;
+  PROF(15);
+  kinematics(T, lane);
+  com_pos(T, lane);
+  PROF(0);
+  crb_factor(T, lane);
+  PROF(1);
+  fwd_smooth(T, lane);   // before the collision stage: its scratch shares LDS with the contact arrays
+  PROF(2);
   int ncon = 0;
-  if (!(P.pad & 2)) ncon = collide(T, S, P, lane);
+  if (!(P.pad & 2)) ncon = collide(T, P, lane);
   else { if (lane == 0) { S.info[0] = 0; S.info[4] = 0; } SYNC(); }
   int nefc = 0;
-  if (!(P.pad & 8)) nefc = make_constraint(T, S, JT, ncon, lane);
+  PROF(7);
+  if (!(P.pad & 8)) nefc = make_constraint(T, JT, RW, ncon, lane);
   else { if (lane == 0) { S.info[1] = 0; S.info[2] = 0; } SYNC(); }
-  if (!(P.pad & 4)) project_constraint(T, S, JT, BT, AR, nefc, lane);
-  fwd_smooth(T, S, lane);
+  PROF(8);
+  if (!(P.pad & 4)) project_constraint(T, JT, BT, AR, RW, nefc, lane);
+  PROF(9);
   if (P.pad & 16) nefc = 0;
-  fwd_constraint(T, S, JT, AR, nefc, lane, (P.pad & 1) ? 0 : T.iterations);
+  fwd_constraint(T, JT, AR, RW, nefc, lane, (P.pad & 1) ? 0 : T.iterations);
+  PROF(10);
 }
 
-__device__ void integrate_pos(Lds &S, const float *q0, const float *vel, const float h, const int lane) {   // [EXT] mj_integratePos
+__device__ void integrate_pos(const float *q0, const float *vel, const float h, const int lane) {   // [EXT] mj_integratePos
   if (lane == 0) {
     for (int i = 0; i < 3; i++) S.qpos[i] = q0[i] + h * vel[i];
     float w[3] = {vel[3], vel[4], vel[5]};
@@ -1409,12 +1591,15 @@ __device__ void integrate_pos(Lds &S, const float *q0, const float *vel, const f
 }
 
 extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
-  __shared__ Lds S;
   const int lane = threadIdx.x, env = blockIdx.x;
   if (env >= P.N) return;
   const Dev &T = *P.T;
   const int mode = P.mode;
   if (mode == MODE_RESET && P.mask && !P.mask[env]) return;
+#ifdef G1_PROFILE
+  if (lane == 0) for (int i = 0; i < 16; i++) S.prof[i] = 0;
+  S.prof_t = clock64();
+#endif
   float *st = P.state + (size_t)env * STATE;
   int *sti = (int *)st;
   int idx_curr = sti[S_IDX], ep_len = sti[S_EPLEN], rcnt = sti[S_RCNT];
@@ -1460,7 +1645,7 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
   int stage = 0;   // RK4 stage of the evaluation about to run (MODE_STEP); every other mode runs one evaluation
   for (;;) {
     if (!sim_err) {
-      forward(P, T, S, env, lane);   // the only call site: the evaluation is ~20 k instructions
+      forward(P, T, env, lane);   // the only call site: the evaluation is ~20 k instructions
       if (mode == MODE_STEP && !after_reset) {   // [EXT] mj_step with mj_RungeKutta(4): A = (1/2, 1/2, 1), B = (1/6, 1/3, 1/3, 1/6)
         const float Bw = (stage == 0 || stage == 3) ? 1.f / 6 : 1.f / 3;
         stage_ncon |= ((unsigned)S.info[0] & 0xFF) << (8 * stage); stage_nefc_lo |= ((unsigned)S.info[1] & 0xFF) << (8 * stage);
@@ -1483,14 +1668,14 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
           if (stage < 3) {
             if (lane < NV) S.tmp[lane] = dq;
             SYNC();
-            integrate_pos(S, S.x0q, S.tmp, h, lane);
+            integrate_pos(S.x0q, S.tmp, h, lane);
             if (lane < NV) S.qvel[lane] = S.x0v[lane] + h * dv;
             SYNC();
             stage++;
             continue;
           }
           if (lane < NV) S.qvel[lane] = S.x0v[lane] + h * S.accv[lane];
-          integrate_pos(S, S.x0q, S.accq, h, lane);
+          integrate_pos(S.x0q, S.accq, h, lane);
           SYNC();
         }
       } else if (mode == MODE_FORCED && !after_reset) {
@@ -1521,7 +1706,7 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
                             cv[0] * Sc, cv[1] * Sc, cv[2] * Sc};
       float rf = 0, lf = 0;
       for (int c = 0; c < S.info[0]; c++) {
-        const int g1 = S.c_g1[c], g2 = S.c_g2[c];
+        const int g1 = S.u.co.c_g1[c], g2 = S.u.co.c_g2[c];
         const bool fl = g1 == T.floor_geom || g2 == T.floor_geom;
         if ((g1 == T.rfoot_geom || g2 == T.rfoot_geom) && fl) rf = 1;
         if ((g1 == T.lfoot_geom || g2 == T.lfoot_geom) && fl) lf = 1;
@@ -1596,15 +1781,16 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
       float *dbg = P.debug + (size_t)env * DMG1_DEBUG_STRIDE;
       for (int i = lane; i < NB * 3; i += 64) dbg[i] = (&S.xpos[0][0])[i];
       if (lane < NV) { dbg[117 + lane] = S.qas[lane]; dbg[160 + lane] = S.qacc[lane]; }
-      if (lane == 0) { dbg[203] = S.info[0]; dbg[204] = S.info[1]; dbg[205] = S.info[3]; dbg[206] = S.info[2]; dbg[207] = S.info[4];
+      if (lane == 0) { dbg[1008] = (float)S.info[5]; dbg[1009] = (float)(S.info[6] & 0xFF); dbg[1010] = (float)((S.info[6] >> 8) & 0xFF); dbg[1011] = (float)((S.info[6] >> 16) & 0xFF);
+                       dbg[203] = S.info[0]; dbg[204] = S.info[1]; dbg[205] = S.info[3]; dbg[206] = S.info[2]; dbg[207] = S.info[4];
                        for (int i = 0; i < 4; i++) { dbg[1000 + i] = (float)((stage_ncon >> (8 * i)) & 0xFF); dbg[1004 + i] = (float)((stage_nefc_lo >> (8 * i)) & 0xFF); } }
       if (lane < MAXCON) {
         float *o = dbg + 208 + 9 * lane;
         const bool on = lane < S.info[0];
-        o[0] = on ? S.c_dist[lane] : 0.f; o[1] = on ? (float)S.c_g1[lane] : -1.f; o[2] = on ? (float)S.c_g2[lane] : -1.f;
-        for (int i = 0; i < 3; i++) { o[3 + i] = on ? S.c_pos[lane][i] : 0.f; o[6 + i] = on ? S.c_frame[lane][i] : 0.f; }
+        o[0] = on ? S.u.co.c_dist[lane] : 0.f; o[1] = on ? (float)S.u.co.c_g1[lane] : -1.f; o[2] = on ? (float)S.u.co.c_g2[lane] : -1.f;
+        for (int i = 0; i < 3; i++) { o[3 + i] = on ? S.u.co.c_pos[lane][i] : 0.f; o[6 + i] = on ? S.u.co.c_frame[lane][i] : 0.f; }
       }
-      for (int r = lane; r < MAXROW; r += 64) dbg[640 + r] = (r < S.info[1]) ? S.e_f[r] : 0.f;
+      for (int r = lane; r < MAXROW; r += 64) dbg[640 + r] = (r < S.info[1]) ? P.rows[(size_t)env * 5 * MAXROW + 2 * MAXROW + r] : 0.f;
     }
     if (task_pass) {
       if (P.rew && lane == 0) P.rew[env] = reward;
@@ -1637,6 +1823,11 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
     }
     break;
   }
+#ifdef G1_PROFILE
+  PROF(14);
+  SYNC();
+  if (P.debug && lane < 16) P.debug[(size_t)env * DMG1_DEBUG_STRIDE + 900 + lane] = (float)S.prof[lane];
+#endif
   if (lane < NQ) st[S_QPOS + lane] = S.qpos[lane];
   if (lane < NV) { st[S_QVEL + lane] = S.qvel[lane]; st[S_WARM + lane] = S.warm[lane]; }
   if (lane < NU) st[S_CTRL + lane] = S.ctrl[lane];
@@ -1664,7 +1855,7 @@ struct DmG1Engine {
   g1::Dev *dT = nullptr;
   double *dMesh = nullptr, *dClus = nullptr;
   int32_t *dOidx = nullptr;
-  float *dState = nullptr, *dJT = nullptr, *dBT = nullptr, *dAR = nullptr;
+  float *dState = nullptr, *dJT = nullptr, *dBT = nullptr, *dAR = nullptr, *dRowsE = nullptr;
   float *dRows = nullptr, *dReset = nullptr, *dCom = nullptr, *dDebug = nullptr;
   int L = 0, flags = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1757,7 +1948,12 @@ static void g1_build_tables(const DmModelG1 &m, g1::Dev &T) {
     }
     for (int i = 0; i < 3; i++) { T.g_bc[g][i] = (float)(0.5 * (lo[i] + hi[i])); T.g_bh[g][i] = (float)(0.5 * (hi[i] - lo[i]) * 1.00001 + 1e-6); }
   }
-  for (int p = 0; p < m.npair; p++) { T.p_g1[p] = (int16_t)m.pair_geom1[p]; T.p_g2[p] = (int16_t)m.pair_geom2[p]; }
+  for (int g = 0; g < 96; g++) T.g_ci[g] = -1;
+  int nci = 0;
+  for (int p = 0; p < m.npair; p++) {
+    T.p_g1[p] = (int16_t)m.pair_geom1[p]; T.p_g2[p] = (int16_t)m.pair_geom2[p];
+    for (int q = 0; q < 2; q++) { const int g = q ? m.pair_geom2[p] : m.pair_geom1[p]; if (T.g_ci[g] < 0 && nci < NCG) T.g_ci[g] = nci++; }
+  }
   for (int i = 0; i < DM_NMESH; i++)
     for (int k = 0; k < 3; k++) T.m_center[i][k] = m.mesh_center[i][k];   // vertex / cluster ranges: g1_build_meshes
   int p = 0;
@@ -1765,51 +1961,53 @@ static void g1_build_tables(const DmModelG1 &m, g1::Dev &T) {
     for (int a = 0; a <= b && p < 128; a++) { T.tri_a[p] = (uint8_t)a; T.tri_b[p] = (uint8_t)b; p++; }
 }
 
-// Reorder every hull into clusters of 64 vertices that are close on the unit sphere of directions (latitude bands of equal
-// count, split by azimuth), with a bounding sphere per cluster; a mesh starts at a multiple of 64 so clusters never straddle.
+// Reorder every hull into compact clusters: a k-d partition (median split along the longest extent) down to leaves of at
+// most 64 vertices; a leaf occupies 64 vertex slots (unused slots carry the invalid original index 0x7fffffff) and has a
+// bounding sphere around the mean of its vertices.
+static void g1_kd_split(const DmModelG1 &m, int a0, std::vector<int> &idx, int lo, int hi, std::vector<std::pair<int, int>> &leaves) {
+  if (hi - lo <= 64) { leaves.push_back({lo, hi}); return; }
+  double mn[3] = {1e30, 1e30, 1e30}, mx[3] = {-1e30, -1e30, -1e30};
+  for (int k = lo; k < hi; k++)
+    for (int i = 0; i < 3; i++) { mn[i] = fmin(mn[i], m.mesh_vert[a0 + idx[k]][i]); mx[i] = fmax(mx[i], m.mesh_vert[a0 + idx[k]][i]); }
+  int ax = 0;
+  for (int i = 1; i < 3; i++) if (mx[i] - mn[i] > mx[ax] - mn[ax]) ax = i;
+  const int mid = (lo + hi) / 2;
+  std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi, [&](int p, int q) {
+    const double vp = m.mesh_vert[a0 + p][ax], vq = m.mesh_vert[a0 + q][ax];
+    return vp < vq || (vp == vq && p < q);
+  });
+  g1_kd_split(m, a0, idx, lo, mid, leaves);
+  g1_kd_split(m, a0, idx, mid, hi, leaves);
+}
 static void g1_build_meshes(const DmModelG1 &m, g1::Dev &T, std::vector<double> &verts, std::vector<int32_t> &oidx,
                             std::vector<double> &clus) {
-  struct VS { double uz, az; int idx; };
   int vadr = 0, cadr = 0;
   for (int me = 0; me < DM_NMESH; me++) {
     const int n = m.mesh_vertnum[me], a0 = m.mesh_vertadr[me];
-    T.m_vadr[me] = vadr; T.m_vnum[me] = n; T.m_cadr[me] = cadr; T.m_cnum[me] = (n + 63) / 64;
+    T.m_vadr[me] = vadr; T.m_cadr[me] = cadr; T.m_vnum[me] = 0; T.m_cnum[me] = 0;
     if (n == 0) continue;
-    std::vector<VS> vs(n);
-    for (int k = 0; k < n; k++) {
-      double u[3] = {m.mesh_vert[a0 + k][0] - m.mesh_center[me][0], m.mesh_vert[a0 + k][1] - m.mesh_center[me][1],
-                     m.mesh_vert[a0 + k][2] - m.mesh_center[me][2]};
-      const double nn = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-      vs[k] = {nn > 0 ? u[2] / nn : 0.0, atan2(u[1], u[0]), k};
-    }
-    std::sort(vs.begin(), vs.end(), [](const VS &a, const VS &b) { return a.uz < b.uz || (a.uz == b.uz && a.idx < b.idx); });
-    const int nclus = (n + 63) / 64;
-    int nb = (int)lround(sqrt((double)nclus));
-    if (nb < 1) nb = 1;
-    const int per_band = ((nclus + nb - 1) / nb) * 64;   // vertices per band, a multiple of 64
-    for (int b0 = 0; b0 < n; b0 += per_band) {
-      const int b1 = b0 + per_band < n ? b0 + per_band : n;
-      std::sort(vs.begin() + b0, vs.begin() + b1, [](const VS &a, const VS &b) { return a.az < b.az || (a.az == b.az && a.idx < b.idx); });
-    }
-    for (int k = 0; k < n; k++) {
-      for (int i = 0; i < 3; i++) verts.push_back(m.mesh_vert[a0 + vs[k].idx][i]);
-      oidx.push_back(vs[k].idx);
-    }
-    for (int c = 0; c < nclus; c++) {
-      const int k0 = 64 * c, k1 = k0 + 64 < n ? k0 + 64 : n;
+    std::vector<int> idx(n);
+    for (int k = 0; k < n; k++) idx[k] = k;
+    std::vector<std::pair<int, int>> leaves;
+    g1_kd_split(m, a0, idx, 0, n, leaves);
+    for (auto &lf : leaves) {
       double cc[3] = {0, 0, 0}, rad = 0;
-      for (int k = k0; k < k1; k++) for (int i = 0; i < 3; i++) cc[i] += verts[3 * (size_t)(vadr + k) + i];
-      for (int i = 0; i < 3; i++) cc[i] /= (k1 - k0);
-      for (int k = k0; k < k1; k++) {
+      const int cnt = lf.second - lf.first;
+      for (int k = lf.first; k < lf.second; k++) for (int i = 0; i < 3; i++) cc[i] += m.mesh_vert[a0 + idx[k]][i];
+      for (int i = 0; i < 3; i++) cc[i] /= cnt;
+      for (int k = lf.first; k < lf.second; k++) {
         double d2 = 0;
-        for (int i = 0; i < 3; i++) { const double df = verts[3 * (size_t)(vadr + k) + i] - cc[i]; d2 += df * df; }
+        for (int i = 0; i < 3; i++) { const double df = m.mesh_vert[a0 + idx[k]][i] - cc[i]; d2 += df * df; }
         rad = fmax(rad, sqrt(d2));
+        for (int i = 0; i < 3; i++) verts.push_back(m.mesh_vert[a0 + idx[k]][i]);
+        oidx.push_back(idx[k]);
       }
+      for (int k = cnt; k < 64; k++) { verts.push_back(0); verts.push_back(0); verts.push_back(0); oidx.push_back(0x7fffffff); }
       clus.push_back(cc[0]); clus.push_back(cc[1]); clus.push_back(cc[2]); clus.push_back(rad * (1 + 1e-9) + 1e-12);
     }
-    const int padded = nclus * 64;   // next mesh starts on a cluster boundary
-    for (int k = n; k < padded; k++) { verts.push_back(0); verts.push_back(0); verts.push_back(0); oidx.push_back(0x7fffffff); }
-    vadr += padded; cadr += nclus;
+    const int nclus = (int)leaves.size();
+    T.m_vnum[me] = nclus * 64; T.m_cnum[me] = nclus;
+    vadr += nclus * 64; cadr += nclus;
   }
 }
 
@@ -1830,10 +2028,18 @@ static int g1_check_model(DmG1Engine *e, const DmModelG1 &m) {
     int n = 0;
     for (int j = m.dof_parent[k]; j >= 0; j = m.dof_parent[j]) n++;
     if (n > 14) return g1_fail(e, DM_EINVAL, "dof chain deeper than 14 ancestors");
+    if (m.dof_parent[k] != g1topo::PARENT[k] || m.dof_Madr[k] != g1topo::MADR[k])
+      return g1_fail(e, DM_EINVAL, "dof tree differs from the compiled-in topology (regenerate csrc/dm_g1_topology.h)");
     if (k >= 6 && !(m.dof_frictionloss[k] > 0)) return g1_fail(e, DM_EINVAL, "kernel assumes friction loss on every hinge");
   }
   for (int a = 0; a < NU; a++)
     if (m.act_gear[a] != 1.0) return g1_fail(e, DM_EINVAL, "kernel assumes motor gear 1");
+  {
+    int seen[DM_NGEOM] = {0}, nci = 0;
+    for (int p = 0; p < m.npair; p++) { seen[m.pair_geom1[p]] = 1; seen[m.pair_geom2[p]] = 1; }
+    for (int g = 0; g < NG; g++) nci += seen[g];
+    if (nci > NCG) return g1_fail(e, DM_EINVAL, "more colliding geoms than the kernel's LDS layout holds");
+  }
   for (int g = 0; g < NG; g++) {
     if (m.geom_margin[g] != 0.0) return g1_fail(e, DM_EINVAL, "kernel assumes zero geom margins (xml has none)");
     if (m.geom_mesh[g] >= DM_NMESH) return g1_fail(e, DM_EINVAL, "mesh id out of range");
@@ -1859,7 +2065,7 @@ extern "C" int dmg1_create(const void *model, size_t model_bytes, const DmG1Conf
   std::vector<int32_t> oidx;
   g1_build_meshes(m, *T, verts, oidx, clus);
   for (int me = 0; me < DM_NMESH; me++)
-    if (T->m_cnum[me] > 128) { delete T; delete e; fprintf(stderr, "dmg1_create: a hull has more than 8192 vertices\n"); return DM_EINVAL; }
+    if (T->m_cnum[me] > 192) { delete T; delete e; fprintf(stderr, "dmg1_create: a hull has more than 192 vertex clusters\n"); return DM_EINVAL; }
   bool ok = hipMalloc(&e->dT, sizeof(g1::Dev)) == hipSuccess;
   if (ok) hipMemcpy(e->dT, T, sizeof(g1::Dev), hipMemcpyHostToDevice);
   delete T;
@@ -1876,6 +2082,7 @@ extern "C" int dmg1_create(const void *model, size_t model_bytes, const DmG1Conf
   ok = ok && hipMalloc(&e->dJT, N * 44 * g1::MAXROW * sizeof(float)) == hipSuccess;
   ok = ok && hipMalloc(&e->dBT, N * 44 * g1::MAXROW * sizeof(float)) == hipSuccess;
   ok = ok && hipMalloc(&e->dAR, N * g1::MAXROW * g1::MAXROW * sizeof(float)) == hipSuccess;
+  ok = ok && hipMalloc(&e->dRowsE, N * 5 * g1::MAXROW * sizeof(float)) == hipSuccess;
   if (!ok) { dmg1_destroy(e); return DM_ENOMEM; }
   std::vector<float> init(N * g1::STATE, 0.f);
   for (size_t i = 0; i < N; i++)
@@ -1888,7 +2095,7 @@ extern "C" int dmg1_create(const void *model, size_t model_bytes, const DmG1Conf
 
 extern "C" int dmg1_destroy(DmG1Handle e) {
   if (!e) return DM_EINVAL;
-  hipFree(e->dT); hipFree(e->dMesh); hipFree(e->dOidx); hipFree(e->dClus); hipFree(e->dState); hipFree(e->dJT); hipFree(e->dBT); hipFree(e->dAR);
+  hipFree(e->dT); hipFree(e->dMesh); hipFree(e->dOidx); hipFree(e->dClus); hipFree(e->dState); hipFree(e->dJT); hipFree(e->dBT); hipFree(e->dAR); hipFree(e->dRowsE);
   hipFree(e->dRows); hipFree(e->dReset); hipFree(e->dCom);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
@@ -1933,7 +2140,7 @@ extern "C" int dmg1_load_clip(DmG1Handle e, int L, const double *q, const double
 }
 
 static int g1_launch(DmG1Engine *e, g1::Launch &P, void *stream, bool time_it) {
-  P.T = e->dT; P.mesh_vert = e->dMesh; P.mesh_oidx = e->dOidx; P.mesh_clus = e->dClus; P.state = e->dState; P.jt = e->dJT; P.bt = e->dBT; P.ar = e->dAR;
+  P.T = e->dT; P.mesh_vert = e->dMesh; P.mesh_oidx = e->dOidx; P.mesh_clus = e->dClus; P.state = e->dState; P.jt = e->dJT; P.bt = e->dBT; P.ar = e->dAR; P.rows = e->dRowsE;
   P.clip.rows = e->dRows; P.clip.reset = e->dReset; P.clip.com = e->dCom; P.clip.L = e->L; P.clip.flags = e->flags;
   P.N = e->N; P.auto_reset = e->cfg.auto_reset; P.max_ep_length = e->cfg.max_ep_length;
   P.vel_obs_scale = e->cfg.vel_obs_scale; P.high_z = e->cfg.high_z; P.obs_bound = e->cfg.obs_bound; P.seed = e->cfg.seed;
