@@ -113,6 +113,21 @@ def g1_record(local_rank, n=4096, steps=20, warmup=5):
            "kernel_ms_last": eng.last_kernel_ms(), "done_fraction_last_step": float(out["done"].float().mean()),
            "reference_published_env_steps_per_s": 1390, "note": "auxiliary: SURVEY 8f-2 (next row), not the headline metric"}
     eng.close()
+    # DPCombinedEnv() as src/sb3_ppo.py:277-278 trains it: walk / run / getup state machine on the G1, RSI auto-reset
+    from deepmimic_mujoco_amd.g1 import HipG1CombinedVecEnv
+    venv = HipG1CombinedVecEnv(n, device=local_rank, seed=3)
+    venv.reset_tensor()
+    for t in range(warmup):
+        venv.step_tensor(acts[t % 8] * 0.25)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(steps):
+        o = venv.step_tensor(acts[t % 8] * 0.25)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rec["dp_combined_env"] = {"env_steps_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3,
+                              "done_fraction_last_step": float(o["done"].float().mean()), "mean_reward": float(o["rew"].mean())}
+    venv.close()
     return rec
 
 

@@ -151,7 +151,13 @@ class DPCombinedEnv:
     ENV_CFG = DPCombinedEnvConfig()
     metadata = {"render.modes": []}
 
-    def __init__(self, verbose=0, _profile=False, robot="humanoid3d", getup_motion="getup_facedown", device=0):
+    def __new__(cls, verbose=0, _profile=False, robot="unitree_g1", getup_motion="getup_facedown", device=0):
+        if robot == "unitree_g1" and cls is DPCombinedEnv:   # the reference's own configuration (:165): the G1 engine
+            from .g1 import G1CombinedEnv
+            return G1CombinedEnv(verbose=verbose, _profile=_profile, device=device)
+        return super().__new__(cls)
+
+    def __init__(self, verbose=0, _profile=False, robot="unitree_g1", getup_motion="getup_facedown", device=0):
         import torch
         self._torch = torch
         self.PROFILE = _profile
@@ -295,7 +301,13 @@ class _LazyCombinedInfos:
 class HipCombinedVecEnv(_SB3VecEnv):
     """N DPCombinedEnv instances as one HIP batch with SubprocVecEnv semantics (auto-reset = reset(rsi=True))."""
 
-    def __init__(self, num_envs, robot="humanoid3d", getup_motion="getup_facedown", device=0, seed=1234,
+    def __new__(cls, num_envs, robot="unitree_g1", getup_motion="getup_facedown", device=0, seed=1234, auto_reset=True, **kw):
+        if robot == "unitree_g1" and cls is HipCombinedVecEnv:
+            from .g1 import HipG1CombinedVecEnv
+            return HipG1CombinedVecEnv(num_envs, device=device, seed=seed, auto_reset=auto_reset)
+        return super().__new__(cls)
+
+    def __init__(self, num_envs, robot="unitree_g1", getup_motion="getup_facedown", device=0, seed=1234,
                  auto_reset=True):
         import torch
         self._torch = torch

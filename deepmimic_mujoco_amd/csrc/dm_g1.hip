@@ -36,8 +36,9 @@ namespace g1 {
 constexpr int NQ = 44, NV = 43, NU = 37, NB = 39, NG = 94, NJ = 38, NM = 434, NACT = 23, NOBS = 85, NREW = 23;
 constexpr int MAXCON = DMG1_MAXCON, MAXROW = DMG1_MAXROW, MAXANC = 16, MAXSURV = 384, NCG = 48;   // NCG: geoms that collide (47)
 constexpr int STATE = 176;   // floats per env in the HBM state row
-constexpr int S_QPOS = 0, S_QVEL = 44, S_WARM = 87, S_CTRL = 130, S_IDX = 167, S_EPLEN = 168, S_EPREW = 169, S_RCNT = 170;
-constexpr int CLIP_ROW = 64;  // per frame: 23 reward qpos | 23 reward qvel | root quat 4 | ee geom xpos 12
+constexpr int S_QPOS = 0, S_QVEL = 44, S_WARM = 87, S_CTRL = 130, S_IDX = 167, S_EPLEN = 168, S_EPREW = 169, S_RCNT = 170, S_MOTION = 171;
+constexpr int NOBS_C = DMG1_NOBS_COMBINED;   // DPCombinedEnv: 82 + extra contacts 8 + phase + player-action obs 7
+constexpr int CLIP_ROW = 64;  // per frame: 23 reward qpos | 23 reward qvel | root quat 4 | ee geom xpos 12 | root velocity xy 2
 constexpr float MINVALF = 1e-15f, MAXVALF = 1e10f;
 constexpr double MINVAL = 1e-15;
 enum { MODE_STEP = 0, MODE_FORCED = 1, MODE_RESET = 2, MODE_SETSTATE = 3 };
@@ -46,7 +47,7 @@ enum { ROW_LIMIT = 0, ROW_CONTACT = 2, ROW_FRICTION = 3 };
 struct Dev {   // read-only model tables (global memory, fp32)
   float timestep, tolerance, pgs_scale, K, B, solimp[5], total_mass_inv, gravity[3];
   float low_z, action_scale;
-  int32_t iterations, npair, maxdepth, torso_body, floor_geom, rfoot_geom, lfoot_geom, ee_geom[4];
+  int32_t iterations, npair, maxdepth, torso_body, floor_geom, rfoot_geom, lfoot_geom, ee_geom[4], extra_geom[8];
   int32_t rew_q[NREW], rew_v[NREW], rew_j[NREW];
   float qpos0[NQ];
   int32_t b_parent[40], b_depth[40], b_dof[40];
@@ -116,7 +117,8 @@ struct Launch {
   float *state;              // N x STATE
   float *jt, *bt, *ar;       // per-env scratch: J^T [44][MAXROW], (D^-1/2 L^-T J^T) [44][MAXROW], A [MAXROW][MAXROW]
   float *rows;               // per-env scratch: R, aref -> b, force, friction-loss bound, meta (type | id << 2): [5][MAXROW]
-  ClipDev clip;
+  ClipDev clips[3];          // DPEnv: clips[0]; DPCombinedEnv: walk, run, getup
+  int32_t task, amnesty_steps, to_getup_len, pad2;
   int32_t N, mode, auto_reset, max_ep_length, run_forward, pad;
   float vel_obs_scale, high_z, obs_bound;
   uint64_t seed;
@@ -1604,11 +1606,19 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
   int *sti = (int *)st;
   int idx_curr = sti[S_IDX], ep_len = sti[S_EPLEN], rcnt = sti[S_RCNT];
   float ep_rew = st[S_EPREW];
+  // TASK (DPCombinedEnv, src/combined_env.py): per-env motion 0 walk, 1 run, 2 getup, 3 to_getup; idx_curr is then the
+  // unwrapped current_motion_n_steps
+  const bool TASK = P.task != 0;
+  int motion = TASK ? sti[S_MOTION] : 0;
+  motion = (motion < 0 || motion > 3) ? 0 : motion;
+  const int NOBS_T = TASK ? NOBS_C : NOBS, NTERMS = TASK ? 8 : 5;
+  if (TASK && (P.clips[0].L < 1 || P.clips[1].L < 1 || P.clips[2].L < 2)) return;   // walk, run, getup all needed
+  if (TASK) idx_curr = idx_curr < 0 ? 0 : idx_curr;
   if (lane < NQ) S.qpos[lane] = st[S_QPOS + lane];
   if (lane < NV) { S.qvel[lane] = st[S_QVEL + lane]; S.warm[lane] = st[S_WARM + lane]; }
   if (lane < NU) S.ctrl[lane] = st[S_CTRL + lane];
   SYNC();
-  const ClipDev clip = P.clip;
+  ClipDev clip = P.clips[TASK ? (motion == 3 ? 2 : motion) : 0];
   if (mode == MODE_STEP) {
     if (lane < NU) S.ctrl[lane] = (lane < NACT) ? P.actions[(size_t)env * NACT + lane] * T.action_scale : 0.f;   // :348-351
   } else if (mode == MODE_FORCED || mode == MODE_SETSTATE) {
@@ -1618,9 +1628,20 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
     }
     if (mode == MODE_SETSTATE && P.in_warm && lane < NV) S.warm[lane] = P.in_warm[(size_t)env * NV + lane];
   } else if (mode == MODE_RESET) {
-    int fi = P.idx_init ? P.idx_init[env] : (int)(hash32(P.seed, env, rcnt, 0x5EED) % (uint32_t)clip.L);
-    fi = fi < 0 ? 0 : (fi >= clip.L ? clip.L - 1 : fi);
-    idx_curr = fi;
+    int fi;
+    if (TASK) {   // DPCombinedEnv.reset(rsi=True) (:219-227): walk with amnesty or getup, random frame; idx_init keeps the motion
+      if (P.idx_init) idx_curr = P.idx_init[env] < 0 ? 0 : P.idx_init[env];
+      else {
+        motion = (hash32(P.seed, env, rcnt, 0x5EED) & 1) ? 2 : 0;
+        clip = P.clips[motion];
+        idx_curr = (int)(hash32(P.seed, env, rcnt, 0x5EEE) % (uint32_t)clip.L) + (motion == 0 ? P.amnesty_steps + 10 : 0);
+      }
+      fi = (motion == 3) ? 1 : idx_curr % clip.L;
+    } else {
+      fi = P.idx_init ? P.idx_init[env] : (int)(hash32(P.seed, env, rcnt, 0x5EED) % (uint32_t)clip.L);
+      fi = fi < 0 ? 0 : (fi >= clip.L ? clip.L - 1 : fi);
+      idx_curr = fi;
+    }
     const float *rr = clip.reset + (size_t)fi * 88;
     if (lane < NQ) S.qpos[lane] = rr[lane];
     if (lane < NV) S.qvel[lane] = rr[44 + lane];
@@ -1686,7 +1707,7 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
     // ---- task layer (derived arrays are those of the LAST forward evaluation)
     const bool task_pass = !after_reset && (mode == MODE_STEP || mode == MODE_FORCED);
     float obs_a = 0, obs_b = 0;   // obs[lane], obs[64 + lane]
-    float terms[5] = {0, 0, 0, 0, 0};
+    float terms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (sim_err) {
       reward = 0; done = true; reason = 5;
       SYNC();
@@ -1705,38 +1726,53 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
       const float tor[8] = {rpy[0] * Sc, rpy[1] * Sc, (cy * cv[3] - sy * cv[4]) * Sc, (sy * cv[3] + cy * cv[4]) * Sc, cv[5] * Sc,
                             cv[0] * Sc, cv[1] * Sc, cv[2] * Sc};
       float rf = 0, lf = 0;
+      unsigned xc = 0;   // bit k: extra-contact geom k (foot spheres, src/config.py:19-20) touches the floor
       for (int c = 0; c < S.info[0]; c++) {
         const int g1 = S.u.co.c_g1[c], g2 = S.u.co.c_g2[c];
         const bool fl = g1 == T.floor_geom || g2 == T.floor_geom;
         if ((g1 == T.rfoot_geom || g2 == T.rfoot_geom) && fl) rf = 1;
         if ((g1 == T.lfoot_geom || g2 == T.lfoot_geom) && fl) lf = 1;
+        if (fl) for (int k = 0; k < 8; k++) if (g1 == T.extra_geom[k] || g2 == T.extra_geom[k]) xc |= 1u << k;
       }
-      float ph = (float)idx_curr / (float)clip.L;
+      // motion length / frame: to_getup is a 180-step pseudo clip whose target is frame 1 of getup (combined_env.py:67-99)
+      const int Lm = (TASK && motion == 3) ? P.to_getup_len : clip.L;
+      const int frame = TASK ? ((motion == 3) ? 1 : idx_curr % clip.L) : idx_curr;
+      float ph = TASK ? (float)(idx_curr % Lm) / (float)Lm : (float)idx_curr / (float)clip.L;
       ph = fminf(fmaxf(ph, 0.f), 1.f);
       auto obs_at = [&](int i) -> float {
         if (i < 37) return S.qpos[7 + i];
         if (i < 74) return S.qvel[6 + i - 37] * Sc;
         if (i < 82) return tor[i - 74];
-        if (i == 82) return rf;
-        if (i == 83) return lf;
-        return ph;
+        if (!TASK) return (i == 82) ? rf : (i == 83) ? lf : ph;
+        // DPCombinedEnv._get_obs (:495-505): extra contacts (:27), phase, get_player_action_obs with PAWalk
+        // (heading (1,0,0) in the yaw-aligned torso frame, one-hot index 0), pa_getup_state
+        if (i < 90) return (float)((xc >> (i - 82)) & 1u);
+        if (i == 90) return ph;
+        if (i == 91) return cy;
+        if (i == 92) return sy;
+        if (i == 93) return 1.f;
+        if (i == 96) return (motion == 3) ? 1.f : 0.f;
+        if (i == 97) return (motion == 2) ? 1.f : 0.f;
+        return 0.f;
       };
       obs_a = obs_at(lane);
-      if (lane < NOBS - 64) obs_b = obs_at(64 + lane);
+      if (lane < NOBS_T - 64) obs_b = obs_at(64 + lane);
       if (task_pass) {
         // ---- calc_imitation_reward, unitree_g1 branch (:193-256)
-        const float *cr = clip.rows + (size_t)idx_curr * CLIP_ROW;
-        float e_cfg = 0, e_vel = 0;
+        const float *cr = clip.rows + (size_t)frame * CLIP_ROW;
+        float e_cfg = 0, e_vel = 0, adiff = 0;
         int viol = 0;
         if (lane < NREW) {
           const int qi = T.rew_q[lane], vi = T.rew_v[lane];
           const float q = S.qpos[qi];
           e_cfg = fabsf(q - cr[lane]);
+          adiff = e_cfg;
           e_vel = fabsf(cr[23 + lane] - S.qvel[vi]);
           const int k = vi;
           viol = (q <= T.d_lo[k] * 0.99f) + (q >= T.d_hi[k] * 0.99f);
         }
         e_cfg = wsum(e_cfg); e_vel = wsum(e_vel);
+        const float dsum = e_cfg;
         const float nviol = wsum((float)viol);
         float rc[3], rt[3], cq[4] = {S.qpos[3], S.qpos[4], S.qpos[5], S.qpos[6]}, tqq[4] = {cr[46], cr[47], cr[48], cr[49]};
         quat_to_rpy(cq, rc);
@@ -1749,7 +1785,7 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
         }
         float cc[3];
         for (int i = 0; i < 3; i++) cc[i] = wsum((lane < NB) ? T.b_mass[lane] * S.xpos[lane][i] : 0.f) * T.total_mass_inv;
-        const float *tc = clip.com + (size_t)idx_curr * 4;
+        const float *tc = clip.com + (size_t)frame * 4;
         float ce = 0;
         for (int i = 0; i < 3; i++) { const float df = tc[i] - cc[i]; ce += df * df; }
         terms[0] = expf(-e_cfg); terms[1] = expf(-0.1f * e_vel); terms[2] = expf(-40.f * ee); terms[3] = expf(-10.f * ce);
@@ -1757,6 +1793,38 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
         reward = 0.75f * terms[0] + 0.1f * terms[1] + 0.15f * terms[2] + 0.0f * terms[3] - 0.1f * terms[4];
         // ---- termination (:418-442)
         const float zc = wsum((lane < NB) ? T.b_mass[lane] * S.xipos[lane][2] : 0.f) * T.total_mass_inv;
+        if (TASK) {
+          // ---- DPCombinedEnv: task reward (combined_env.py:338-354), motion state machine + termination (:393-445)
+          const float ALIM = 0.2617993877991494f, MAX_ANGLE = 1.0471975511965976f;   // deg2rad(15), deg2rad(60)
+          const float droll = fabsf(rc[0] - rt[0]), dpitch = fabsf(rc[1] - rt[1]);
+          float imitation = reward, task_r = 0.f;
+          if (motion == 0 || motion == 1) {   // heading + velocity error against the clip's root velocity
+            const float ex = cr[62] - S.qvel[0], ey = cr[63] - S.qvel[1];
+            task_r = expf(-sqrtf(ex * ex + ey * ey) * 10.f);
+          }
+          if (motion == 3) { imitation = 0.f; task_r = expf(-(dsum + dpitch + droll) / 5.f) / 3.f; }
+          reward = imitation * 0.7f + task_r * 0.3f;
+          const unsigned long long badm = __ballot(adiff > ALIM);
+          const bool all_close = !__any(!(adiff < ALIM));   // lanes >= 23 carry 0
+          terms[5] = imitation; terms[6] = task_r;
+          terms[7] = (float)(__popcll(badm) + (dpitch > ALIM ? 1 : 0) + (droll > ALIM ? 1 : 0));   // debug_n_bad_angles
+          done = false; reason = 0;
+          if (idx_curr >= Lm - 1) {   // out of time; :396 compares PlayerAction objects by identity: getup always hands over to run
+            if (motion == 2) { motion = 1; idx_curr = 0; }
+            if (motion == 3) { motion = 2; idx_curr = 0; }
+          }
+          if (dpitch < ALIM && droll < ALIM && all_close && motion == 3) { motion = 2; idx_curr = 0; }
+          if (motion == 0 || motion == 1) {
+            const bool fallen = (zc < T.low_z) || (zc > P.high_z) || (droll > MAX_ANGLE) || (dpitch > MAX_ANGLE);
+            if (fallen) {
+              if (!(idx_curr > P.amnesty_steps)) { done = true; reason = 7; }
+              motion = 3; idx_curr = 0;
+            }
+          }
+          if (P.max_ep_length != 0 && ep_len >= P.max_ep_length) { done = true; reason = 3; }
+          clip = P.clips[motion == 3 ? 2 : motion];
+          idx_curr += 1;   // :454 (not wrapped)
+        } else {
         if (!(clip.flags & 1)) {
           done = (zc < T.low_z) || (zc > P.high_z);
           reason = (zc < T.low_z) ? 1 : 2;
@@ -1768,12 +1836,13 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
         if (P.max_ep_length != 0 && ep_len >= P.max_ep_length) { done = true; reason = 3; }
         if ((clip.flags & 2) && idx_curr + 1 == clip.L) { done = true; reason = 4; }
         idx_curr = (idx_curr + 1) % clip.L;
+        }
         ep_rew += reward;
         ep_len += 1;
         const bool ob = !(fabsf(obs_a) <= P.obs_bound) || !(fabsf(obs_b) <= P.obs_bound);
         if (__any(ob)) {
           obs_a = 0; obs_b = 0; reward = 0; done = true; reason = 6;
-          for (int i = 0; i < 5; i++) terms[i] = 0;
+          for (int i = 0; i < 8; i++) terms[i] = 0;
         }
       }
     }
@@ -1796,15 +1865,23 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
       if (P.rew && lane == 0) P.rew[env] = reward;
       if (P.done && lane == 0) P.done[env] = done ? 1 : 0;
       if (P.reason && lane == 0) P.reason[env] = reason;
-      if (P.terms && lane < 5) P.terms[(size_t)env * 5 + lane] = (lane == 0) ? terms[0] : (lane == 1) ? terms[1] : (lane == 2) ? terms[2]
-                                                                : (lane == 3) ? terms[3] : terms[4];
+      if (P.terms && lane < NTERMS) P.terms[(size_t)env * NTERMS + lane] = (lane == 0) ? terms[0] : (lane == 1) ? terms[1] : (lane == 2) ? terms[2]
+                                                              : (lane == 3) ? terms[3] : (lane == 4) ? terms[4] : (lane == 5) ? terms[5] : (lane == 6) ? terms[6] : terms[7];
       if (done && P.auto_reset && mode == MODE_STEP) {
         if (P.terminal_obs) {
-          P.terminal_obs[(size_t)env * NOBS + lane] = obs_a;
-          if (lane < NOBS - 64) P.terminal_obs[(size_t)env * NOBS + 64 + lane] = obs_b;
+          P.terminal_obs[(size_t)env * NOBS_T + lane] = obs_a;
+          if (lane < NOBS_T - 64) P.terminal_obs[(size_t)env * NOBS_T + 64 + lane] = obs_b;
         }
-        const int fi = (int)(hash32(P.seed, env, rcnt, 0x5EED) % (uint32_t)clip.L);
-        idx_curr = fi;
+        int fi;
+        if (TASK) {   // DPCombinedEnv.reset(rsi=True) (:219-227)
+          motion = (hash32(P.seed, env, rcnt, 0x5EED) & 1) ? 2 : 0;
+          clip = P.clips[motion];
+          idx_curr = (int)(hash32(P.seed, env, rcnt, 0x5EEE) % (uint32_t)clip.L) + (motion == 0 ? P.amnesty_steps + 10 : 0);
+          fi = idx_curr % clip.L;
+        } else {
+          fi = (int)(hash32(P.seed, env, rcnt, 0x5EED) % (uint32_t)clip.L);
+          idx_curr = fi;
+        }
         rcnt++;
         const float *rr = clip.reset + (size_t)fi * 88;
         SYNC();
@@ -1818,8 +1895,8 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
       }
     }
     if (P.obs) {
-      P.obs[(size_t)env * NOBS + lane] = obs_a;
-      if (lane < NOBS - 64) P.obs[(size_t)env * NOBS + 64 + lane] = obs_b;
+      P.obs[(size_t)env * NOBS_T + lane] = obs_a;
+      if (lane < NOBS_T - 64) P.obs[(size_t)env * NOBS_T + 64 + lane] = obs_b;
     }
     break;
   }
@@ -1831,7 +1908,7 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
   if (lane < NQ) st[S_QPOS + lane] = S.qpos[lane];
   if (lane < NV) { st[S_QVEL + lane] = S.qvel[lane]; st[S_WARM + lane] = S.warm[lane]; }
   if (lane < NU) st[S_CTRL + lane] = S.ctrl[lane];
-  if (lane == 0) { sti[S_IDX] = idx_curr; sti[S_EPLEN] = ep_len; st[S_EPREW] = ep_rew; sti[S_RCNT] = rcnt; }
+  if (lane == 0) { sti[S_IDX] = idx_curr; sti[S_EPLEN] = ep_len; st[S_EPREW] = ep_rew; sti[S_RCNT] = rcnt; if (TASK) sti[S_MOTION] = motion; }
 }
 
 extern "C" __global__ void g1_gather_kernel(const float *state, int N, int off, int n, int stride, float *out) {
@@ -1856,8 +1933,8 @@ struct DmG1Engine {
   double *dMesh = nullptr, *dClus = nullptr;
   int32_t *dOidx = nullptr;
   float *dState = nullptr, *dJT = nullptr, *dBT = nullptr, *dAR = nullptr, *dRowsE = nullptr;
-  float *dRows = nullptr, *dReset = nullptr, *dCom = nullptr, *dDebug = nullptr;
-  int L = 0, flags = 0;
+  float *dRows[3] = {nullptr, nullptr, nullptr}, *dReset[3] = {nullptr, nullptr, nullptr}, *dCom[3] = {nullptr, nullptr, nullptr}, *dDebug = nullptr;
+  int L[3] = {0, 0, 0}, flags[3] = {0, 0, 0};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
 };
@@ -1871,6 +1948,7 @@ extern "C" void dmg1_default_config(DmG1Config *c) {
   memset(c, 0, sizeof *c);
   c->num_envs = 1; c->max_ep_length = 1000; c->vel_obs_scale = 0.1f; c->high_z = 2.0f; c->obs_bound = 100.0f;
   c->seed = 0; c->auto_reset = 1; c->device = 0;
+  c->task = 0; c->amnesty_steps = 150; c->to_getup_len = 180;
 }
 extern "C" size_t dmg1_model_sizeof(void) { return sizeof(DmModelG1); }
 
@@ -1891,6 +1969,7 @@ static void g1_build_tables(const DmModelG1 &m, g1::Dev &T) {
   T.iterations = m.iterations; T.npair = m.npair;
   T.torso_body = m.torso_body; T.floor_geom = m.floor_geom; T.rfoot_geom = m.rfoot_geom; T.lfoot_geom = m.lfoot_geom;
   for (int i = 0; i < 4; i++) T.ee_geom[i] = m.ee_geom[i];
+  for (int i = 0; i < 8; i++) T.extra_geom[i] = m.extra_geom[i];
   for (int i = 0; i < NREW; i++) { T.rew_q[i] = m.rew_qposadr[i]; T.rew_v[i] = m.rew_dofadr[i]; T.rew_j[i] = m.rew_jnt[i]; }
   for (int i = 0; i < NQ; i++) T.qpos0[i] = (float)m.qpos0[i];
   int maxd = 0;
@@ -2096,7 +2175,7 @@ extern "C" int dmg1_create(const void *model, size_t model_bytes, const DmG1Conf
 extern "C" int dmg1_destroy(DmG1Handle e) {
   if (!e) return DM_EINVAL;
   hipFree(e->dT); hipFree(e->dMesh); hipFree(e->dOidx); hipFree(e->dClus); hipFree(e->dState); hipFree(e->dJT); hipFree(e->dBT); hipFree(e->dAR); hipFree(e->dRowsE);
-  hipFree(e->dRows); hipFree(e->dReset); hipFree(e->dCom);
+  for (int c = 0; c < 3; c++) { hipFree(e->dRows[c]); hipFree(e->dReset[c]); hipFree(e->dCom[c]); }
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   delete e;
@@ -2104,9 +2183,9 @@ extern "C" int dmg1_destroy(DmG1Handle e) {
 }
 extern "C" const char *dmg1_last_error(DmG1Handle e) { return e ? e->err.c_str() : "null handle"; }
 
-extern "C" int dmg1_load_clip(DmG1Handle e, int L, const double *q, const double *v, const double *bx, const double *gx, int flags) {
+extern "C" int dmg1_load_clip(DmG1Handle e, int clip_id, int L, const double *q, const double *v, const double *bx, const double *gx, int flags) {
   using namespace g1;
-  if (!e || L < 1 || !q || !v || !bx || !gx) return DM_EINVAL;
+  if (!e || L < 1 || !q || !v || !bx || !gx || clip_id < 0 || clip_id > 2) return DM_EINVAL;
   g1::Dev *T = new g1::Dev();
   hipMemcpy(T, e->dT, sizeof(g1::Dev), hipMemcpyDeviceToHost);
   std::vector<float> rows((size_t)L * CLIP_ROW, 0.f), reset((size_t)L * 88, 0.f), com((size_t)L * 4, 0.f);
@@ -2116,6 +2195,7 @@ extern "C" int dmg1_load_clip(DmG1Handle e, int L, const double *q, const double
     float *r = &rows[(size_t)f * CLIP_ROW];
     for (int i = 0; i < NREW; i++) { r[i] = (float)q[(size_t)f * NQ + T->rew_q[i]]; r[23 + i] = (float)v[(size_t)f * NV + T->rew_v[i]]; }
     for (int i = 0; i < 4; i++) r[46 + i] = (float)q[(size_t)f * NQ + 3 + i];
+    r[62] = (float)v[(size_t)f * NV]; r[63] = (float)v[(size_t)f * NV + 1];
     for (int e4 = 0; e4 < 4; e4++)
       for (int i = 0; i < 3; i++) r[50 + 3 * e4 + i] = (float)gx[((size_t)f * NG + T->ee_geom[e4]) * 3 + i];
     for (int i = 0; i < NQ; i++) reset[(size_t)f * 88 + i] = (float)q[(size_t)f * NQ + i];
@@ -2127,21 +2207,23 @@ extern "C" int dmg1_load_clip(DmG1Handle e, int L, const double *q, const double
     }
   }
   delete T;
-  hipFree(e->dRows); hipFree(e->dReset); hipFree(e->dCom);
-  e->dRows = e->dReset = e->dCom = nullptr;
-  if (hipMalloc(&e->dRows, rows.size() * 4) != hipSuccess || hipMalloc(&e->dReset, reset.size() * 4) != hipSuccess ||
-      hipMalloc(&e->dCom, com.size() * 4) != hipSuccess)
+  const int c = clip_id;
+  hipFree(e->dRows[c]); hipFree(e->dReset[c]); hipFree(e->dCom[c]);
+  e->dRows[c] = e->dReset[c] = e->dCom[c] = nullptr;
+  if (hipMalloc(&e->dRows[c], rows.size() * 4) != hipSuccess || hipMalloc(&e->dReset[c], reset.size() * 4) != hipSuccess ||
+      hipMalloc(&e->dCom[c], com.size() * 4) != hipSuccess)
     return g1_fail(e, DM_ENOMEM, "clip tables");
-  hipMemcpy(e->dRows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice);
-  hipMemcpy(e->dReset, reset.data(), reset.size() * 4, hipMemcpyHostToDevice);
-  hipMemcpy(e->dCom, com.data(), com.size() * 4, hipMemcpyHostToDevice);
-  e->L = L; e->flags = flags;
+  hipMemcpy(e->dRows[c], rows.data(), rows.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(e->dReset[c], reset.data(), reset.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(e->dCom[c], com.data(), com.size() * 4, hipMemcpyHostToDevice);
+  e->L[c] = L; e->flags[c] = flags;
   return DM_OK;
 }
 
 static int g1_launch(DmG1Engine *e, g1::Launch &P, void *stream, bool time_it) {
   P.T = e->dT; P.mesh_vert = e->dMesh; P.mesh_oidx = e->dOidx; P.mesh_clus = e->dClus; P.state = e->dState; P.jt = e->dJT; P.bt = e->dBT; P.ar = e->dAR; P.rows = e->dRowsE;
-  P.clip.rows = e->dRows; P.clip.reset = e->dReset; P.clip.com = e->dCom; P.clip.L = e->L; P.clip.flags = e->flags;
+  for (int c = 0; c < 3; c++) { P.clips[c].rows = e->dRows[c]; P.clips[c].reset = e->dReset[c]; P.clips[c].com = e->dCom[c]; P.clips[c].L = e->L[c]; P.clips[c].flags = e->flags[c]; }
+  P.task = e->cfg.task; P.amnesty_steps = e->cfg.amnesty_steps; P.to_getup_len = e->cfg.to_getup_len;
   P.N = e->N; P.auto_reset = e->cfg.auto_reset; P.max_ep_length = e->cfg.max_ep_length;
   P.vel_obs_scale = e->cfg.vel_obs_scale; P.high_z = e->cfg.high_z; P.obs_bound = e->cfg.obs_bound; P.seed = e->cfg.seed;
   P.debug = e->dDebug;
@@ -2154,7 +2236,7 @@ static int g1_launch(DmG1Engine *e, g1::Launch &P, void *stream, bool time_it) {
 }
 
 extern "C" int dmg1_reset(DmG1Handle e, const uint8_t *mask, const int32_t *idx_init, float *obs_out, void *stream) {
-  if (!e || !e->L) return e ? g1_fail(e, DM_EINVAL, "no clip loaded") : DM_EINVAL;
+  if (!e || !e->L[0]) return e ? g1_fail(e, DM_EINVAL, "no clip loaded") : DM_EINVAL;
   g1::Launch P;
   memset(&P, 0, sizeof P);
   P.mode = g1::MODE_RESET; P.mask = mask; P.idx_init = idx_init; P.obs = obs_out;
@@ -2163,7 +2245,7 @@ extern "C" int dmg1_reset(DmG1Handle e, const uint8_t *mask, const int32_t *idx_
 extern "C" int dmg1_step(DmG1Handle e, const float *actions, float *obs, float *rew, uint8_t *done, float *terms, int32_t *reason,
                          float *terminal_obs, void *stream) {
   if (!e || !actions) return DM_EINVAL;
-  if (!e->L) return g1_fail(e, DM_EINVAL, "no clip loaded");
+  if (!e->L[0]) return g1_fail(e, DM_EINVAL, "no clip loaded");
   g1::Launch P;
   memset(&P, 0, sizeof P);
   P.mode = g1::MODE_STEP; P.actions = actions; P.obs = obs; P.rew = rew; P.done = done; P.terms = terms; P.reason = reason;
@@ -2173,7 +2255,7 @@ extern "C" int dmg1_step(DmG1Handle e, const float *actions, float *obs, float *
 extern "C" int dmg1_step_forced(DmG1Handle e, const float *qpos, const float *qvel, float *obs, float *rew, uint8_t *done,
                                 float *terms, int32_t *reason, void *stream) {
   if (!e || !qpos || !qvel) return DM_EINVAL;
-  if (!e->L) return g1_fail(e, DM_EINVAL, "no clip loaded");
+  if (!e->L[0]) return g1_fail(e, DM_EINVAL, "no clip loaded");
   g1::Launch P;
   memset(&P, 0, sizeof P);
   P.mode = g1::MODE_FORCED; P.in_qpos = qpos; P.in_qvel = qvel; P.obs = obs; P.rew = rew; P.done = done; P.terms = terms; P.reason = reason;
@@ -2209,6 +2291,17 @@ extern "C" int dmg1_set_counters(DmG1Handle e, const int32_t *idx, const int32_t
   const int nb = (e->N + 255) / 256;
   if (idx) hipLaunchKernelGGL(g1::g1_scatter_int_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, e->dState, e->N, g1::S_IDX, g1::STATE, idx);
   if (eplen) hipLaunchKernelGGL(g1::g1_scatter_int_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, e->dState, e->N, g1::S_EPLEN, g1::STATE, eplen);
+  return DM_OK;
+}
+extern "C" int dmg1_obs_dim(DmG1Handle e) { return e ? (e->cfg.task ? DMG1_NOBS_COMBINED : DMG1_NOBS) : DM_EINVAL; }
+extern "C" int dmg1_get_motion(DmG1Handle e, int32_t *motion, void *stream) {
+  if (!e || !motion) return DM_EINVAL;
+  g1_gather(e, g1::S_MOTION, 1, (float *)motion, stream);
+  return DM_OK;
+}
+extern "C" int dmg1_set_motion(DmG1Handle e, const int32_t *motion, void *stream) {
+  if (!e || !motion) return DM_EINVAL;
+  hipLaunchKernelGGL(g1::g1_scatter_int_kernel, dim3((e->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->dState, e->N, g1::S_MOTION, g1::STATE, motion);
   return DM_OK;
 }
 extern "C" int dmg1_set_debug(DmG1Handle e, float *debug) {

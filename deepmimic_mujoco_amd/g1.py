@@ -17,16 +17,18 @@ from .config import RobotConfig
 
 NQ, NV, NU, NBODY, NGEOM, NJNT, NM, MAXPAIR, NOBS = 44, 43, 37, 39, 94, 38, 434, 1024, 85
 NACT, NMESH, NMESHVERT, NREWJ, NEE = 23, 32, 40000, 23, 4
+NOBS_COMBINED = 98
+TASK_DPENV, TASK_COMBINED = 0, 1
 MAXCON, MAXROW, DEBUG_STRIDE = 48, 256, 1024
 # [mjmodel.get_joint_qpos_addr(n) ...] minus root and hand joints (src/deepmimic_env.py:206-207)
 REW_QPOS = [7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 32, 33, 34, 35, 36]
 REW_QVEL = [6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 31, 32, 33, 34, 35]
 CLIP_FLOOR, CLIP_ACYCLIC, CLIP_RUN_RULE = 1, 2, 4
 REASONS = {0: None, 1: "low_z", 2: "high_z", 3: "max_ep_len", 4: "acyclical_end", 5: "sim_error", 6: "obs_out_of_bounds",
-           8: "run roll/pitch limit"}
+           7: "fallen without amnesty", 8: "run roll/pitch limit"}
 EXPORTS = ["dmg1_default_config", "dmg1_model_sizeof", "dmg1_create", "dmg1_destroy", "dmg1_last_error", "dmg1_load_clip",
            "dmg1_reset", "dmg1_step", "dmg1_step_forced", "dmg1_set_state", "dmg1_get_state", "dmg1_get_counters",
-           "dmg1_set_counters", "dmg1_set_debug", "dmg1_last_kernel_ms"]
+           "dmg1_set_counters", "dmg1_set_debug", "dmg1_last_kernel_ms", "dmg1_obs_dim", "dmg1_get_motion", "dmg1_set_motion"]
 
 _i32, _f64 = C.c_int32, C.c_double
 
@@ -133,7 +135,8 @@ def load_g1_model():
 
 class DmG1Config(C.Structure):
     _fields_ = [("num_envs", C.c_int32), ("max_ep_length", C.c_int32), ("vel_obs_scale", C.c_float), ("high_z", C.c_float),
-                ("obs_bound", C.c_float), ("seed", C.c_uint64), ("auto_reset", C.c_int32), ("device", C.c_int32)]
+                ("obs_bound", C.c_float), ("seed", C.c_uint64), ("auto_reset", C.c_int32), ("device", C.c_int32),
+                ("task", C.c_int32), ("amnesty_steps", C.c_int32), ("to_getup_len", C.c_int32)]
 
 
 _BOUND = []
@@ -151,7 +154,10 @@ def _lib():
         L.dmg1_destroy.argtypes = [vp]
         L.dmg1_last_error.argtypes = [vp]
         L.dmg1_last_error.restype = C.c_char_p
-        L.dmg1_load_clip.argtypes = [vp, i32, vp, vp, vp, vp, i32]
+        L.dmg1_load_clip.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32]
+        L.dmg1_obs_dim.argtypes = [vp]
+        L.dmg1_get_motion.argtypes = [vp, vp, vp]
+        L.dmg1_set_motion.argtypes = [vp, vp, vp]
         L.dmg1_reset.argtypes = [vp] * 5
         L.dmg1_step.argtypes = [vp] * 9
         L.dmg1_step_forced.argtypes = [vp] * 9
@@ -175,7 +181,7 @@ def _ptr(t):
 class G1HipEngine:
     """Batch of N Unitree G1 DeepMimic environments resident on one MI355X (tensors in, tensors out)."""
 
-    def __init__(self, num_envs, device=0, seed=0, auto_reset=True, max_ep_length=1000):
+    def __init__(self, num_envs, device=0, seed=0, auto_reset=True, max_ep_length=1000, task=TASK_DPENV):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("G1HipEngine needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
@@ -187,6 +193,10 @@ class G1HipEngine:
         cfg = DmG1Config()
         self.L.dmg1_default_config(C.byref(cfg))
         cfg.num_envs, cfg.seed, cfg.auto_reset, cfg.device, cfg.max_ep_length = self.N, seed, int(auto_reset), device, max_ep_length
+        cfg.task = int(task)
+        self.task = int(task)
+        self.obs_dim = NOBS_COMBINED if task else NOBS
+        self.terms_dim = 8 if task else 5
         self.h = C.c_void_p()
         rc = self.L.dmg1_create(C.byref(self.cmodel), C.sizeof(DmModelG1), C.byref(cfg), C.byref(self.h))
         if rc != 0:
@@ -212,18 +222,19 @@ class G1HipEngine:
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
 
-    def load_clip(self, mocap, floor=False, acyclic=False, run_rule=False):
+    def load_clip(self, mocap, floor=False, acyclic=False, run_rule=False, clip_id=0):
         q, v, bx, gx = [np.ascontiguousarray(a, np.float64) for a in mocap.tables()]
-        self.clip_len = len(q)
+        if clip_id == 0:
+            self.clip_len = len(q)
         flags = (CLIP_FLOOR if floor else 0) | (CLIP_ACYCLIC if acyclic else 0) | (CLIP_RUN_RULE if run_rule else 0)
-        self._check(self.L.dmg1_load_clip(self.h, len(q), q.ctypes.data, v.ctypes.data, bx.ctypes.data, gx.ctypes.data, flags),
-                    "dmg1_load_clip")
+        self._check(self.L.dmg1_load_clip(self.h, int(clip_id), len(q), q.ctypes.data, v.ctypes.data, bx.ctypes.data, gx.ctypes.data,
+                                          flags), "dmg1_load_clip")
 
     def alloc_outputs(self):
         t, d, n = self.torch, self.device, self.N
-        return dict(obs=t.zeros(n, NOBS, device=d), rew=t.zeros(n, device=d), done=t.zeros(n, dtype=t.uint8, device=d),
-                    terms=t.zeros(n, 5, device=d), reason=t.zeros(n, dtype=t.int32, device=d),
-                    terminal_obs=t.zeros(n, NOBS, device=d))
+        return dict(obs=t.zeros(n, self.obs_dim, device=d), rew=t.zeros(n, device=d), done=t.zeros(n, dtype=t.uint8, device=d),
+                    terms=t.zeros(n, self.terms_dim, device=d), reason=t.zeros(n, dtype=t.int32, device=d),
+                    terminal_obs=t.zeros(n, self.obs_dim, device=d))
 
     def reset(self, obs, idx_init=None, mask=None):
         self._check(self.L.dmg1_reset(self.h, _ptr(mask), _ptr(idx_init), _ptr(obs), self._stream()), "dmg1_reset")
@@ -258,6 +269,14 @@ class G1HipEngine:
 
     def set_counters(self, idx_curr=None, episode_length=None):
         self._check(self.L.dmg1_set_counters(self.h, _ptr(idx_curr), _ptr(episode_length), self._stream()), "dmg1_set_counters")
+
+    def get_motion(self):
+        m = self.torch.zeros(self.N, dtype=self.torch.int32, device=self.device)
+        self._check(self.L.dmg1_get_motion(self.h, _ptr(m), self._stream()), "dmg1_get_motion")
+        return m
+
+    def set_motion(self, motion):
+        self._check(self.L.dmg1_set_motion(self.h, _ptr(motion), self._stream()), "dmg1_set_motion")
 
     def enable_debug(self):
         self._debug = self.torch.zeros(self.N, DEBUG_STRIDE, device=self.device)
@@ -442,6 +461,161 @@ class G1DPEnv:
         t = self._torch
         self._eng.set_state(t.tensor(np.asarray(qpos)[None], dtype=t.float32, device=self._eng.device),
                             t.tensor(np.asarray(qvel)[None], dtype=t.float32, device=self._eng.device))
+
+    def close(self):
+        self._eng.close()
+
+
+# ------------------------------------------------------------------------------------------ DPCombinedEnv on the G1
+COMBINED_CLIPS = ("walk", "run", "getup_facedown_towalk")      # src/combined_env.py:168-170
+MOTION_WALK, MOTION_RUN, MOTION_GETUP, MOTION_TO_GETUP = 0, 1, 2, 3
+
+
+def _combined_engine(num_envs, device, seed, auto_reset):
+    from .combined_env import DPCombinedEnvConfig
+    cfg = DPCombinedEnvConfig()
+    eng = G1HipEngine(num_envs, device=device, seed=seed, auto_reset=auto_reset, max_ep_length=cfg.MAX_EP_LENGTH, task=TASK_COMBINED)
+    mocaps = []
+    for cid, m in enumerate(COMBINED_CLIPS):
+        mcfg, mc = _g1_mocap(m)
+        eng.load_clip(mc, clip_id=cid)
+        mocaps.append(mc)
+    return eng, mocaps
+
+
+class HipG1CombinedVecEnv(HipG1VecEnv):
+    """N ``DPCombinedEnv()`` instances — the reference's training environment (src/sb3_ppo.py:277-278): Unitree G1, walk / run /
+    getup / to_getup motion state machine, obs 98, 23 actions — as one HIP batch with SubprocVecEnv semantics."""
+
+    def __init__(self, num_envs, device=0, seed=1234, auto_reset=True):
+        import torch
+        from .deepmimic_env import Box
+        self._torch = torch
+        self.num_envs = int(num_envs)
+        self.robot_config = RobotConfig("unitree_g1")
+        self.engine, self.mocaps = _combined_engine(self.num_envs, device, seed, auto_reset)
+        self.model = self.engine.gmodel
+        self.device = self.engine.device
+        self.out = self.engine.alloc_outputs()
+        lo, hi = self.model.act_ctrlrange[:NACT, 0].astype(np.float32) / 20.0, self.model.act_ctrlrange[:NACT, 1].astype(np.float32) / 20.0
+        self.action_space = Box(lo, hi, dtype=np.float32)            # ctrlrange / ACT_SCALE (src/combined_env.py:196-200)
+        self.observation_space = Box(-np.inf, np.inf, (NOBS_COMBINED,), np.float32)
+        self._actions = torch.zeros(self.num_envs, NACT, device=self.device)
+        self.render_mode = None
+        self.reset_infos = [{} for _ in range(self.num_envs)]
+
+    def step_wait(self):
+        from .combined_env import _LazyCombinedInfos
+        t = self._torch
+        out = self.step_tensor(self._actions)
+        packed = t.cat([out["obs"], out["terminal_obs"], out["terms"], out["rew"][:, None], out["done"][:, None].float(),
+                        out["reason"][:, None].float()], dim=1).cpu().numpy()
+        d, k = NOBS_COMBINED, 8
+        obs, tobs, terms = (np.ascontiguousarray(packed[:, 0:d]), np.ascontiguousarray(packed[:, d:2 * d]),
+                            np.ascontiguousarray(packed[:, 2 * d:2 * d + k]))
+        rew = packed[:, 2 * d + k].copy()
+        done = packed[:, 2 * d + k + 1] != 0
+        reason = packed[:, 2 * d + k + 2].astype(np.int32)
+        return obs, rew, done, _LazyCombinedInfos(terms, reason, done, tobs)
+
+
+class G1CombinedEnv:
+    """``DPCombinedEnv()`` of the reference (src/combined_env.py:102-533) — hard-wired to the Unitree G1 there — as one
+    environment of the batch engine; ``combined_env.DPCombinedEnv(robot="unitree_g1")`` constructs this class."""
+
+    version = "v0.2.up"
+
+    def __init__(self, verbose=0, _profile=False, device=0):
+        import random
+        import torch
+        from .combined_env import DPCombinedEnvConfig, MTToGetup, PAWalk
+        from .deepmimic_env import Box
+        self._torch, self._random, self.verbose = torch, random, verbose
+        self.ENV_CFG = DPCombinedEnvConfig()
+        self.robot = "unitree_g1"
+        self.robot_config = RobotConfig(self.robot)
+        self._eng, mocaps = _combined_engine(1, device, 0, False)
+        self.walk_mocap, self.run_mocap, self.getup_mocap = mocaps
+        self.action_mocap = None
+        self.to_getup_mocap = MTToGetup(self.getup_mocap)
+        self._motions = [self.walk_mocap, self.run_mocap, self.getup_mocap, self.to_getup_mocap]
+        self.model = self._eng.gmodel
+        self._out = self._eng.alloc_outputs()
+        self.episode_reward, self.episode_length, self.debug_n_bad_angles = 0, 0, 0
+        self.current_motion_n_steps, self.current_motion_mocap, self.current_player_action = None, None, PAWalk()
+        lo, hi = self.model.act_ctrlrange[:NACT, 0].astype(np.float32) / 20.0, self.model.act_ctrlrange[:NACT, 1].astype(np.float32) / 20.0
+        self.action_space = Box(lo, hi, dtype=np.float32)
+        self.observation_space = Box(-np.inf, np.inf, (NOBS_COMBINED,), np.float64)
+
+    def _motion_id(self):
+        return self._motions.index(self.current_motion_mocap)
+
+    def get_current_motion_state(self):
+        idx = self.current_motion_n_steps % self.current_motion_mocap.get_length()
+        return self.current_motion_mocap.get_qpos(idx) * 1.0, self.current_motion_mocap.get_qvel(idx) * 1.0
+
+    def change_to_motion(self, motion):
+        self.current_motion_mocap = motion
+        self.current_motion_n_steps = 0
+
+    def _push(self):
+        t, dev = self._torch, self._eng.device
+        self._eng.set_motion(t.tensor([self._motion_id()], dtype=t.int32, device=dev))
+        self._eng.set_counters(t.tensor([self.current_motion_n_steps], dtype=t.int32, device=dev),
+                               t.tensor([self.episode_length], dtype=t.int32, device=dev))
+
+    def reset(self, rsi=True):
+        from .combined_env import PAWalk
+        t, dev = self._torch, self._eng.device
+        if rsi:   # :219-227
+            if self._random.randint(0, 1) == 0:
+                self.current_motion_mocap = self.walk_mocap
+                self.current_motion_n_steps = self.ENV_CFG.AMNESTY_STEPS + 10 + self._random.randint(0, self.walk_mocap.get_length() - 1)
+            else:
+                self.current_motion_mocap = self.getup_mocap
+                self.current_motion_n_steps = self._random.randint(0, self.getup_mocap.get_length() - 1)
+        else:
+            self.current_motion_mocap, self.current_motion_n_steps = self.getup_mocap, 0
+        self.current_player_action = PAWalk()
+        self.episode_reward, self.episode_length = 0, 0
+        self._eng.set_motion(t.tensor([self._motion_id()], dtype=t.int32, device=dev))
+        obs = t.zeros(1, NOBS_COMBINED, device=dev)
+        self._eng.reset(obs, idx_init=t.tensor([self.current_motion_n_steps], dtype=t.int32, device=dev))
+        return obs[0].double().cpu().numpy()
+
+    def step(self, action, force_state=None):
+        t, dev = self._torch, self._eng.device
+        action = np.asarray(action, np.float64)
+        if action.shape == (NU,):
+            action = action[:NACT]
+        assert action.shape == (NACT,)
+        self._push()
+        if force_state is not None:
+            q, v = force_state
+            self._eng.step_forced(t.tensor(np.asarray(q)[None], dtype=t.float32, device=dev),
+                                  t.tensor(np.asarray(v)[None], dtype=t.float32, device=dev), self._out)
+        else:
+            self._eng.step(t.tensor(action[None], dtype=t.float32, device=dev), self._out)
+        obs = self._out["obs"][0].double().cpu().numpy()
+        reason, done = int(self._out["reason"][0].item()), bool(self._out["done"][0].item())
+        if reason == 5:
+            return obs, 0, True, {}
+        terms = self._out["terms"][0].cpu().numpy()
+        self.current_motion_mocap = self._motions[int(self._eng.get_motion()[0].item())]
+        self.current_motion_n_steps = int(self._eng.get_counters()[0][0].item())
+        self.debug_n_bad_angles = int(terms[7])
+        self.episode_length += 1
+        if reason == 6:
+            self.episode_reward = float(self._eng.get_counters()[2][0].item())
+            return obs, 0, True, {}
+        reward = float(self._out["rew"][0].item())
+        self.episode_reward += reward
+        info = {"reward_config": float(terms[0]), "reward_qvel": float(terms[1]), "reward_end_eff": float(terms[2]),
+                "reward_com": float(terms[3]), "reward_joint_limit": float(terms[4]), "imitation_reward": float(terms[5]),
+                "task_reward": float(terms[6])}
+        if REASONS.get(reason):
+            info["done_reason"] = REASONS[reason]
+        return obs, reward, done, info
 
     def close(self):
         self._eng.close()

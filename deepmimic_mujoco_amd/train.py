@@ -57,7 +57,7 @@ def main(argv=None):
     motions = args.motion.split(",")
     if args.env == "dp_combined_env":                                   # src/sb3_ppo.py:276-278
         from .combined_env import HipCombinedVecEnv
-        env = HipCombinedVecEnv(args.envs, device=local_rank, seed=1234 + 7919 * rank)
+        env = HipCombinedVecEnv(args.envs, robot="humanoid3d", device=local_rank, seed=1234 + 7919 * rank)   # (PPO is wired to the humanoid3d batch)
     else:
         env = HipDeepMimicVecEnv(args.envs, motion=motions if len(motions) > 1 else motions[0], device=local_rank,
                                  seed=1234 + 7919 * rank, sub_batches=args.sub_batches if args.envs % args.sub_batches == 0 else 1)

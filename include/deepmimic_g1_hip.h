@@ -26,6 +26,7 @@ typedef struct DmG1Engine *DmG1Handle;
 #define DMG1_NU 37
 #define DMG1_NACT 23   /* policy actions: the 14 hand motors are held at 0 (src/deepmimic_env.py:303-307) */
 #define DMG1_NOBS 85   /* qpos[7:] 37 | 0.1 qvel[6:] 37 | torso 8 | foot contacts 2 | phase 1 (src/deepmimic_env.py:33-45) */
+#define DMG1_NOBS_COMBINED 98 /* DPCombinedEnv: 82 + extra contacts 8 + phase 1 + player-action obs 7 (src/combined_env.py:495-505) */
 #define DMG1_NBODY 39
 #define DMG1_NGEOM 94
 #define DMG1_MAXCON 48  /* contact slots per forward evaluation (MuJoCo: nconmax 200, xml :10) */
@@ -41,6 +42,12 @@ typedef struct DmG1Config {
   uint64_t seed;
   int32_t auto_reset;
   int32_t device;
+  int32_t task;            /* 0: DPEnv (src/deepmimic_env.py); 1: DPCombinedEnv (src/combined_env.py:101-533) as the reference runs
+                            * it: clips 0, 1, 2 = walk, run, getup_facedown_towalk, per-env motion 0 walk 1 run 2 getup 3 to_getup,
+                            * obs 98, terms 8 (the five imitation terms, imitation_reward, task_reward, debug_n_bad_angles),
+                            * max_ep_length 2000 */
+  int32_t amnesty_steps;   /* 150 (DPCombinedEnvConfig.AMNESTY_STEPS, combined_env.py:34) */
+  int32_t to_getup_len;    /* 180 (MTToGetup.length, combined_env.py:97) */
 } DmG1Config;
 
 void dmg1_default_config(DmG1Config *cfg);
@@ -53,8 +60,8 @@ const char *dmg1_last_error(DmG1Handle h);
 
 /* Replaces DPEnv.load_mocap (src/deepmimic_env.py:321-324): HOST float64 tables of MocapDM(robot="unitree_g1"):
  * qpos[L*44], qvel[L*43], body_xpos[L*39*3], geom_xpos[L*94*3].  flags: 1 floor motion, 2 acyclical motion
- * (src/config.py:36-37), 4 the "run" roll / pitch rule (src/deepmimic_env.py:426-433). */
-int dmg1_load_clip(DmG1Handle h, int L, const double *host_qpos, const double *host_qvel, const double *host_body_xpos,
+ * (src/config.py:36-37), 4 the "run" roll / pitch rule (src/deepmimic_env.py:426-433).  clip_id 0 (DPEnv) or 0..2. */
+int dmg1_load_clip(DmG1Handle h, int clip_id, int L, const double *host_qpos, const double *host_qvel, const double *host_body_xpos,
                    const double *host_geom_xpos, int flags);
 
 /* Replaces DPEnv.reset() / reset_model(idx_init) (src/deepmimic_env.py:496-510).  mask NULL = all envs; idx_init NULL =
@@ -78,6 +85,12 @@ int dmg1_set_state(DmG1Handle h, const float *qpos, const float *qvel, const flo
 int dmg1_get_state(DmG1Handle h, float *qpos, float *qvel, float *qacc_warmstart, void *stream);
 int dmg1_get_counters(DmG1Handle h, int32_t *idx_curr, int32_t *episode_length, float *episode_reward, void *stream);
 int dmg1_set_counters(DmG1Handle h, const int32_t *idx_curr, const int32_t *episode_length, void *stream);
+
+/* Row width of the obs buffers for the configured task (85 / 98); per-env motion id of the DPCombinedEnv task
+ * (env.current_motion_mocap, combined_env.py:190; under that task dmg1_get/set_counters' idx_curr is current_motion_n_steps). */
+int dmg1_obs_dim(DmG1Handle h);
+int dmg1_get_motion(DmG1Handle h, int32_t *motion, void *stream);
+int dmg1_set_motion(DmG1Handle h, const int32_t *motion, void *stream);
 
 /* Parity-test hook: per-env dump of the last forward evaluation, float[N*DMG1_DEBUG_STRIDE] (NULL switches it off):
  *  [0:117) xpos | [117:160) qacc_smooth | [160:203) qacc | 203 ncon | 204 nefc | 205 solver_iter | 206 nlimit | 207 overflow |

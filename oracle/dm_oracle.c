@@ -1328,8 +1328,10 @@ int dmo_env_reset(const DmModel *m, DmoData *d, DmoEnv *e, const DmoClip *clip, 
   return err;
 }
 
-#ifndef DM_ROBOT_G1
-/* ------------------------------------------------------------------ DPCombinedEnv semantics (src/combined_env.py) */
+/* ------------------------------------------------------------------ DPCombinedEnv semantics (src/combined_env.py)
+ * humanoid3d build: the class's logic on the 34-DoF model (no action scale, no extra-contact geoms, low_z 0.7).
+ * G1 build: the class as the reference runs it (:164-178): walk / run / getup_facedown_towalk, ACT_SCALE 20 with 14 padded
+ * hand torques (:251-254), ADD_EXTRA_CONTACT_OBS (:27) -> obs 98, imitation terms on the 23-joint subset, low_z 0.4. */
 #define COMB_AMNESTY_STEPS 150   /* DPCombinedEnvConfig.AMNESTY_STEPS :34 */
 #define COMB_MAX_EP_LENGTH 2000  /* :22 */
 #define COMB_TO_GETUP_LEN 180    /* MTToGetup.length :97 */
@@ -1347,18 +1349,29 @@ static const DmoClip *comb_clip(const DmoCombEnv *e, const DmoClip *clips, int *
 void dmo_combined_obs(const DmModel *m, const DmoData *d, const DmoCombEnv *e, const DmoClip *clips, double *obs) {
   double base[DM_NOBS];
   int L = comb_len(e, clips);
+  const int T8 = (NQ - 7) + (NV - 6) + 8;                         /* qpos[7:], qvel[6:], torso: 64 / 82 */
   dmo_get_obs(m, d, e->n_steps % L, L, base);                    /* shared get_obs (deepmimic_env.py:33-45) */
-  for (int i = 0; i < 64; i++) obs[i] = base[i];                  /* ADD_FOOT_CONTACT_OBS False (:25); no extra-contact geoms */
-  obs[64] = base[66];                                             /* phase */
+  for (int i = 0; i < T8; i++) obs[i] = base[i];                  /* ADD_FOOT_CONTACT_OBS False (:25) */
+  int o = T8;
+#ifdef DM_ROBOT_G1
+  for (int k = 0; k < 8; k++) obs[o + k] = 0;                     /* get_extra_contact_obs (deepmimic_env.py:107-121) */
+  for (int c = 0; c < d->ncon; c++) {
+    int g1 = d->contact[c].geom1, g2 = d->contact[c].geom2;
+    if (g1 != m->floor_geom && g2 != m->floor_geom) continue;
+    for (int k = 0; k < 8; k++) if (g1 == m->extra_geom[k] || g2 == m->extra_geom[k]) obs[o + k] = 1;
+  }
+  o += 8;
+#endif
+  obs[o] = base[T8 + 2];                                          /* phase */
   /* get_player_action_obs (deepmimic_env.py:145-173) with PAWalk: heading (1,0,0), onehot index 0 */
   double rpy[3];
   dmo_quat_to_rpy(d->xquat[m->torso_body], rpy);
   const double hwx = 1.0, hwy = 0.0;
-  obs[65] = hwx * cos(-rpy[2]) - hwy * sin(-rpy[2]);
-  obs[66] = hwx * sin(-rpy[2]) + hwy * cos(-rpy[2]);
-  obs[67] = 1; obs[68] = 0; obs[69] = 0;
-  obs[70] = (e->motion == DMO_MOTION_TO_GETUP) ? 1 : 0;           /* pa_getup_state (:499-504) */
-  obs[71] = (e->motion == DMO_MOTION_GETUP) ? 1 : 0;
+  obs[o + 1] = hwx * cos(-rpy[2]) - hwy * sin(-rpy[2]);
+  obs[o + 2] = hwx * sin(-rpy[2]) + hwy * cos(-rpy[2]);
+  obs[o + 3] = 1; obs[o + 4] = 0; obs[o + 5] = 0;
+  obs[o + 6] = (e->motion == DMO_MOTION_TO_GETUP) ? 1 : 0;        /* pa_getup_state (:499-504) */
+  obs[o + 7] = (e->motion == DMO_MOTION_GETUP) ? 1 : 0;
 }
 
 static void comb_change(DmoCombEnv *e, int motion) { e->motion = motion; e->n_steps = 0; } /* :529-533 */
@@ -1370,7 +1383,11 @@ int dmo_combined_step(const DmModel *m, DmoData *d, DmoCombEnv *e, const DmoClip
   if (fq && fv) {
     err = dmo_set_state(m, d, fq, fv);                            /* :260-262 */
   } else {
+#ifdef DM_ROBOT_G1
+    for (int a = 0; a < NU; a++) d->ctrl[a] = a < m->n_policy_action ? action[a] * m->action_scale : 0.0; /* :251-254 */
+#else
     for (int a = 0; a < NU; a++) d->ctrl[a] = action[a] * 1.0;    /* :251 (ACT_SCALE applies to unitree_g1 only) */
+#endif
     err = dmo_step(m, d);                                         /* :267 */
   }
   if (err) {                                                      /* :271-284 */
@@ -1394,7 +1411,12 @@ int dmo_combined_step(const DmModel *m, DmoData *d, DmoCombEnv *e, const DmoClip
   int nbad = 0;
   const double PI = 3.14159265358979323846;
   const double ALIM = 15.0 * (PI / 180.0), MAX_ANGLE = 60.0 * (PI / 180.0); /* np.deg2rad(15), np.deg2rad(60) */
+#ifdef DM_ROBOT_G1
+  for (int k = 0; k < DM_NREWJ; k++) {                            /* config_angle_diffs of the 23-joint subset */
+    const int i = m->rew_qposadr[k];
+#else
   for (int i = 7; i < NQ; i++) {
+#endif
     double a = fabs(d->qpos[i] - tq[i]);
     dsum += a;
     if (a > dmax) dmax = a;
@@ -1428,7 +1450,11 @@ int dmo_combined_step(const DmModel *m, DmoData *d, DmoCombEnv *e, const DmoClip
     double mt = 0, zc = 0;
     for (int b = 0; b < NB; b++) { mt += m->body_mass[b]; zc += m->body_mass[b] * d->xipos[b][2]; }
     zc /= mt;
+#ifdef DM_ROBOT_G1
+    int fallen = (zc < m->low_z) || (zc > 2.0);                   /* robot_config.low_z (:419) */
+#else
     int fallen = (zc < 0.7) || (zc > 2.0);
+#endif
     if (droll > MAX_ANGLE) fallen = 1;
     if (dpitch > MAX_ANGLE) fallen = 1;
     if (fallen) {
@@ -1466,7 +1492,6 @@ int dmo_combined_reset(const DmModel *m, DmoData *d, DmoCombEnv *e, const DmoCli
 }
 
 /* ------------------------------------------------------------------ CPU baseline driver */
-#endif /* !DM_ROBOT_G1 */
 
 static uint32_t hash32(uint64_t seed, uint32_t env, uint32_t step, uint32_t j) {
   /* counter-based generator shared with the HIP bench path (csrc/dm_kernels.hip: dm_hash32) */

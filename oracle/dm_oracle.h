@@ -126,7 +126,11 @@ int dmo_env_reset(const DmModel *m, DmoData *d, DmoEnv *e, const DmoClip *clip, 
 /* ---- DPCombinedEnv (src/combined_env.py) on the humanoid3d model: walk / run / getup / to_getup state machine.
  * The reference class is hard-wired to unitree_g1 (:165); this restates its step()/reset()/_get_obs() with the
  * humanoid3d RobotConfig (no action scale, no extra-contact geoms, low_z 0.7).  clips[3] = walk, run, getup. */
+#ifdef DM_ROBOT_G1
+#define DMO_NOBS_COMBINED 98 /* 37 + 37 + torso 8 + extra contacts 8 + phase + player-action obs 7 */
+#else
 #define DMO_NOBS_COMBINED 72
+#endif
 enum { DMO_MOTION_WALK = 0, DMO_MOTION_RUN = 1, DMO_MOTION_GETUP = 2, DMO_MOTION_TO_GETUP = 3 };
 enum { DMO_REASON_FALLEN_NO_AMNESTY = 7 };
 typedef struct DmoCombEnv {

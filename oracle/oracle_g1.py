@@ -156,3 +156,45 @@ class G1Sim:
         done = self.L.dmo_env_step(C.byref(self.cm), self.d, C.byref(self.env), C.byref(clip.c), _p(act), fq, fv, _p(obs),
                                    C.byref(rew), _p(terms), C.byref(reason))
         return obs, rew.value, bool(done), terms, reason.value
+
+
+NOBS_COMBINED = 98
+
+
+class _CombEnv(C.Structure):
+    _fields_ = [("motion", C.c_int32), ("n_steps", C.c_int32), ("episode_length", C.c_int32), ("pad", C.c_int32),
+                ("episode_reward", C.c_double)]
+
+
+class G1CombSim(G1Sim):
+    """One fp64 DPCombinedEnv (src/combined_env.py) as the reference runs it: Unitree G1, clips = (walk, run,
+    getup_facedown_towalk); motion ids 0 walk, 1 run, 2 getup, 3 to_getup."""
+
+    def __init__(self, clips):
+        super().__init__()
+        L = self.L
+        L.dmo_combined_obs.argtypes = [C.c_void_p] * 5
+        L.dmo_combined_step.argtypes = [C.c_void_p] * 11
+        L.dmo_combined_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        self.clips = clips
+        self.carr = (_Clip * 3)(*[c.c for c in clips])
+        self.cenv = _CombEnv(0, 0, 0, 0, 0.0)
+
+    def comb_reset(self, motion, n_steps):
+        obs = np.zeros(NOBS_COMBINED)
+        err = self.L.dmo_combined_reset(C.byref(self.cm), self.d, C.byref(self.cenv), self.carr, motion, n_steps, _p(obs))
+        return obs, err
+
+    def comb_step(self, action, force_state=None):
+        act = np.zeros(NU)
+        act[:len(action)] = action
+        obs, terms = np.zeros(NOBS_COMBINED), np.zeros(8)
+        rew, reason = C.c_double(0), C.c_int32(0)
+        pq = pv = None
+        if force_state is not None:
+            fq = np.ascontiguousarray(force_state[0], np.float64)
+            fv = np.ascontiguousarray(force_state[1], np.float64)
+            pq, pv = _p(fq), _p(fv)
+        done = self.L.dmo_combined_step(C.byref(self.cm), self.d, C.byref(self.cenv), self.carr, _p(act), pq, pv, _p(obs),
+                                        C.byref(rew), _p(terms), C.byref(reason))
+        return obs, rew.value, bool(done), terms, reason.value

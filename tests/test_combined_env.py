@@ -249,7 +249,7 @@ def test_gpu_combined_vecenv_autoreset_and_mirror(model):
     import torch
     from deepmimic_mujoco_amd.combined_env import DPCombinedEnv, HipCombinedVecEnv, NOBS_COMBINED
     N = 512
-    env = HipCombinedVecEnv(N, seed=7)
+    env = HipCombinedVecEnv(N, robot="humanoid3d", seed=7)
     obs = env.reset()
     assert obs.shape == (N, NOBS_COMBINED)
     motion, n_steps = [t.cpu().numpy() for t in env.motion_state()]
@@ -283,7 +283,7 @@ def test_gpu_combined_vecenv_autoreset_and_mirror(model):
     assert TO_GETUP in set(np.unique(m2))                              # amnesty falls land in to_getup
     env.close()
 
-    e1 = DPCombinedEnv()
+    e1 = DPCombinedEnv(robot="humanoid3d")
     o = e1.reset(rsi=False)
     assert o.shape == (NOBS_COMBINED,) and e1.current_motion_mocap is e1.getup_mocap and e1.current_motion_n_steps == 0
     assert o[71] == 1.0 and o[64] == 0.0
@@ -305,7 +305,7 @@ def test_gpu_ppo_on_combined_env():
     """src/sb3_ppo.py trains `dp_combined_env` by default (:247-278): the learner takes the 72-d observation."""
     from deepmimic_mujoco_amd.combined_env import HipCombinedVecEnv
     from deepmimic_mujoco_amd.ppo import PPO
-    venv = HipCombinedVecEnv(128, seed=3)
+    venv = HipCombinedVecEnv(128, robot="humanoid3d", seed=3)
     ppo = PPO(venv, net_arch=(64, 32), n_steps=16, batch_size=512, n_epochs=2, learning_rate=3e-4)
     assert ppo.obs_dim == 72
     ppo.learn(2 * 16 * 128, log_interval=0)

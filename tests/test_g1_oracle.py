@@ -515,3 +515,50 @@ def test_g1_passive_rollout_regime(walk):
         if done:
             break
     assert 8 <= steps <= 60 and reason == 1
+
+
+# ------------------------------------------------------------------------------------------ DPCombinedEnv on the G1
+@pytest.fixture(scope="module")
+def comb_clips():
+    clips, mocaps = [], []
+    for m in ("walk", "run", "getup_facedown_towalk"):
+        mc = MocapDM(robot="unitree_g1")
+        mc.load_mocap(MotionConfig(m, robot="unitree_g1").mocap_path)
+        mocaps.append(mc)
+        clips.append(og.G1Clip(*mc.tables()))
+    return clips, mocaps
+
+
+def test_g1_combined_env_state_machine_on_the_oracle(comb_clips):
+    """DPCombinedEnv as the reference runs it (src/combined_env.py on the G1): obs 98 with the extra-contact block, getup runs
+    out of time and hands over to RUN (the `== PAWalk()` identity quirk, :396), a robot that falls without amnesty ends the
+    episode and enters to_getup; teacher-forced onto the clip the imitation terms are 1 and walk earns the velocity reward."""
+    clips, mocaps = comb_clips
+    s = og.G1CombSim(clips)
+    obs, err = s.comb_reset(2, 0)
+    assert err == 0 and obs.shape == (98,)
+    assert list(obs[93:98]) == [1, 0, 0, 0, 1] and abs(obs[91] - 1) < 1e-6 and abs(obs[90]) < 1e-12   # one-hot PAWalk, getup flag
+    L = clips[2].L
+    seen_contact = False
+    for t in range(L + 5):
+        obs, r, d, terms, reason = s.comb_step(np.zeros(23))
+        seen_contact |= obs[82:90].any()
+        assert set(np.unique(obs[82:90])) <= {0.0, 1.0}
+        if d:
+            break
+    assert seen_contact
+    assert t == L - 1 and d and reason == 7          # out of time at n_steps = L - 1 -> run -> fallen (lying) without amnesty
+    assert s.cenv.motion == 3 and s.cenv.n_steps == 1
+    # teacher-forced walk: all imitation terms 1, task reward 1 (root velocity of the clip), reward 0.7 + 0.3
+    s.comb_reset(0, 200)
+    fr = 200 % clips[0].L
+    fq, fv = np.array(mocaps[0].get_qpos(fr)), np.array(mocaps[0].get_qvel(fr))
+    obs, r, d, terms, reason = s.comb_step(np.zeros(23), force_state=(fq, fv))
+    assert not d and np.allclose(terms[:4], 1, atol=1e-6) and abs(terms[6] - 1) < 1e-9 and abs(r - (0.7 * (1 - 0.1 * terms[4]) + 0.3)) < 1e-6
+    assert s.cenv.motion == 0 and s.cenv.n_steps == 201
+    # to_getup: success within 15 degrees of frame 1 of the getup clip hands over to getup
+    s.comb_reset(3, 5)
+    fq, fv = np.array(mocaps[2].get_qpos(1)), np.array(mocaps[2].get_qvel(1))
+    obs, r, d, terms, reason = s.comb_step(np.zeros(23), force_state=(fq, fv))
+    assert obs[96] == 1 and obs[97] == 0 and terms[5] == 0 and abs(terms[6] - 1 / 3) < 1e-6    # imitation 0, exp(0) / 3
+    assert s.cenv.motion == 2 and s.cenv.n_steps == 1
