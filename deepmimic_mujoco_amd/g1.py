@@ -242,7 +242,7 @@ class G1HipEngine:
     def step(self, actions, out):
         assert actions.shape == (self.N, NACT) and actions.dtype == self.torch.float32 and actions.is_contiguous()
         self._check(self.L.dmg1_step(self.h, _ptr(actions), _ptr(out["obs"]), _ptr(out["rew"]), _ptr(out["done"]),
-                                     _ptr(out["terms"]), _ptr(out["reason"]), _ptr(out["terminal_obs"]), self._stream()),
+                                     _ptr(out.get("terms")), _ptr(out.get("reason")), _ptr(out.get("terminal_obs")), self._stream()),
                     "dmg1_step")
 
     def step_forced(self, qpos, qvel, out):
@@ -326,6 +326,13 @@ class HipG1VecEnv:
         self._actions = torch.zeros(self.num_envs, NACT, device=self.device)
         self.render_mode = None
         self.reset_infos = [{} for _ in range(self.num_envs)]
+        self._ppo_attrs()
+
+    def _ppo_attrs(self):   # what deepmimic_mujoco_amd.ppo reads of a batch env
+        self.engines, self.sub_batches, self.sub_slices, self.sub_out = [self.engine], 1, [slice(0, self.num_envs)], [self.out]
+
+    def step_sub(self, k, actions_k):
+        return self.step_tensor(actions_k)
 
     def reset_tensor(self, idx_init=None):
         self.engine.reset(self.out["obs"], idx_init=idx_init)
@@ -503,6 +510,7 @@ class HipG1CombinedVecEnv(HipG1VecEnv):
         self._actions = torch.zeros(self.num_envs, NACT, device=self.device)
         self.render_mode = None
         self.reset_infos = [{} for _ in range(self.num_envs)]
+        self._ppo_attrs()
 
     def step_wait(self):
         from .combined_env import _LazyCombinedInfos

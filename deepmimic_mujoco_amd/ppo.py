@@ -523,8 +523,9 @@ class PPO:
         self._rollout_seed = (0x5EED0000 + seed + 0x9E3779B1 * self.rank) & 0x7FFFFFFFFFFFFFFF
         self.buffer_dtype = buffer_dtype
         torch.manual_seed(seed)  # identical initial weights on every rank; no parameter broadcast needed
-        self.obs_dim = int(env.observation_space.shape[0]) if env is not None else 67   # 67 DPEnv, 72 DPCombinedEnv
-        self.policy = (policy if policy is not None else MlpPolicy(obs_dim=self.obs_dim, net_arch=tuple(net_arch))).to(self.device)
+        self.obs_dim = int(env.observation_space.shape[0]) if env is not None else 67   # 67 DPEnv, 72 DPCombinedEnv; G1: 85 / 98
+        self.act_dim = int(env.action_space.shape[0]) if env is not None else 28        # 28 humanoid3d, 23 Unitree G1
+        self.policy = (policy if policy is not None else MlpPolicy(obs_dim=self.obs_dim, act_dim=self.act_dim, net_arch=tuple(net_arch))).to(self.device)
         on_gpu = self.device.type == "cuda"
         # The optimizer step of one minibatch is ~60 small kernels: launch-bound.  On one GPU it is captured
         # once into a hipGraph and replayed (640 replays per PPO iteration with the reference's settings).
@@ -567,7 +568,7 @@ class PPO:
         if key not in sc:
             n = key[0]
             z = lambda *shape: torch.zeros(*shape, device=self.device)
-            sc[key] = dict(act=z(n, 28), act_env=z(n, 28), logp=z(n))
+            sc[key] = dict(act=z(n, self.act_dim), act_env=z(n, self.act_dim), logp=z(n))
             self._rsc = sc
         if getattr(self, "_rctrs", None) is None:
             # draw counters, advanced on the device: ONE PER SUB-BATCH — sub-batch chains run on their own streams (or as
@@ -589,7 +590,7 @@ class PPO:
         mean = self.policy.action_net(self.policy.pi(obs))
         val = self.policy.value_net(self.policy.vf(obs)).squeeze(-1).contiguous()
         p = lambda t: C.c_void_p(t.data_ptr())
-        rc = _lib.load_library().dm_policy_sample(p(mean.contiguous()), p(self.policy.log_std), n, 28,
+        rc = _lib.load_library().dm_policy_sample(p(mean.contiguous()), p(self.policy.log_std), n, self.act_dim,
                                                   C.c_uint64(self._rollout_seed + 7919 * env_index), p(self._ctr(env_index)), p(self.act_lo),
                                                   p(self.act_hi), p(sc["act"]), p(sc["act_env"]), p(sc["logp"]),
                                                   C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
@@ -603,7 +604,7 @@ class PPO:
         p = lambda x: C.c_void_p(x.data_ptr())
         n = val.shape[0]
         rc = _lib.load_library().dm_rollout_store(
-            n, self.obs_dim, 28, p(last[sl]), p(sc["act"]), p(val), p(sc["logp"]), p(out["rew"]), p(out["done"]), p(out["obs"]),
+            n, self.obs_dim, self.act_dim, p(last[sl]), p(sc["act"]), p(val), p(sc["logp"]), p(out["rew"]), p(out["done"]), p(out["obs"]),
             p(rb["obs"][t, sl]), p(rb["act"][t, sl]), p(rb["val"][t, sl]), p(rb["logp"][t, sl]), p(rb["rew"][t, sl]),
             p(rb["done"][t, sl]), p(last[sl]), p(self._ctr(env_index)) if bump else None,
             C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
@@ -628,11 +629,11 @@ class PPO:
         st = getattr(self, "_fp", None)
         if st is None:
             z = lambda *shape, dt=torch.float32: torch.zeros(*shape, device=dev, dtype=dt)
-            rb = dict(obs=z(T, N, self.obs_dim), act=z(T, N, 28), rew=z(T, N), done_u8=z(T, N, dt=torch.uint8), val=z(T, N),
+            rb = dict(obs=z(T, N, self.obs_dim), act=z(T, N, self.act_dim), rew=z(T, N), done_u8=z(T, N, dt=torch.uint8), val=z(T, N),
                       logp=z(T, N))
             last = (env.reset_tensor() if self._last_obs is None else self._last_obs).clone()
             self._rollout_scratch((N, 0))
-            st = self._fp = dict(rb=rb, last=last, fwd=FusedPolicyForward(self.policy, dev), act_env=z(N, 28),
+            st = self._fp = dict(rb=rb, last=last, fwd=FusedPolicyForward(self.policy, dev), act_env=z(N, self.act_dim),
                                  streams=[torch.cuda.Stream(device=dev) for _ in range(K)] if K > 1 else None, graph=None)
         rb, last, fwd = st["rb"], st["last"], st["fwd"]
         if self._last_obs is not None and self._last_obs.data_ptr() != last.data_ptr():
@@ -695,7 +696,7 @@ class PPO:
         env, T, N, dev, bd = self.env, self.n_steps, self.n_envs, self.device, self.buffer_dtype
         K = env.sub_batches
         z = lambda *shape, dt=torch.float32: torch.zeros(*shape, device=dev, dtype=dt)
-        rb = dict(obs=z(T, N, self.obs_dim, dt=bd), act=z(T, N, 28, dt=bd), rew=z(T, N), done=z(T, N), val=z(T, N), logp=z(T, N))
+        rb = dict(obs=z(T, N, self.obs_dim, dt=bd), act=z(T, N, self.act_dim, dt=bd), rew=z(T, N), done=z(T, N), val=z(T, N), logp=z(T, N))
         last = env.reset_tensor().clone() if self._last_obs is None else self._last_obs.clone()
         streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
 
@@ -749,7 +750,7 @@ class PPO:
         K = env.sub_batches
         if getattr(self, "_pipe", None) is None:
             z = lambda *shape: torch.zeros(*shape, device=dev)
-            rb = dict(obs=z(T, N, self.obs_dim), act=z(T, N, 28), rew=z(T, N), done=z(T, N), val=z(T, N), logp=z(T, N))
+            rb = dict(obs=z(T, N, self.obs_dim), act=z(T, N, self.act_dim), rew=z(T, N), done=z(T, N), val=z(T, N), logp=z(T, N))
             last = env.reset_tensor().clone() if self._last_obs is None else self._last_obs.clone()
             self._pipe = (rb, last, [torch.cuda.Stream(device=dev) for _ in range(K)])
         rb, last, streams = self._pipe
@@ -793,7 +794,7 @@ class PPO:
             return rb
         T, N, dev = self.n_steps, self.n_envs, self.device
         bd = self.buffer_dtype
-        buf = dict(obs=torch.zeros(T, N, self.obs_dim, device=dev, dtype=bd), act=torch.zeros(T, N, 28, device=dev, dtype=bd),
+        buf = dict(obs=torch.zeros(T, N, self.obs_dim, device=dev, dtype=bd), act=torch.zeros(T, N, self.act_dim, device=dev, dtype=bd),
                    rew=torch.zeros(T, N, device=dev), done=torch.zeros(T, N, device=dev),
                    val=torch.zeros(T, N, device=dev), logp=torch.zeros(T, N, device=dev))
         if self._last_obs is None:
@@ -1027,7 +1028,7 @@ class PPO:
 
     def _static_minibatch(self):
         B, dev = self.batch_size, self.device
-        return dict(obs=torch.zeros(B, self.obs_dim, device=dev), act=torch.zeros(B, 28, device=dev), adv=torch.zeros(B, device=dev),
+        return dict(obs=torch.zeros(B, self.obs_dim, device=dev), act=torch.zeros(B, self.act_dim, device=dev), adv=torch.zeros(B, device=dev),
                     ret=torch.zeros(B, device=dev), logp=torch.zeros(B, device=dev))
 
     def _epoch_graph_ok(self, flat, n):

@@ -20,6 +20,8 @@ def main(argv=None):
     ap.add_argument("--motion", default="walk", help="clip name or comma list (multi-clip: env i -> clip i mod k)")
     ap.add_argument("--env", default="deep_mimic_mujoco", choices=["deep_mimic_mujoco", "dp_combined_env"],
                     help="env_name of src/sb3_ppo.py:247-248 (dp_combined_env: walk/run/getup state machine on humanoid3d)")
+    ap.add_argument("--robot", default="humanoid3d", choices=["humanoid3d", "unitree_g1"],
+                    help="src/sb3_ppo.py:251 trains unitree_g1 (its dp_combined_env is hard-wired to it)")
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=32)          # 32 x 4096 = the reference's 4096 x 32 batch
     ap.add_argument("--epochs", type=int, default=20)           # src/sb3_ppo.py:259
@@ -57,7 +59,9 @@ def main(argv=None):
     motions = args.motion.split(",")
     if args.env == "dp_combined_env":                                   # src/sb3_ppo.py:276-278
         from .combined_env import HipCombinedVecEnv
-        env = HipCombinedVecEnv(args.envs, robot="humanoid3d", device=local_rank, seed=1234 + 7919 * rank)   # (PPO is wired to the humanoid3d batch)
+        env = HipCombinedVecEnv(args.envs, robot=args.robot, device=local_rank, seed=1234 + 7919 * rank)
+    elif args.robot == "unitree_g1":                                    # src/sb3_ppo.py:274-275 with robot = "unitree_g1"
+        env = HipDeepMimicVecEnv(args.envs, motion=motions[0], robot="unitree_g1", device=local_rank, seed=1234 + 7919 * rank)
     else:
         env = HipDeepMimicVecEnv(args.envs, motion=motions if len(motions) > 1 else motions[0], device=local_rank,
                                  seed=1234 + 7919 * rank, sub_batches=args.sub_batches if args.envs % args.sub_batches == 0 else 1)

@@ -293,3 +293,22 @@ def test_g1_combined_surfaces():
         obs, rew, done, infos = venv.step(np.zeros((16, 23), np.float32))
         assert obs.shape == (16, 98) and np.isfinite(obs).all() and len(infos) == 16
     venv.close()
+
+
+def test_ppo_iteration_on_the_g1_combined_env():
+    """The reference's training setup (src/sb3_ppo.py:249-313: PPO on DPCombinedEnv(), Unitree G1, MLP [256,128]) on the device-
+    resident loop: one-launch policy forward (D = 98, A = 23), dmg1_step, fused learner; one iteration changes the weights,
+    keeps everything finite and the stored actions inside the action space (ctrlrange / 20)."""
+    import torch
+    from deepmimic_mujoco_amd.combined_env import HipCombinedVecEnv
+    from deepmimic_mujoco_amd.ppo import PPO
+    env = HipCombinedVecEnv(256, seed=11)
+    ppo = PPO(env, n_steps=8, batch_size=512, n_epochs=2, seed=3)
+    assert ppo.obs_dim == 98 and ppo.act_dim == 23
+    w0 = [p.detach().clone() for p in ppo.policy.parameters()]
+    ppo.learn(256 * 8 * 2, log_interval=0)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p).all() for p in ppo.policy.parameters())
+    assert any((p.detach() - q).abs().max() > 0 for p, q in zip(ppo.policy.parameters(), w0))
+    assert np.isfinite(ppo.stats["mean_reward"]) and np.isfinite(ppo.stats.get("loss", 0.0))
+    env.close()
