@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #define DM_OK 0
@@ -498,6 +499,24 @@ __device__ __forceinline__ void dsub(double *r, const double *a, const double *b
 // (2) all clusters whose upper bound reaches the lower bound are scanned, every lane keeping its own best — no cross-lane
 // step between the loads — and one wave reduction ends it.  Exact; equal support values resolve to the lowest ORIGINAL
 // vertex index, as a serial first-maximum scan would.
+// wave maximum of a double, uniform in every lane: four DPP steps inside each row of 16 lanes (both dwords moved with the same
+// control), then the four row maxima through v_readlane — ~25 instructions instead of six LDS-permute round trips
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wmax_f64(double v) {
+  v = fmax(v, dpp_f64<0xB1>(v));    // quad_perm [1,0,3,2]
+  v = fmax(v, dpp_f64<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = fmax(v, dpp_f64<0x141>(v));   // row_half_mirror
+  v = fmax(v, dpp_f64<0x140>(v));   // row_mirror
+  return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
 struct MeshPick { double best; int bo, bk; };
 __device__ __forceinline__ void pick_update(MeshPick &p, double sv, int so, int sk) {
   if (sv > p.best || (sv == p.best && so < p.bo)) { p.best = sv; p.bo = so; p.bk = sk; }
@@ -517,12 +536,21 @@ __device__ __forceinline__ void scan4(const Geo &g, const double *dl, const int 
   for (int q = 0; q < 4; q++)
     if (o[q] != 0x7fffffff) pick_update(p, x[q] * dl[0] + y[q] * dl[1] + z[q] * dl[2], o[q], 64 * c[q] + lane);
 }
+// the lanes' picks -> the wave's pick: the maximum value, and among equal values the lowest original index (one lane in all
+// but degenerate cases: a ballot and a v_readlane; ties walk the tied lanes)
 __device__ __forceinline__ void wave_pick(MeshPick &p) {
-  for (int o = 32; o > 0; o >>= 1) {
-    const double v = __shfl_xor(p.best, o);
-    const int bo = __shfl_xor(p.bo, o), bk = __shfl_xor(p.bk, o);
-    pick_update(p, v, bo, bk);
+  const double vmax = wmax_f64(p.best);
+  unsigned long long eq = __ballot(p.best == vmax);
+  int l = __ffsll((long long)eq) - 1;
+  int bo = __builtin_amdgcn_readlane(p.bo, l), bk = __builtin_amdgcn_readlane(p.bk, l);
+  eq &= eq - 1;
+  while (eq) {
+    l = __ffsll((long long)eq) - 1;
+    eq &= eq - 1;
+    const int o2 = __builtin_amdgcn_readlane(p.bo, l), k2 = __builtin_amdgcn_readlane(p.bk, l);
+    if (o2 < bo) { bo = o2; bk = k2; }
   }
+  p.best = vmax; p.bo = bo; p.bk = bk;
 }
 __device__ __forceinline__ void scan_candidates(const Geo &g, const double *dl, const double (&ub)[3], const double bound, const int skip,
                                                 MeshPick &p, const int lane) {
@@ -556,11 +584,17 @@ __device__ __forceinline__ void cluster_bounds(const Geo &g, const double *dl, c
       if (dc > best) { best = dc; top = c; }
     }
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    const double ob = __shfl_xor(best, o);
-    const int oc = __shfl_xor(top, o);
-    if (ob > best || (ob == best && oc < top)) { best = ob; top = oc; }
+  const double vmax = wmax_f64(best);
+  unsigned long long eq = __ballot(best == vmax);
+  int l = __ffsll((long long)eq) - 1, t = __builtin_amdgcn_readlane(top, l);
+  eq &= eq - 1;
+  while (eq) {
+    l = __ffsll((long long)eq) - 1;
+    eq &= eq - 1;
+    const int t2 = __builtin_amdgcn_readlane(top, l);
+    if (t2 < t) t = t2;
   }
+  top = t;
 }
 // Support vertices of up to two hulls at once, in local directions dlA / dlB.  The vertices are stored in compact clusters
 // (k-d leaves, padded to 64 slots) with a bounding sphere each.  Three dependent memory round trips for BOTH hulls together
@@ -568,7 +602,7 @@ __device__ __forceinline__ void cluster_bounds(const Geo &g, const double *dl, c
 // centre . d + radius |d|; (2) the cluster with the largest centre . d is scanned: a true support value to prune with;
 // (3) the clusters whose bound still reaches it are scanned together, every lane keeping its own best, one wave reduction
 // at the end.  Exact; equal support values resolve to the lowest ORIGINAL vertex index, like a serial first-maximum scan.
-__device__ __noinline__ void mesh_support_pair(const Geo &A, const double *dlA, const bool meshA, int &iA, const Geo &B,
+__device__ __forceinline__ void mesh_support_pair(const Geo &A, const double *dlA, const bool meshA, int &iA, const Geo &B,
                                                   const double *dlB, const bool meshB, int &iB, const int lane) {
   double ubA[3], ubB[3];
   int topA, topB;
@@ -579,7 +613,7 @@ __device__ __noinline__ void mesh_support_pair(const Geo &A, const double *dlA, 
     scan4(A, dlA, ca, pa, lane);
     scan4(B, dlB, cb, pb, lane); }
   double ba = pa.best, bb = pb.best;
-  for (int o = 32; o > 0; o >>= 1) { ba = fmax(ba, __shfl_xor(ba, o)); bb = fmax(bb, __shfl_xor(bb, o)); }
+  ba = wmax_f64(ba); bb = wmax_f64(bb);
   if (meshA) scan_candidates(A, dlA, ubA, ba, topA, pa, lane);
   if (meshB) scan_candidates(B, dlB, ubB, bb, topB, pb, lane);
   wave_pick(pa);
@@ -629,7 +663,13 @@ __device__ __forceinline__ void mpr_support(const Geo &a, const Geo &b, const do
   support_local(b, dlb, pb);
   if (ma || mb) {
     int ia, ib;
+#ifdef G1_PROFILE
+    const long long t0_ = clock64();
+#endif
     mesh_support_pair(a, dla, ma, ia, b, dlb, mb, ib, lane);
+#ifdef G1_PROFILE
+    if (lane == 0) { S.prof[13] += (unsigned)(clock64() - t0_); S.prof[12] += 1; }
+#endif
     if (ma) { pa[0] = a.vert[3 * ia]; pa[1] = a.vert[3 * ia + 1]; pa[2] = a.vert[3 * ia + 2]; }
     if (mb) { pb[0] = b.vert[3 * ib]; pb[1] = b.vert[3 * ib + 1]; pb[2] = b.vert[3 * ib + 2]; }
   }
@@ -689,94 +729,112 @@ __device__ __forceinline__ double tri_closest_origin(const double *a, const doub
   return ddot(w, w);
 }
 // 0 = penetration (depth, dir a -> b, pos), -1 = none
-__device__ __noinline__ int mpr_penetration(const Geo &a, const Geo &b, double *depth, double *dir, double *pos, const int lane) {
-  Sup ps[4], v4;
+// The routine is a state machine around ONE support evaluation site (discoverPortal's vertices 1, 2, 3.., refinePortal,
+// findPenetr): the support mapping of two hulls is the bulk of the code, and one inlined copy costs neither the code size
+// of five nor a function call (whose callee-saved registers would go through scratch memory a hundred times per env-step).
+// The arithmetic and its order are those of the straight-line libccd routine.
+__device__ __forceinline__ int mpr_penetration(const Geo &a, const Geo &b, double *depth, double *dir, double *pos, const int lane) {
+  enum { V1, V2, DISCOVER, REFINE, PENETR };
+  Sup ps[4], sv;
   double d[3], va[3], vb[3], dot;
   for (int i = 0; i < 3; i++) { ps[0].v1[i] = a.center[i]; ps[0].v2[i] = b.center[i]; ps[0].v[i] = a.center[i] - b.center[i]; }
   if (ccd_zero(ps[0].v[0]) && ccd_zero(ps[0].v[1]) && ccd_zero(ps[0].v[2])) ps[0].v[0] += CCD_EPS * 10;
   for (int i = 0; i < 3; i++) d[i] = -ps[0].v[i];
   dnormalize(d);
-  mpr_support(a, b, d, ps[1], lane);
-  dot = ddot(ps[1].v, d);
-  if (ccd_zero(dot) || dot < 0) return -1;
-  dcross(d, ps[0].v, ps[1].v);
-  if (ccd_zero(ddot(d, d))) {
-    for (int i = 0; i < 3; i++) pos[i] = 0.5 * (ps[1].v1[i] + ps[1].v2[i]);
-    if (ccd_zero(ps[1].v[0]) && ccd_zero(ps[1].v[1]) && ccd_zero(ps[1].v[2])) { *depth = 0; dir[0] = dir[1] = dir[2] = 0; return 0; }
-    for (int i = 0; i < 3; i++) dir[i] = ps[1].v[i];
-    *depth = dnormalize(dir);
-    return 0;
-  }
-  dnormalize(d);
-  mpr_support(a, b, d, ps[2], lane);
-  dot = ddot(ps[2].v, d);
-  if (ccd_zero(dot) || dot < 0) return -1;
-  dsub(va, ps[1].v, ps[0].v); dsub(vb, ps[2].v, ps[0].v);
-  dcross(d, va, vb);
-  dnormalize(d);
-  if (ddot(d, ps[0].v) > 0) { Sup t = ps[1]; ps[1] = ps[2]; ps[2] = t; for (int i = 0; i < 3; i++) d[i] = -d[i]; }
-  for (int guard = 0;; guard++) {
-    if (guard > 1000) return -1;
-    mpr_support(a, b, d, ps[3], lane);
-    dot = ddot(ps[3].v, d);
-    if (ccd_zero(dot) || dot < 0) return -1;
-    bool cont = false;
-    dcross(va, ps[1].v, ps[3].v);
-    dot = ddot(va, ps[0].v);
-    if (dot < 0 && !ccd_zero(dot)) { ps[2] = ps[3]; cont = true; }
-    if (!cont) {
-      dcross(va, ps[3].v, ps[2].v);
-      dot = ddot(va, ps[0].v);
-      if (dot < 0 && !ccd_zero(dot)) { ps[1] = ps[3]; cont = true; }
-    }
-    if (!cont) break;
-    dsub(va, ps[1].v, ps[0].v); dsub(vb, ps[2].v, ps[0].v);
-    dcross(d, va, vb);
-    dnormalize(d);
-  }
-  for (int guard = 0;; guard++) {   // refinePortal
-    if (guard >= 10000) return -1;
-    portal_dir(ps, d);
-    dot = ddot(d, ps[1].v);
-    if (ccd_zero(dot) || dot > 0) break;
-    mpr_support(a, b, d, v4, lane);
-    dot = ddot(v4.v, d);
-    if (!(ccd_zero(dot) || dot > 0) || reach_tol(ps, v4, d)) return -1;
-    expand_portal(ps, v4);
-  }
-  for (int it = 0;; it++) {   // findPenetr
-    portal_dir(ps, d);
-    mpr_support(a, b, d, v4, lane);
-    if (reach_tol(ps, v4, d) || it > MPR_ITER) {
-      *depth = sqrt(tri_closest_origin(ps[1].v, ps[2].v, ps[3].v, dir));
-      if (ccd_zero(*depth)) dir[0] = dir[1] = dir[2] = 0; else dnormalize(dir);
-      double bb[4], t[3], sum;
-      portal_dir(ps, d);
-      dcross(t, ps[1].v, ps[2].v); bb[0] = ddot(t, ps[3].v);
-      dcross(t, ps[3].v, ps[2].v); bb[1] = ddot(t, ps[0].v);
-      dcross(t, ps[0].v, ps[1].v); bb[2] = ddot(t, ps[3].v);
-      dcross(t, ps[2].v, ps[1].v); bb[3] = ddot(t, ps[0].v);
-      sum = bb[0] + bb[1] + bb[2] + bb[3];
-      if (ccd_zero(sum) || sum < 0) {
-        bb[0] = 0;
-        dcross(t, ps[2].v, ps[3].v); bb[1] = ddot(t, d);
-        dcross(t, ps[3].v, ps[1].v); bb[2] = ddot(t, d);
-        dcross(t, ps[1].v, ps[2].v); bb[3] = ddot(t, d);
-        sum = bb[1] + bb[2] + bb[3];
+  int state = V1, guard = 0, it = 0;
+  for (;;) {
+    mpr_support(a, b, d, sv, lane);
+    if (state == V1) {
+      ps[1] = sv;
+      dot = ddot(ps[1].v, d);
+      if (ccd_zero(dot) || dot < 0) return -1;
+      dcross(d, ps[0].v, ps[1].v);
+      if (ccd_zero(ddot(d, d))) {
+        for (int i = 0; i < 3; i++) pos[i] = 0.5 * (ps[1].v1[i] + ps[1].v2[i]);
+        if (ccd_zero(ps[1].v[0]) && ccd_zero(ps[1].v[1]) && ccd_zero(ps[1].v[2])) { *depth = 0; dir[0] = dir[1] = dir[2] = 0; return 0; }
+        for (int i = 0; i < 3; i++) dir[i] = ps[1].v[i];
+        *depth = dnormalize(dir);
+        return 0;
       }
-      const double inv = 1.0 / sum;
-      double p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
-      for (int k = 0; k < 4; k++)
-        for (int i = 0; i < 3; i++) { p1[i] += bb[k] * ps[k].v1[i]; p2[i] += bb[k] * ps[k].v2[i]; }
-      for (int i = 0; i < 3; i++) pos[i] = 0.5 * inv * (p1[i] + p2[i]);
-      return 0;
+      dnormalize(d);
+      state = V2;
+    } else if (state == V2) {
+      ps[2] = sv;
+      dot = ddot(ps[2].v, d);
+      if (ccd_zero(dot) || dot < 0) return -1;
+      dsub(va, ps[1].v, ps[0].v); dsub(vb, ps[2].v, ps[0].v);
+      dcross(d, va, vb);
+      dnormalize(d);
+      if (ddot(d, ps[0].v) > 0) { Sup t = ps[1]; ps[1] = ps[2]; ps[2] = t; for (int i = 0; i < 3; i++) d[i] = -d[i]; }
+      state = DISCOVER;
+      guard = 0;
+    } else if (state == DISCOVER) {
+      if (guard > 1000) return -1;
+      guard++;
+      ps[3] = sv;
+      dot = ddot(ps[3].v, d);
+      if (ccd_zero(dot) || dot < 0) return -1;
+      bool cont = false;
+      dcross(va, ps[1].v, ps[3].v);
+      dot = ddot(va, ps[0].v);
+      if (dot < 0 && !ccd_zero(dot)) { ps[2] = ps[3]; cont = true; }
+      if (!cont) {
+        dcross(va, ps[3].v, ps[2].v);
+        dot = ddot(va, ps[0].v);
+        if (dot < 0 && !ccd_zero(dot)) { ps[1] = ps[3]; cont = true; }
+      }
+      if (cont) {
+        dsub(va, ps[1].v, ps[0].v); dsub(vb, ps[2].v, ps[0].v);
+        dcross(d, va, vb);
+        dnormalize(d);
+      } else {   // portal found: refinePortal's first test, or straight on to findPenetr (same portal direction)
+        portal_dir(ps, d);
+        dot = ddot(d, ps[1].v);
+        state = (ccd_zero(dot) || dot > 0) ? PENETR : REFINE;
+        guard = 0;
+      }
+    } else if (state == REFINE) {
+      dot = ddot(sv.v, d);
+      if (!(ccd_zero(dot) || dot > 0) || reach_tol(ps, sv, d)) return -1;
+      expand_portal(ps, sv);
+      if (++guard >= 10000) return -1;
+      portal_dir(ps, d);
+      dot = ddot(d, ps[1].v);
+      if (ccd_zero(dot) || dot > 0) state = PENETR;
+    } else {   // findPenetr
+      if (reach_tol(ps, sv, d) || it > MPR_ITER) {
+        *depth = sqrt(tri_closest_origin(ps[1].v, ps[2].v, ps[3].v, dir));
+        if (ccd_zero(*depth)) dir[0] = dir[1] = dir[2] = 0; else dnormalize(dir);
+        double bb[4], t[3], sum;
+        portal_dir(ps, d);
+        dcross(t, ps[1].v, ps[2].v); bb[0] = ddot(t, ps[3].v);
+        dcross(t, ps[3].v, ps[2].v); bb[1] = ddot(t, ps[0].v);
+        dcross(t, ps[0].v, ps[1].v); bb[2] = ddot(t, ps[3].v);
+        dcross(t, ps[2].v, ps[1].v); bb[3] = ddot(t, ps[0].v);
+        sum = bb[0] + bb[1] + bb[2] + bb[3];
+        if (ccd_zero(sum) || sum < 0) {
+          bb[0] = 0;
+          dcross(t, ps[2].v, ps[3].v); bb[1] = ddot(t, d);
+          dcross(t, ps[3].v, ps[1].v); bb[2] = ddot(t, d);
+          dcross(t, ps[1].v, ps[2].v); bb[3] = ddot(t, d);
+          sum = bb[1] + bb[2] + bb[3];
+        }
+        const double inv = 1.0 / sum;
+        double p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
+        for (int k = 0; k < 4; k++)
+          for (int i = 0; i < 3; i++) { p1[i] += bb[k] * ps[k].v1[i]; p2[i] += bb[k] * ps[k].v2[i]; }
+        for (int i = 0; i < 3; i++) pos[i] = 0.5 * inv * (p1[i] + p2[i]);
+        return 0;
+      }
+      expand_portal(ps, sv);
+      it++;
+      portal_dir(ps, d);
     }
-    expand_portal(ps, v4);
   }
 }
 
 // [EXT] mjc_Convex at margin 0; spheres get their analytic normal afterwards (mjc_fixNormal)
-__device__ __noinline__ int np_convex(Con *c, const Geo &a, const Geo &b, const int lane) {
+__device__ __forceinline__ int np_convex(Con *c, const Geo &a, const Geo &b, const int lane) {
   double depth, dir[3], pos[3];
   if (mpr_penetration(a, b, &depth, dir, pos, lane) != 0) return 0;
   if (dir[0] == 0 && dir[1] == 0 && dir[2] == 0) return 0;
@@ -1359,6 +1417,16 @@ struct RowSolve {
     if constexpr (I > 0) RowSolve<I - 1>::run(x, L);
   }
 };
+// compile-time loop with early exit: f(integral_constant<int, I>) returns false to stop
+template <int I, int N>
+struct StaticFor {
+  template <class F>
+  static __device__ __forceinline__ void run(F &&f) {
+    if constexpr (I < N) {
+      if (f(std::integral_constant<int, I>{})) StaticFor<I + 1, N>::run(f);
+    }
+  }
+};
 __device__ __forceinline__ float bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 // A = J M^-1 J^T + R into the per-env scratch.  Up to 128 rows: lane r (and r + 64) keeps its row of B = D^-1/2 L^-T J^T in
@@ -1368,30 +1436,40 @@ __device__ __noinline__ void project_constraint(const Dev &T, const float *JT, f
                                                 const int nefc, const int lane) {
   const float *e_R = RW;
   if (nefc <= 128) {
-    float x0[NV], x1[NV];
-    const bool two = nefc > 64;
+    // rows in chunks of 64: the lanes' rows of B in 43 registers each; A[i][j] for i in the same chunk by broadcasts of row
+    // i, for i in the other chunk from the rows that chunk stored in the B^T scratch (wave-uniform loads)
+    const int nchunk = (nefc + 63) >> 6;
+    for (int cj = 0; cj < nchunk; cj++) {
+      const int j = lane + 64 * cj;
+      const bool on = j < nefc;
+      float x[NV];
 #pragma unroll
-    for (int k = 0; k < NV; k++) {
-      x0[k] = (lane < nefc) ? JT[k * MAXROW + lane] : 0.f;
-      x1[k] = (two && lane + 64 < nefc) ? JT[k * MAXROW + lane + 64] : 0.f;
-    }
-    RowSolve<NV - 1>::run(x0, S.qLD);
-    if (two) RowSolve<NV - 1>::run(x1, S.qLD);
+      for (int k = 0; k < NV; k++) x[k] = on ? JT[k * MAXROW + j] : 0.f;
+      RowSolve<NV - 1>::run(x, S.qLD);
 #pragma unroll
-    for (int k = 0; k < NV; k++) { const float d = S.dsq[k]; x0[k] *= d; x1[k] *= d; }
-    const float r0 = (lane < nefc) ? e_R[lane] : 0.f, r1 = (two && lane + 64 < nefc) ? e_R[lane + 64] : 0.f;
-    for (int i = 0; i < nefc; i++) {
-      const int l = i & 63;
-      float s0 = 0, s1 = 0;
-      if (i < 64) {
+      for (int k = 0; k < NV; k++) x[k] *= S.dsq[k];
+      if (nchunk > 1) {
 #pragma unroll
-        for (int k = 0; k < NV; k++) { const float b = bcast(x0[k], l); s0 = fmaf(b, x0[k], s0); s1 = fmaf(b, x1[k], s1); }
-      } else {
-#pragma unroll
-        for (int k = 0; k < NV; k++) { const float b = bcast(x1[k], l); s0 = fmaf(b, x0[k], s0); s1 = fmaf(b, x1[k], s1); }
+        for (int k = 0; k < NV; k++) if (on) BT[k * MAXROW + j] = x[k];
+        SYNC();
       }
-      if (lane < nefc) AR[i * MAXROW + lane] = s0 + ((i == lane) ? r0 : 0.f);
-      if (two && lane + 64 < nefc) AR[i * MAXROW + lane + 64] = s1 + ((i == lane + 64) ? r1 : 0.f);
+      const float rj = on ? e_R[j] : 0.f;
+      const int i0 = 64 * cj, i1 = (i0 + 64 < nefc) ? i0 + 64 : nefc;
+      for (int i = i0; i < i1; i++) {   // rows of the same chunk: broadcasts
+        const int l = i & 63;
+        float s0 = 0;
+#pragma unroll
+        for (int k = 0; k < NV; k++) s0 = fmaf(bcast(x[k], l), x[k], s0);
+        if (on) AR[i * MAXROW + j] = s0 + ((i == j) ? rj : 0.f);
+      }
+      if (cj == 1) {                    // cross block: rows of chunk 0 (in the scratch) against this chunk's columns, both ways
+        for (int i = 0; i < 64; i++) {
+          float s0 = 0;
+#pragma unroll
+          for (int k = 0; k < NV; k++) s0 = fmaf(BT[k * MAXROW + i], x[k], s0);
+          if (on) { AR[i * MAXROW + j] = s0; AR[j * MAXROW + i] = s0; }
+        }
+      }
     }
     SYNC();
     return;
@@ -1493,6 +1571,33 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
       if (nr > 3 && lane + 192 < nefc) res[3] += row_[lane + 192] * dl_;                           \
     }                                                                                              \
   }
+  if (nefc <= 64) {
+    // up to 64 rows (nine evaluations in ten): lane j keeps its row of A in 64 registers, the sweep is unrolled over the rows
+    // with static lanes and static register indices — no memory and no dynamic lane select in the sweep's dependent chain
+    float arow[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) arow[i] = (i < nefc && lane < nefc) ? AR[i * MAXROW + lane] : 0.f;
+    float res0 = res[0], f0 = fr[0];
+    const float ainv0 = dinv[0], aii0 = diag[0], fl0 = lm[0];
+    while (iter < max_iter) {
+      float improvement = 0;
+      StaticFor<0, 64>::run([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (i >= nefc) return false;
+        const float rs_ = bcast(res0, i), old_ = bcast(f0, i), ai_ = bcast(ainv0, i), fl_ = bcast(fl0, i), aii_ = bcast(aii0, i);
+        float f_ = fmaf(-rs_, ai_, old_);
+        f_ = (fl_ >= 0.f) ? fminf(fmaxf(f_, -fl_), fl_) : fmaxf(f_, 0.f);
+        const float dl_ = f_ - old_;
+        improvement -= dl_ * fmaf(0.5f * dl_, aii_, rs_);
+        f0 = (lane == i) ? f_ : f0;
+        res0 = fmaf(arow[i], dl_, res0);
+        return true;
+      });
+      iter++;
+      if (improvement * T.pgs_scale < T.tolerance) break;
+    }
+    fr[0] = f0;
+  } else {
   const int n0 = nefc < 64 ? nefc : 64, n1 = nefc < 128 ? nefc : 128;
   while (iter < max_iter) {
     float improvement = 0;
@@ -1527,6 +1632,7 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
     }
     iter++;
     if (improvement * T.pgs_scale < T.tolerance) break;   // (uniform: every lane accumulated the same sum)
+  }
   }
 #undef PGS_STEP
   PROF(12);
