@@ -118,6 +118,7 @@ struct Launch {
   float *state;              // N x STATE
   float *jt, *bt, *ar;       // per-env scratch: J^T [44][MAXROW], (D^-1/2 L^-T J^T) [44][MAXROW], A [MAXROW][MAXROW]
   float *rows;               // per-env scratch: R, aref -> b, force, friction-loss bound, meta (type | id << 2): [5][MAXROW]
+  float *sepc;               // per-env separating-direction cache of the MPR pairs: [SEPC + 1][4]
   ClipDev clips[3];          // DPEnv: clips[0]; DPCombinedEnv: walk, run, getup
   int32_t task, amnesty_steps, to_getup_len, pad2;
   int32_t N, mode, auto_reset, max_ep_length, run_forward, pad;
@@ -733,8 +734,14 @@ __device__ __forceinline__ double tri_closest_origin(const double *a, const doub
 // findPenetr): the support mapping of two hulls is the bulk of the code, and one inlined copy costs neither the code size
 // of five nor a function call (whose callee-saved registers would go through scratch memory a hundred times per env-step).
 // The arithmetic and its order are those of the straight-line libccd routine.
-__device__ __forceinline__ int mpr_penetration(const Geo &a, const Geo &b, double *depth, double *dir, double *pos, const int lane) {
-  enum { V1, V2, DISCOVER, REFINE, PENETR };
+// `hint` (or null): a direction that separated the pair at an earlier evaluation — tested first with one support evaluation;
+// returns -2 if it still separates them (disjoint shapes: MPR would find no contact either, so the shortcut is result-neutral).
+// On a `no intersection` verdict reached through a strictly negative support projection, `sep` receives that direction.
+__device__ __forceinline__ int mpr_penetration(const Geo &a, const Geo &b, double *depth, double *dir, double *pos, const double *hint,
+                                               double *sep, bool &sep_valid, const int lane) {
+  enum { V1, V2, DISCOVER, REFINE, PENETR, HINT };
+  constexpr double SEP_EPS = 1e-9;
+  sep_valid = false;
   Sup ps[4], sv;
   double d[3], va[3], vb[3], dot;
   for (int i = 0; i < 3; i++) { ps[0].v1[i] = a.center[i]; ps[0].v2[i] = b.center[i]; ps[0].v[i] = a.center[i] - b.center[i]; }
@@ -742,12 +749,19 @@ __device__ __forceinline__ int mpr_penetration(const Geo &a, const Geo &b, doubl
   for (int i = 0; i < 3; i++) d[i] = -ps[0].v[i];
   dnormalize(d);
   int state = V1, guard = 0, it = 0;
+  if (hint) { state = HINT; for (int i = 0; i < 3; i++) d[i] = hint[i]; }
+#define MPR_MISS(DOT) do { if ((DOT) < -SEP_EPS) { sep[0] = d[0]; sep[1] = d[1]; sep[2] = d[2]; sep_valid = true; } return -1; } while (0)
   for (;;) {
     mpr_support(a, b, d, sv, lane);
-    if (state == V1) {
+    if (state == HINT) {
+      if (ddot(sv.v, d) < -SEP_EPS) return -2;
+      for (int i = 0; i < 3; i++) d[i] = -ps[0].v[i];   // the hint went stale: the routine proper
+      dnormalize(d);
+      state = V1;
+    } else if (state == V1) {
       ps[1] = sv;
       dot = ddot(ps[1].v, d);
-      if (ccd_zero(dot) || dot < 0) return -1;
+      if (ccd_zero(dot) || dot < 0) MPR_MISS(dot);
       dcross(d, ps[0].v, ps[1].v);
       if (ccd_zero(ddot(d, d))) {
         for (int i = 0; i < 3; i++) pos[i] = 0.5 * (ps[1].v1[i] + ps[1].v2[i]);
@@ -761,7 +775,7 @@ __device__ __forceinline__ int mpr_penetration(const Geo &a, const Geo &b, doubl
     } else if (state == V2) {
       ps[2] = sv;
       dot = ddot(ps[2].v, d);
-      if (ccd_zero(dot) || dot < 0) return -1;
+      if (ccd_zero(dot) || dot < 0) MPR_MISS(dot);
       dsub(va, ps[1].v, ps[0].v); dsub(vb, ps[2].v, ps[0].v);
       dcross(d, va, vb);
       dnormalize(d);
@@ -773,7 +787,7 @@ __device__ __forceinline__ int mpr_penetration(const Geo &a, const Geo &b, doubl
       guard++;
       ps[3] = sv;
       dot = ddot(ps[3].v, d);
-      if (ccd_zero(dot) || dot < 0) return -1;
+      if (ccd_zero(dot) || dot < 0) MPR_MISS(dot);
       bool cont = false;
       dcross(va, ps[1].v, ps[3].v);
       dot = ddot(va, ps[0].v);
@@ -795,7 +809,8 @@ __device__ __forceinline__ int mpr_penetration(const Geo &a, const Geo &b, doubl
       }
     } else if (state == REFINE) {
       dot = ddot(sv.v, d);
-      if (!(ccd_zero(dot) || dot > 0) || reach_tol(ps, sv, d)) return -1;
+      if (!(ccd_zero(dot) || dot > 0)) MPR_MISS(dot);
+      if (reach_tol(ps, sv, d)) return -1;
       expand_portal(ps, sv);
       if (++guard >= 10000) return -1;
       portal_dir(ps, d);
@@ -831,12 +846,37 @@ __device__ __forceinline__ int mpr_penetration(const Geo &a, const Geo &b, doubl
       portal_dir(ps, d);
     }
   }
+#undef MPR_MISS
 }
 
 // [EXT] mjc_Convex at margin 0; spheres get their analytic normal afterwards (mjc_fixNormal)
-__device__ __forceinline__ int np_convex(Con *c, const Geo &a, const Geo &b, const int lane) {
-  double depth, dir[3], pos[3];
-  if (mpr_penetration(a, b, &depth, dir, pos, lane) != 0) return 0;
+// Separating-direction cache (per env, in global memory): pairs that passed the box filter but do not touch — adjacent links,
+// typically — keep the direction that proved it, stored in geom 1's frame; the next evaluation re-tests it with ONE support
+// evaluation instead of running the portal search (4..5 on average).  Entries: pair id, direction xyz; slot SEPC = next victim.
+constexpr int SEPC = 16;
+__device__ __forceinline__ int np_convex(Con *c, const Geo &a, const Geo &b, float *cache, const int pair, const int lane) {
+  double depth, dir[3], pos[3], hint[3], sep[3];
+  bool sep_valid;
+  int slot = -1;
+  if (cache) {
+    const unsigned long long hit = __ballot(lane < SEPC && __float_as_int(cache[4 * (lane < SEPC ? lane : 0)]) == pair);
+    if (hit) {
+      slot = __ffsll((long long)hit) - 1;
+      const double hl[3] = {cache[4 * slot + 1], cache[4 * slot + 2], cache[4 * slot + 3]};
+      drot(hint, a.mat, hl);
+      dnormalize(hint);
+    }
+  }
+  const int res = mpr_penetration(a, b, &depth, dir, pos, slot >= 0 ? hint : nullptr, sep, sep_valid, lane);
+  if (cache && res == -1 && sep_valid) {   // remember what separated them (geom 1's frame)
+    if (slot < 0) { slot = __float_as_int(cache[4 * SEPC]) & (SEPC - 1); if (lane == 0) cache[4 * SEPC] = __int_as_float(slot + 1); }
+    double sl[3];
+    drot_t(sl, a.mat, sep);
+    if (lane == 0) { cache[4 * slot] = __int_as_float(pair); cache[4 * slot + 1] = (float)sl[0]; cache[4 * slot + 2] = (float)sl[1]; cache[4 * slot + 3] = (float)sl[2]; }
+  } else if (cache && res == 0 && slot >= 0) {
+    if (lane == 0) cache[4 * slot] = __int_as_float(-1);   // they touch now: drop the entry
+  }
+  if (res != 0) return 0;
   if (dir[0] == 0 && dir[1] == 0 && dir[2] == 0) return 0;
   c->dist = -depth;
   for (int i = 0; i < 3; i++) { c->pos[i] = pos[i]; c->n[i] = dir[i]; }
@@ -1248,7 +1288,7 @@ __device__ __noinline__ int collide(const Dev &T, const Launch &P, const int lan
     } else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_SPHERE) n = np_sphere_sphere(rc, A.pos, A.size[0], B.pos, B.size[0]);
     else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_BOX) n = np_sphere_box(rc, A, B);
     else if (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX) n = np_box_box(rc, A, B, S.u.co.poly[0], S.u.co.poly[1]);
-    else if (!(P.pad & 64)) n = np_convex(rc, A, B, lane);
+    else if (!(P.pad & 64)) n = np_convex(rc, A, B, (P.pad & 256) ? nullptr : P.sepc + (size_t)blockIdx.x * (4 * SEPC + 4), p, lane);
     SYNC();
     PROF((t1 == DM_GEOM_PLANE && t2 == DM_GEOM_MESH) ? 5 : ((t1 == DM_GEOM_PLANE || (t1 == DM_GEOM_SPHERE && (t2 == DM_GEOM_SPHERE || t2 == DM_GEOM_BOX)) || (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX)) ? 4 : 6));
     for (int k = 0; k < n; k++) {
@@ -2038,7 +2078,7 @@ struct DmG1Engine {
   g1::Dev *dT = nullptr;
   double *dMesh = nullptr, *dClus = nullptr;
   int32_t *dOidx = nullptr;
-  float *dState = nullptr, *dJT = nullptr, *dBT = nullptr, *dAR = nullptr, *dRowsE = nullptr;
+  float *dState = nullptr, *dJT = nullptr, *dBT = nullptr, *dAR = nullptr, *dRowsE = nullptr, *dSepc = nullptr;
   float *dRows[3] = {nullptr, nullptr, nullptr}, *dReset[3] = {nullptr, nullptr, nullptr}, *dCom[3] = {nullptr, nullptr, nullptr}, *dDebug = nullptr;
   int L[3] = {0, 0, 0}, flags[3] = {0, 0, 0};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -2268,6 +2308,8 @@ extern "C" int dmg1_create(const void *model, size_t model_bytes, const DmG1Conf
   ok = ok && hipMalloc(&e->dBT, N * 44 * g1::MAXROW * sizeof(float)) == hipSuccess;
   ok = ok && hipMalloc(&e->dAR, N * g1::MAXROW * g1::MAXROW * sizeof(float)) == hipSuccess;
   ok = ok && hipMalloc(&e->dRowsE, N * 5 * g1::MAXROW * sizeof(float)) == hipSuccess;
+  ok = ok && hipMalloc(&e->dSepc, N * (4 * g1::SEPC + 4) * sizeof(float)) == hipSuccess;
+  if (ok) hipMemset(e->dSepc, 0xFF, N * (4 * g1::SEPC + 4) * sizeof(float));   // pair id -1 everywhere
   if (!ok) { dmg1_destroy(e); return DM_ENOMEM; }
   std::vector<float> init(N * g1::STATE, 0.f);
   for (size_t i = 0; i < N; i++)
@@ -2280,7 +2322,7 @@ extern "C" int dmg1_create(const void *model, size_t model_bytes, const DmG1Conf
 
 extern "C" int dmg1_destroy(DmG1Handle e) {
   if (!e) return DM_EINVAL;
-  hipFree(e->dT); hipFree(e->dMesh); hipFree(e->dOidx); hipFree(e->dClus); hipFree(e->dState); hipFree(e->dJT); hipFree(e->dBT); hipFree(e->dAR); hipFree(e->dRowsE);
+  hipFree(e->dT); hipFree(e->dMesh); hipFree(e->dOidx); hipFree(e->dClus); hipFree(e->dState); hipFree(e->dJT); hipFree(e->dBT); hipFree(e->dAR); hipFree(e->dRowsE); hipFree(e->dSepc);
   for (int c = 0; c < 3; c++) { hipFree(e->dRows[c]); hipFree(e->dReset[c]); hipFree(e->dCom[c]); }
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
@@ -2327,7 +2369,7 @@ extern "C" int dmg1_load_clip(DmG1Handle e, int clip_id, int L, const double *q,
 }
 
 static int g1_launch(DmG1Engine *e, g1::Launch &P, void *stream, bool time_it) {
-  P.T = e->dT; P.mesh_vert = e->dMesh; P.mesh_oidx = e->dOidx; P.mesh_clus = e->dClus; P.state = e->dState; P.jt = e->dJT; P.bt = e->dBT; P.ar = e->dAR; P.rows = e->dRowsE;
+  P.T = e->dT; P.mesh_vert = e->dMesh; P.mesh_oidx = e->dOidx; P.mesh_clus = e->dClus; P.state = e->dState; P.jt = e->dJT; P.bt = e->dBT; P.ar = e->dAR; P.rows = e->dRowsE; P.sepc = e->dSepc;
   for (int c = 0; c < 3; c++) { P.clips[c].rows = e->dRows[c]; P.clips[c].reset = e->dReset[c]; P.clips[c].com = e->dCom[c]; P.clips[c].L = e->L[c]; P.clips[c].flags = e->flags[c]; }
   P.task = e->cfg.task; P.amnesty_steps = e->cfg.amnesty_steps; P.to_getup_len = e->cfg.to_getup_len;
   P.N = e->N; P.auto_reset = e->cfg.auto_reset; P.max_ep_length = e->cfg.max_ep_length;
