@@ -119,6 +119,8 @@ struct Launch {
   float *jt, *bt, *ar;       // per-env scratch: J^T [44][MAXROW], (D^-1/2 L^-T J^T) [44][MAXROW], A [MAXROW][MAXROW]
   float *rows;               // per-env scratch: R, aref -> b, force, friction-loss bound, meta (type | id << 2): [5][MAXROW]
   float *sepc;               // per-env separating-direction cache of the MPR pairs: [SEPC + 1][4]
+  const int32_t *order;      // STEP: workgroup -> env, heaviest envs first (g1_schedule_kernel), or null
+  int32_t *cost;             // STEP: per-env work estimate of this step, or null
   ClipDev clips[3];          // DPEnv: clips[0]; DPCombinedEnv: walk, run, getup
   int32_t task, amnesty_steps, to_getup_len, pad2;
   int32_t N, mode, auto_reset, max_ep_length, run_forward, pad;
@@ -1225,7 +1227,7 @@ __device__ __forceinline__ bool obb_separated(const float *c1, const float *R1, 
 }
 
 // [EXT] mj_collision: candidate pairs in canonical order, bounding-sphere + bounding-box filters, narrowphase
-__device__ __noinline__ int collide(const Dev &T, const Launch &P, const int lane) {
+__device__ __noinline__ int collide(const Dev &T, const Launch &P, const int env, const int lane) {
   int nsurv = 0, overflow = 0;
   for (int base = 0; base < T.npair; base += 64) {
     const int p = base + lane;
@@ -1288,7 +1290,7 @@ __device__ __noinline__ int collide(const Dev &T, const Launch &P, const int lan
     } else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_SPHERE) n = np_sphere_sphere(rc, A.pos, A.size[0], B.pos, B.size[0]);
     else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_BOX) n = np_sphere_box(rc, A, B);
     else if (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX) n = np_box_box(rc, A, B, S.u.co.poly[0], S.u.co.poly[1]);
-    else if (!(P.pad & 64)) n = np_convex(rc, A, B, (P.pad & 256) ? nullptr : P.sepc + (size_t)blockIdx.x * (4 * SEPC + 4), p, lane);
+    else if (!(P.pad & 64)) n = np_convex(rc, A, B, (P.pad & 256) ? nullptr : P.sepc + (size_t)env * (4 * SEPC + 4), p, lane);
     SYNC();
     PROF((t1 == DM_GEOM_PLANE && t2 == DM_GEOM_MESH) ? 5 : ((t1 == DM_GEOM_PLANE || (t1 == DM_GEOM_SPHERE && (t2 == DM_GEOM_SPHERE || t2 == DM_GEOM_BOX)) || (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX)) ? 4 : 6));
     for (int k = 0; k < n; k++) {
@@ -1706,7 +1708,7 @@ __device__ __noinline__ void forward(const Launch &P, const Dev &T, const int en
   fwd_smooth(T, lane);   // before the collision stage: its scratch shares LDS with the contact arrays
   PROF(2);
   int ncon = 0;
-  if (!(P.pad & 2)) ncon = collide(T, P, lane);
+  if (!(P.pad & 2)) ncon = collide(T, P, env, lane);
   else { if (lane == 0) { S.info[0] = 0; S.info[4] = 0; } SYNC(); }
   int nefc = 0;
   PROF(7);
@@ -1739,8 +1741,9 @@ __device__ void integrate_pos(const float *q0, const float *vel, const float h, 
 }
 
 extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
-  const int lane = threadIdx.x, env = blockIdx.x;
-  if (env >= P.N) return;
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= P.N) return;
+  const int env = (P.order && P.mode == MODE_STEP) ? P.order[blockIdx.x] : (int)blockIdx.x;
   const Dev &T = *P.T;
   const int mode = P.mode;
   if (mode == MODE_RESET && P.mask && !P.mask[env]) return;
@@ -1803,6 +1806,7 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
   bool sim_err = false, done = false, after_reset = false;
   int reason = 0;
   unsigned stage_ncon = 0, stage_nefc_lo = 0;   // byte i = count at RK stage i (debug)
+  int work = 0;                                 // work estimate of this step (longest-first scheduling of the next one)
   float reward = 0;
   const float h = T.timestep;
   if (mode == MODE_STEP || mode == MODE_FORCED) {   // mj_checkPos / mj_checkVel
@@ -1813,6 +1817,7 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
   for (;;) {
     if (!sim_err) {
       forward(P, T, env, lane);   // the only call site: the evaluation is ~20 k instructions
+      work += 4000 + S.info[1] * (8 + 6 * S.info[3]) + 3000 * ((S.info[6] >> 16) & 0xFF);   // fixed part, rows x sweeps, MPR pairs
       if (mode == MODE_STEP && !after_reset) {   // [EXT] mj_step with mj_RungeKutta(4): A = (1/2, 1/2, 1), B = (1/6, 1/3, 1/3, 1/6)
         const float Bw = (stage == 0 || stage == 3) ? 1.f / 6 : 1.f / 3;
         stage_ncon |= ((unsigned)S.info[0] & 0xFF) << (8 * stage); stage_nefc_lo |= ((unsigned)S.info[1] & 0xFF) << (8 * stage);
@@ -2055,6 +2060,29 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
   if (lane < NV) { st[S_QVEL + lane] = S.qvel[lane]; st[S_WARM + lane] = S.warm[lane]; }
   if (lane < NU) st[S_CTRL + lane] = S.ctrl[lane];
   if (lane == 0) { sti[S_IDX] = idx_curr; sti[S_EPLEN] = ep_len; st[S_EPREW] = ep_rew; sti[S_RCNT] = rcnt; if (TASK) sti[S_MOTION] = motion; }
+  if (P.cost && mode == MODE_STEP && lane == 0) P.cost[env] = work;
+}
+
+// Longest-first launch order: env costs vary by an order of magnitude (a robot lying on the floor solves 100 rows for 50
+// sweeps, one that was just reset 45 rows for a few), and a batch is only ~2 rounds of resident waves, so the heavy envs must
+// start first.  One workgroup: 64 cost buckets (heaviest = bucket 0), histogram, prefix, scatter.  The order inside a
+// bucket is arbitrary — results do not depend on the launch order (outputs and RNG are keyed by env).
+extern "C" __global__ void __launch_bounds__(1024) g1_schedule_kernel(const int32_t *cost, int32_t *order, int N) {
+  __shared__ int hist[64], base[64], cmax;
+  const int t = threadIdx.x;
+  if (t < 64) hist[t] = 0;
+  if (t == 0) cmax = 1;
+  __syncthreads();
+  int m = 1;
+  for (int i = t; i < N; i += 1024) m = max(m, cost[i]);
+  atomicMax(&cmax, m);
+  __syncthreads();
+  const float sc = 64.f / ((float)cmax + 1.f);
+  for (int i = t; i < N; i += 1024) atomicAdd(&hist[63 - min(63, (int)((float)cost[i] * sc))], 1);
+  __syncthreads();
+  if (t == 0) { int a = 0; for (int b = 0; b < 64; b++) { base[b] = a; a += hist[b]; } }
+  __syncthreads();
+  for (int i = t; i < N; i += 1024) order[atomicAdd(&base[63 - min(63, (int)((float)cost[i] * sc))], 1)] = i;
 }
 
 extern "C" __global__ void g1_gather_kernel(const float *state, int N, int off, int n, int stride, float *out) {
@@ -2079,6 +2107,7 @@ struct DmG1Engine {
   double *dMesh = nullptr, *dClus = nullptr;
   int32_t *dOidx = nullptr;
   float *dState = nullptr, *dJT = nullptr, *dBT = nullptr, *dAR = nullptr, *dRowsE = nullptr, *dSepc = nullptr;
+  int32_t *dOrder = nullptr, *dCost = nullptr;
   float *dRows[3] = {nullptr, nullptr, nullptr}, *dReset[3] = {nullptr, nullptr, nullptr}, *dCom[3] = {nullptr, nullptr, nullptr}, *dDebug = nullptr;
   int L[3] = {0, 0, 0}, flags[3] = {0, 0, 0};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -2310,6 +2339,8 @@ extern "C" int dmg1_create(const void *model, size_t model_bytes, const DmG1Conf
   ok = ok && hipMalloc(&e->dRowsE, N * 5 * g1::MAXROW * sizeof(float)) == hipSuccess;
   ok = ok && hipMalloc(&e->dSepc, N * (4 * g1::SEPC + 4) * sizeof(float)) == hipSuccess;
   if (ok) hipMemset(e->dSepc, 0xFF, N * (4 * g1::SEPC + 4) * sizeof(float));   // pair id -1 everywhere
+  ok = ok && hipMalloc(&e->dOrder, N * sizeof(int32_t)) == hipSuccess && hipMalloc(&e->dCost, N * sizeof(int32_t)) == hipSuccess;
+  if (ok) hipMemset(e->dCost, 0, N * sizeof(int32_t));
   if (!ok) { dmg1_destroy(e); return DM_ENOMEM; }
   std::vector<float> init(N * g1::STATE, 0.f);
   for (size_t i = 0; i < N; i++)
@@ -2322,7 +2353,7 @@ extern "C" int dmg1_create(const void *model, size_t model_bytes, const DmG1Conf
 
 extern "C" int dmg1_destroy(DmG1Handle e) {
   if (!e) return DM_EINVAL;
-  hipFree(e->dT); hipFree(e->dMesh); hipFree(e->dOidx); hipFree(e->dClus); hipFree(e->dState); hipFree(e->dJT); hipFree(e->dBT); hipFree(e->dAR); hipFree(e->dRowsE); hipFree(e->dSepc);
+  hipFree(e->dT); hipFree(e->dMesh); hipFree(e->dOidx); hipFree(e->dClus); hipFree(e->dState); hipFree(e->dJT); hipFree(e->dBT); hipFree(e->dAR); hipFree(e->dRowsE); hipFree(e->dSepc); hipFree(e->dOrder); hipFree(e->dCost);
   for (int c = 0; c < 3; c++) { hipFree(e->dRows[c]); hipFree(e->dReset[c]); hipFree(e->dCom[c]); }
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
@@ -2378,6 +2409,11 @@ static int g1_launch(DmG1Engine *e, g1::Launch &P, void *stream, bool time_it) {
   if (const char *sk = getenv("DMG1_SKIP")) P.pad = atoi(sk);   // profiling aid: bit 0 no PGS sweeps, 1 no collision, 2 no A matrix, 3 no rows, 4 no constraint solve
   hipStream_t s = (hipStream_t)stream;
   if (time_it) hipEventRecord(e->ev0, s);
+  if (P.mode == g1::MODE_STEP && e->N >= 512 && !getenv("DMG1_NO_LPT")) {   // longest-first order from the previous step's costs
+    hipLaunchKernelGGL(g1::g1_schedule_kernel, dim3(1), dim3(1024), 0, s, e->dCost, e->dOrder, e->N);
+    P.order = e->dOrder;
+  }
+  if (P.mode == g1::MODE_STEP) P.cost = e->dCost;
   hipLaunchKernelGGL(g1::g1_step_kernel, dim3(e->N), dim3(64), 0, s, P);
   if (time_it) { hipEventRecord(e->ev1, s); e->timed = true; }
   return hipGetLastError() == hipSuccess ? DM_OK : g1_fail(e, DM_EHIP, "kernel launch failed");
