@@ -13,6 +13,8 @@ import random
 
 import numpy as np
 
+from .deepmimic_env import LazyInfos as _LazyInfos
+
 from . import _lib
 from .config import MotionConfig, RobotConfig
 from .deepmimic_env import Box, _SB3VecEnv, _SimView, _INFO_KEYS
@@ -281,21 +283,11 @@ class DPCombinedEnv:
         self._eng.close()
 
 
-class _LazyCombinedInfos:
-    def __init__(self, terms, reason, done, terminal_obs):
-        self._terms, self._reason, self._done, self._tobs = terms, reason, done, terminal_obs
+class _LazyCombinedInfos(_LazyInfos):
+    """`infos` of a DPCombinedEnv batch step: the list-like lazy container of deepmimic_env.LazyInfos (slices, item assignment,
+    ``isinstance(infos, list)``) with this env's info dict (imitation terms, imitation_reward, task_reward, done_reason)."""
 
-    def __len__(self):
-        return len(self._done)
-
-    def __getitem__(self, i):
-        info = _combined_info(self._terms[i], self._reason[i])
-        if self._done[i]:
-            info["terminal_observation"] = self._tobs[i].copy()
-        return info
-
-    def __iter__(self):
-        return (self[i] for i in range(len(self)))
+    _make = staticmethod(lambda terms, reason: _combined_info(terms, reason))
 
 
 class HipCombinedVecEnv(_SB3VecEnv):

@@ -267,6 +267,8 @@ class LazyInfos(list):
     ``isinstance(infos, (list, tuple))``) whose dicts are built on first access — 4096 dicts per step would dominate the
     numpy surface.  Unmaterialised slots hold ``None`` internally; every public access path materialises them."""
 
+    _make = staticmethod(lambda terms, reason: _make_info(terms, reason))
+
     def __init__(self, terms, reason, done, terminal_obs):
         super().__init__([None] * len(done))
         self._terms, self._reason, self._done, self._tobs = terms, reason, done, terminal_obs
@@ -276,7 +278,7 @@ class LazyInfos(list):
         if v is None:
             if i < 0:
                 i += len(self)
-            v = _make_info(self._terms[i], self._reason[i])
+            v = self._make(self._terms[i], self._reason[i])
             if self._done[i]:
                 v["terminal_observation"] = self._tobs[i].copy()
             list.__setitem__(self, i, v)

@@ -196,3 +196,22 @@ def test_dpenv_episode_reward_advances_before_the_obs_guard(model, clips):
     assert d and r == 0 and info == {} and np.all(o == 0)
     assert env.episode_length == 2 and env.episode_reward != before and np.isfinite(env.episode_reward)
     env.close()
+
+
+def test_combined_env_infos_are_list_like_too():
+    """DPCombinedEnv batches (humanoid3d and Unitree G1) hand SB3 the same list-like lazy infos as DPEnv batches."""
+    import numpy as np
+    from deepmimic_mujoco_amd.combined_env import _LazyCombinedInfos
+    n = 6
+    terms = np.arange(n * 8, dtype=np.float32).reshape(n, 8)
+    reason = np.array([0, 7, 3, 0, 0, 5], np.int32)
+    done = np.array([0, 1, 1, 0, 0, 1], bool)
+    tobs = np.ones((n, 98), np.float32)
+    infos = _LazyCombinedInfos(terms, reason, done, tobs)
+    assert isinstance(infos, list) and len(infos) == n
+    assert infos[1]["done_reason"] == "fallen without amnesty" and infos[1]["terminal_observation"].shape == (98,)
+    assert "terminal_observation" not in infos[0] and abs(infos[0]["task_reward"] - 6.0) < 1e-6
+    part = infos[2:4]
+    assert isinstance(part, list) and len(part) == 2 and part[0]["done_reason"] == "max_ep_len"
+    infos[3] = {"x": 1}
+    assert infos[3] == {"x": 1} and [type(i) for i in infos] == [dict] * n
