@@ -84,7 +84,7 @@ def _mlp_flops_per_step(B, D, H1, H2, A):
     return trunk(A) + trunk(1)
 
 
-def g1_record(local_rank, n=4096, steps=20, warmup=5):
+def g1_record(local_rank, n=4096, steps=20, warmup=5, with_cpu=False):
     """Auxiliary record: the second robot of the reference, DPEnv(robot="unitree_g1") — the robot its published figure
     (~1 390 env-steps/s, src/plot_profiling.py:486) was measured on.  Full step() with auto-reset, random actions in [-1, 1]
     (x 20 torque scale inside), walk clip, dmg1_step through the C-ABI; kernel time from HIP events inside the library."""
@@ -128,6 +128,22 @@ def g1_record(local_rank, n=4096, steps=20, warmup=5):
     rec["dp_combined_env"] = {"env_steps_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3,
                               "done_fraction_last_step": float(o["done"].float().mean()), "mean_reward": float(o["rew"].mean())}
     venv.close()
+    if with_cpu:   # the fp64 G1 oracle on 16 host threads, bounded sample of the same workload (checker code: CPU leg only)
+        import ctypes as C
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import oracle_g1 as og
+        L = og.lib()
+        L.dmo_bench_steps.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64]
+        L.dmo_bench_steps.restype = C.c_double
+        _, cm = og.g1_model()
+        clip = og.G1Clip(*mc.tables())
+        threads, nenv, nst = 16, 2, 60
+        with ThreadPoolExecutor(threads) as ex:
+            t0 = time.perf_counter()
+            list(ex.map(lambda k: L.dmo_bench_steps(C.byref(cm), C.byref(clip.c), nenv, nst, 77 + k), range(threads)))
+            dtc = time.perf_counter() - t0
+        rec["cpu_baseline"] = {"value": threads * nenv * nst / dtc, "unit": "env-steps/s", "cores": threads, "kind": "port",
+                               "sample": "%d threads x %d envs x %d random-torque steps, walk clip, fp64 G1 oracle" % (threads, nenv, nst)}
     return rec
 
 
@@ -376,7 +392,7 @@ def main():
     g1 = None
     if rank == 0 and not args.no_g1 and args.actions == "random" and N == 4096 and args.integrator != "Euler":
         try:
-            g1 = g1_record(local_rank)
+            g1 = g1_record(local_rank, with_cpu=(world == 1 and not args.no_cpu_baseline))
         except Exception as e:  # noqa: BLE001
             g1 = {"error": repr(e)[:300]}
 

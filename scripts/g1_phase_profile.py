@@ -23,3 +23,11 @@ print("kernel ms", eng.last_kernel_ms(), "mean stamped ticks per env-step %.0f (
 for i, nm in enumerate(names):
     if d[:, i].mean() > 0:
         print("%-22s %9.0f  %5.1f %%" % (nm, d[:, i].mean(), 100 * d[:, i].mean() / tot))
+tt = (d.sum(1) - d[:, 13])
+print("per-env stamped ticks: mean %.2fM p50 %.2fM p90 %.2fM p99 %.2fM max %.2fM; sum / 2048 slots = %.2fM" % (tt.mean() / 1e6, tt.median() / 1e6, tt.quantile(0.9) / 1e6, tt.quantile(0.99) / 1e6, tt.max() / 1e6, tt.sum() / 2048 / 1e6))
+full = dbg.cpu()
+nefc = full[:, 204]
+for lo, hi in ((0, 48), (48, 64), (64, 80), (80, 128), (128, 256)):
+    m = (nefc >= lo) & (nefc < hi)
+    if m.any():
+        print("last-stage rows %3d..%3d: %5d envs, mean ticks %.2fM, PGS %.2fM, MPR %.2fM" % (lo, hi, int(m.sum()), tt[m].mean() / 1e6, d[m, 12].mean() / 1e6, d[m, 6].mean() / 1e6))
