@@ -1639,6 +1639,56 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
       if (improvement * T.pgs_scale < T.tolerance) break;
     }
     fr[0] = f0;
+  } else if (nefc <= 128) {
+    // 65..128 rows (bodies on the floor — the envs that set the launch time): rows j and j + 64 per lane; the first 64 sweep
+    // steps run as above on two register rows of A (columns 0..63), the steps for rows 64.. take their A rows from the
+    // scratch, prefetched a block ahead
+    float ar0[64], ar1[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) { ar0[i] = AR[i * MAXROW + lane]; ar1[i] = (lane + 64 < nefc) ? AR[i * MAXROW + lane + 64] : 0.f; }
+    float res0 = res[0], res1 = res[1], f0 = fr[0], f1 = fr[1];
+    const float ainv0 = dinv[0], aii0 = diag[0], fl0 = lm[0], ainv1 = dinv[1], aii1 = diag[1], fl1 = lm[1];
+    while (iter < max_iter) {
+      float improvement = 0;
+      StaticFor<0, 64>::run([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const float rs_ = bcast(res0, i), old_ = bcast(f0, i), ai_ = bcast(ainv0, i), fl_ = bcast(fl0, i), aii_ = bcast(aii0, i);
+        float f_ = fmaf(-rs_, ai_, old_);
+        f_ = (fl_ >= 0.f) ? fminf(fmaxf(f_, -fl_), fl_) : fmaxf(f_, 0.f);
+        const float dl_ = f_ - old_;
+        improvement -= dl_ * fmaf(0.5f * dl_, aii_, rs_);
+        f0 = (lane == i) ? f_ : f0;
+        res0 = fmaf(ar0[i], dl_, res0);
+        res1 = fmaf(ar1[i], dl_, res1);
+        return true;
+      });
+      for (int i0 = 64; i0 < nefc; i0 += PF) {
+        float a0[PF], a1[PF];
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+          const int i = i0 + q;
+          a0[q] = (i < nefc) ? AR[i * MAXROW + lane] : 0.f;
+          a1[q] = (i < nefc && lane + 64 < nefc) ? AR[i * MAXROW + lane + 64] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+          const int src = i0 + q - 64;
+          if (i0 + q < nefc) {
+            const float rs_ = bcast(res1, src), old_ = bcast(f1, src), ai_ = bcast(ainv1, src), fl_ = bcast(fl1, src), aii_ = bcast(aii1, src);
+            float f_ = fmaf(-rs_, ai_, old_);
+            f_ = (fl_ >= 0.f) ? fminf(fmaxf(f_, -fl_), fl_) : fmaxf(f_, 0.f);
+            const float dl_ = f_ - old_;
+            improvement -= dl_ * fmaf(0.5f * dl_, aii_, rs_);
+            f1 = (lane == src) ? f_ : f1;
+            res0 = fmaf(a0[q], dl_, res0);
+            res1 = fmaf(a1[q], dl_, res1);
+          }
+        }
+      }
+      iter++;
+      if (improvement * T.pgs_scale < T.tolerance) break;
+    }
+    fr[0] = f0; fr[1] = f1;
   } else {
   const int n0 = nefc < 64 ? nefc : 64, n1 = nefc < 128 ? nefc : 128;
   while (iter < max_iter) {
