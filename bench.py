@@ -108,10 +108,28 @@ def g1_record(local_rank, n=4096, steps=20, warmup=5, with_cpu=False):
         eng.step(acts[t % 8], out)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    kms = eng.last_kernel_ms()
     rec = {"robot": "unitree_g1 (43 DoF, 32 convex meshes, friction loss)", "envs_per_gpu": n, "steps": steps,
            "env_steps_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3, "kernel": "g1_step_kernel",
            "kernel_ms_last": eng.last_kernel_ms(), "done_fraction_last_step": float(out["done"].float().mean()),
            "reference_published_env_steps_per_s": 1390, "note": "auxiliary: SURVEY 8f-2 (next row), not the headline metric"}
+    try:   # what bounds g1_step_kernel: instruction issue / latency, from the committed PMC file of the same command
+        import csv
+        path = os.path.join(ROOT, "profiles", "r02_g1_pmc_g1_step_kernel.csv")
+        v = {r["counter"]: float(r["mean_per_dispatch_over_last_10_dispatches"]) for r in csv.DictReader(open(path))}
+        w = v["SQ_WAVES"]
+        wave_cycles = 4.0 * v["SQ_WAVE_CYCLES"] / w
+        launch_cycles = kms * 1e-3 * 2.4e9
+        rec["valu"] = {"valu_per_env_step": v["SQ_INSTS_VALU"] / w, "salu_per_env_step": v["SQ_INSTS_SALU"] / w,
+                       "lds_per_env_step": v["SQ_INSTS_LDS"] / w, "vmem_per_env_step": v["SQ_INSTS_VMEM"] / w,
+                       "wave_cycles_per_env_step": wave_cycles, "cycles_per_instruction": wave_cycles / ((v["SQ_INSTS_VALU"] + v["SQ_INSTS_SALU"] + v["SQ_INSTS_LDS"] + v["SQ_INSTS_VMEM"]) / w),
+                       "issue_frac_launch": n * (v["SQ_INSTS_VALU"] / w) * 2.0 / (1024 * launch_cycles),
+                       "wait_frac": v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], "resident_waves_per_simd": 2,
+                       "hbm_bytes_per_env_step": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 / n,
+                       "algorithmic_bytes_per_env_step": 4 * (44 + 43 + 43 + 23 + 4 + 44 + 43 + 43 + 85 + 1 + 5 + 2 + 2),
+                       "counters_from": "profiles/r02_g1_pmc_g1_step_kernel.csv"}
+    except Exception as e:  # noqa: BLE001
+        rec["valu"] = {"error": repr(e)[:200]}
     eng.close()
     # DPCombinedEnv() as src/sb3_ppo.py:277-278 trains it: walk / run / getup state machine on the G1, RSI auto-reset
     from deepmimic_mujoco_amd.g1 import HipG1CombinedVecEnv

@@ -123,3 +123,10 @@ def test_g1_clips_load(motion):
     q = np.array(mc.data_config)
     assert q.shape[1] == 44 and np.allclose(np.linalg.norm(q[:, 3:7], axis=1), 1, atol=0.05)     # interpolated quaternions are not renormalised (mocap_v2.py:325)
     assert abs(mc.dt - 0.01666) < 1e-4
+
+
+def test_generated_g1_topology_header_matches_the_xml(g1):
+    """csrc/dm_g1_topology.h (the compile-time 43-dof tree the G1 kernel's row solves are unrolled over) is in sync with the asset."""
+    from deepmimic_mujoco_amd import gen_topology
+    assert open(gen_topology.OUT_G1).read() == gen_topology.render_g1(g1)
+    assert list(g1.dof_parent[:7]) == [-1, 0, 1, 2, 3, 4, 5] and g1.dof_parent[12] == 5 and g1.dof_parent[18] == 5 and g1.nM == 434
