@@ -250,7 +250,15 @@ class DPEnv:
         return self._time
 
     def render(self, mode=None):
-        raise NotImplementedError("rendering needs a MuJoCo viewer; out of scope (SURVEY §8f-4)")
+        """Software stick figure (render.py) of the current body poses: there is no MuJoCo viewer behind this env."""
+        from .render import stick_figure
+        if self._eng._debug is None:
+            self._eng.enable_debug()
+        q, v, w, c = self._eng.get_state()
+        self._eng.forward()                                     # refresh the derived arrays of the stored state ...
+        self._eng.set_state(q, v, warm=w, ctrl=c, run_forward=False)   # ... and put the warm start back: rendering is not physics
+        xpos = self._eng._debug[0, :42].double().cpu().numpy().reshape(14, 3)
+        return stick_figure(xpos, self.model.body_parent)
 
     def seed(self, seed=None):
         random.seed(seed)

@@ -469,6 +469,17 @@ class G1DPEnv:
         self._eng.set_state(t.tensor(np.asarray(qpos)[None], dtype=t.float32, device=self._eng.device),
                             t.tensor(np.asarray(qvel)[None], dtype=t.float32, device=self._eng.device))
 
+    def render(self, mode=None):
+        """Software stick figure (render.py) of the current body poses."""
+        from .render import stick_figure
+        if self._eng._debug is None:
+            self._eng.enable_debug()
+        q, v, w = self._eng.get_state()
+        self._eng.set_state(q, v, warm=w, run_forward=True)     # refresh the derived arrays; the warm start is put back
+        self._eng.set_state(q, v, warm=w, run_forward=False)
+        xpos = self._eng._debug[0, :117].double().cpu().numpy().reshape(39, 3)
+        return stick_figure(xpos, self.model.body_parent)
+
     def close(self):
         self._eng.close()
 
@@ -624,6 +635,17 @@ class G1CombinedEnv:
         if REASONS.get(reason):
             info["done_reason"] = REASONS[reason]
         return obs, reward, done, info
+
+    def render(self, mode=None):
+        """Software stick figure (render.py) of the current body poses."""
+        from .render import stick_figure
+        if self._eng._debug is None:
+            self._eng.enable_debug()
+        q, v, w = self._eng.get_state()
+        self._eng.set_state(q, v, warm=w, run_forward=True)     # refresh the derived arrays; the warm start is put back
+        self._eng.set_state(q, v, warm=w, run_forward=False)
+        xpos = self._eng._debug[0, :117].double().cpu().numpy().reshape(39, 3)
+        return stick_figure(xpos, self.model.body_parent)
 
     def close(self):
         self._eng.close()

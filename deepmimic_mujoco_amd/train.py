@@ -37,6 +37,9 @@ def main(argv=None):
                          "than the plain loop on ROCm 7.2: ~5 us per graph node x 2 200 nodes)")
     ap.add_argument("--rollout-graph", action="store_true", help="with --sub-batches > 1: capture the rollout as one hipGraph")
     ap.add_argument("--json", action="store_true", help="print a JSON throughput summary on rank 0")
+    ap.add_argument("--eval-every", type=int, default=0, help="eval dashboard every N global steps (src/sb3_ppo.py:313 EVAL_N); 0 = off")
+    ap.add_argument("--run-name", default="run")
+    ap.add_argument("--eval-dir", default="~/deep_mimic")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + several ranks on one GPU only rehearses the multi-rank path")
     args = ap.parse_args(argv)
@@ -69,8 +72,24 @@ def main(argv=None):
               batch_size=args.minibatch, n_epochs=args.epochs, learning_rate=args.lr, seed=args.seed,
               buffer_dtype=torch.bfloat16 if args.bf16_buffer else torch.float32, rollout_graph=args.rollout_graph)
     hist = []
+    dash = None
+    if args.eval_every > 0 and rank == 0:                               # src/sb3_ppo.py:273-313: one eval env next to the batch
+        from .eval_dashboard import EvalDashboardCallback
+        if args.env == "dp_combined_env":
+            from .combined_env import DPCombinedEnv
+            eval_env = DPCombinedEnv(robot=args.robot, device=local_rank)
+        else:
+            from .deepmimic_env import DPEnv
+            eval_env = DPEnv(motions[0], robot=args.robot, device=local_rank)
+        dash = EvalDashboardCallback(eval_env, args.motion + "_" + args.run_name, every_n_global_steps=args.eval_every, out_root=args.eval_dir)
+
+    def _cb(p):
+        hist.append(dict(p.stats))
+        if dash is not None:
+            dash(p)
+        return True
     t0 = time.perf_counter()
-    ppo.learn(args.total, log_interval=0 if args.json else 1, callback=lambda p: hist.append(dict(p.stats)))
+    ppo.learn(args.total, log_interval=0 if args.json else 1, callback=_cb)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:

@@ -312,3 +312,32 @@ def test_ppo_iteration_on_the_g1_combined_env():
     assert any((p.detach() - q).abs().max() > 0 for p, q in zip(ppo.policy.parameters(), w0))
     assert np.isfinite(ppo.stats["mean_reward"]) and np.isfinite(ppo.stats.get("loss", 0.0))
     env.close()
+
+
+def test_render_and_eval_dashboard_on_the_real_envs(tmp_path):
+    """render(mode="rgb_array") (software stick figure) on DPEnv humanoid3d / G1 and DPCombinedEnv(); rendering must not disturb
+    the physics (same next step with and without a render call); one dashboard episode with a PPO policy on the G1 env."""
+    import torch
+    from deepmimic_mujoco_amd.combined_env import DPCombinedEnv
+    from deepmimic_mujoco_amd.deepmimic_env import DPEnv, HipDeepMimicVecEnv
+    from deepmimic_mujoco_amd.eval_dashboard import eval_dashboard_rollout
+    from deepmimic_mujoco_amd.ppo import PPO
+    for make in (lambda: DPEnv("walk"), lambda: DPEnv("walk", robot="unitree_g1"), lambda: DPCombinedEnv()):
+        e1, e2 = make(), make()
+        o1 = e1.reset_model(idx_init=3) if hasattr(e1, "reset_model") else e1.reset(rsi=False)
+        o2 = e2.reset_model(idx_init=3) if hasattr(e2, "reset_model") else e2.reset(rsi=False)
+        assert np.array_equal(o1, o2)
+        act = np.full(e1.action_space.shape[0], 0.1)
+        for t in range(3):
+            img = e1.render(mode="rgb_array")
+            assert img.shape == (240, 320, 3) and len(np.unique(img.reshape(-1, 3), axis=0)) >= 4
+            a, b = e1.step(act), e2.step(act)
+            assert np.array_equal(a[0], b[0]) and a[1] == b[1], "render changed the physics"
+        e1.close(); e2.close()
+    venv = HipDeepMimicVecEnv(64, motion="walk", robot="unitree_g1", seed=1)
+    ppo = PPO(venv, n_steps=4, batch_size=128, n_epochs=1, seed=0)
+    ev = DPEnv("walk", robot="unitree_g1")
+    ep_len, ep_rew = eval_dashboard_rollout(ppo, ev, 123, "g1test", out_root=str(tmp_path), max_steps=30)
+    assert 1 <= ep_len <= 30 and np.isfinite(ep_rew)
+    assert (tmp_path / "g1test_videos" / "global_step_123.gif").exists() and (tmp_path / "g1test_videos" / "log.csv").exists()
+    ev.close(); venv.close()
