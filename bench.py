@@ -408,7 +408,7 @@ def main():
             ppo_loop = {"error": repr(e)[:300]}
 
     g1 = None
-    if rank == 0 and not args.no_g1 and args.actions == "random" and N == 4096 and args.integrator != "Euler":
+    if world == 1 and not args.no_g1 and args.actions == "random" and N == 4096 and args.integrator != "Euler":   # single-GPU runs only
         try:
             g1 = g1_record(local_rank, with_cpu=(world == 1 and not args.no_cpu_baseline))
         except Exception as e:  # noqa: BLE001
