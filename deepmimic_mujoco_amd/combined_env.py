@@ -362,24 +362,37 @@ class HipCombinedVecEnv(_SB3VecEnv):
         self.engine.close()
 
     def seed(self, seed=None):
-        return [None] * self.num_envs
+        """SB3 VecEnv.seed: re-keys the engine's counter-based reset generator; returns the per-env seeds SB3 expects."""
+        if seed is None:
+            return [None] * self.num_envs
+        self.engine.set_seed(int(seed))
+        return [int(seed) + i for i in range(self.num_envs)]
+
+    def _n_indices(self, indices):
+        return self.num_envs if indices is None else len(np.atleast_1d(indices))
 
     def get_attr(self, attr_name, indices=None):
-        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
-        return [getattr(self, attr_name)] * n
+        return [getattr(self, attr_name)] * self._n_indices(indices)
 
     def set_attr(self, attr_name, value, indices=None):
         setattr(self, attr_name, value)
 
-    def env_method(self, method_name, *args, indices=None, **kwargs):
-        raise NotImplementedError("per-env method calls have no batched equivalent")
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        """One batch object stands for all envs (as in HipDeepMimicVecEnv): the method runs once on it."""
+        return [getattr(self, method_name)(*method_args, **method_kwargs)] * self._n_indices(indices)
 
     def env_is_wrapped(self, wrapper_class, indices=None):
-        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
-        return [False] * n
+        return [False] * self._n_indices(indices)
+
+    def getattr_depth_check(self, name, already_found):
+        return None
+
+    @property
+    def unwrapped(self):
+        return self
 
     def get_images(self):
-        raise NotImplementedError("rendering is out of scope (SURVEY §8f-4)")
+        return [None] * self.num_envs
 
     def render(self, mode=None):
-        raise NotImplementedError("rendering is out of scope (SURVEY §8f-4)")
+        return None

@@ -373,13 +373,34 @@ class HipG1VecEnv:
     def seed(self, seed=None):
         return [None if seed is None else int(seed) + i for i in range(self.num_envs)]
 
+    # ---- the rest of SB3's VecEnv surface (same conventions as HipDeepMimicVecEnv: one batch object stands for all envs)
+    def _n_indices(self, indices):
+        return self.num_envs if indices is None else len(np.atleast_1d(indices))
+
     def get_attr(self, attr_name, indices=None):
-        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
-        return [getattr(self, attr_name)] * n
+        return [getattr(self, attr_name)] * self._n_indices(indices)
+
+    def set_attr(self, attr_name, value, indices=None):
+        setattr(self, attr_name, value)
+
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        return [getattr(self, method_name)(*method_args, **method_kwargs)] * self._n_indices(indices)
 
     def env_is_wrapped(self, wrapper_class, indices=None):
-        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
-        return [False] * n
+        return [False] * self._n_indices(indices)
+
+    def getattr_depth_check(self, name, already_found):
+        return None
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def get_images(self):
+        return [None] * self.num_envs
+
+    def render(self, mode=None):
+        return None
 
 
 class G1DPEnv:

@@ -215,3 +215,14 @@ def test_combined_env_infos_are_list_like_too():
     assert isinstance(part, list) and len(part) == 2 and part[0]["done_reason"] == "max_ep_len"
     infos[3] = {"x": 1}
     assert infos[3] == {"x": 1} and [type(i) for i in infos] == [dict] * n
+
+
+def test_every_batch_env_class_has_the_vecenv_surface():
+    """The combined-env and the Unitree G1 batch classes expose the same SB3 VecEnv surface as HipDeepMimicVecEnv."""
+    from deepmimic_mujoco_amd.combined_env import HipCombinedVecEnv
+    from deepmimic_mujoco_amd.g1 import HipG1CombinedVecEnv, HipG1VecEnv
+    for cls in (HipCombinedVecEnv, HipG1VecEnv, HipG1CombinedVecEnv):
+        for name in list(SB3VecEnvABC.__abstractmethods__) + NON_ABSTRACT:
+            assert hasattr(cls, name), (cls.__name__, name)
+        for name in ("get_attr", "set_attr", "env_method", "env_is_wrapped"):
+            assert "indices" in inspect.signature(getattr(cls, name)).parameters, (cls.__name__, name)
