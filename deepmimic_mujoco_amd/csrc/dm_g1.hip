@@ -135,9 +135,19 @@ struct Launch {
 };
 
 // ------------------------------------------------------------------------------------------ small math (fp32)
+// sum over the 64 lanes, uniform in every lane: four DPP steps inside each row of 16, the four row sums through v_readlane
+// (~12 instructions; six LDS-permute round trips would sit in every dependent chain that reduces)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wsum(float v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v);   // row_half_mirror
+  v += dpp_f32<0x140>(v);   // row_mirror
+  return (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16))) +
+         (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48)));
 }
 __device__ __forceinline__ void cross3(float *r, const float *a, const float *b) {
   float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];

