@@ -265,6 +265,332 @@ extern "C" int dm_colsum(const float *Y, int B, int O, float *out, void *stream)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// First layer of a wide policy / value trunk ([1024,512] of BASELINE configs 3-5): Y = tanh(X W^T + b) with X [B x I], I <= 128
+// (the observation: 67 / 72 / 85 / 98 wide), W [O x I], Y [B x O].  K is so short that the layer is bound by writing Y; the
+// library runs the GEMM at 30 TFLOP/s (unaligned K) and the framework adds a separate 2 x 16 MB tanh pass.  Here a workgroup
+// stages a 64-row block of X and a 128-row block of W in LDS (both are CONTIGUOUS in memory: flat 16-byte copies; row stride
+// I + 1 odd-ised in LDS = conflict-free column reads), each of its four waves owns 32 x 64 outputs on v_mfma_f32_32x32x2f32,
+// and bias + tanh are applied on the accumulators: Y is written once, coalesced, and never read back by an activation pass.
+namespace {
+
+constexpr int LT_ROWS = 64, LT_COLS = 128, LT_MAXI = 128;
+
+// tanh without branches (the library routine is ~90 instructions with six branches: 4 M activations of one launch were 11 us
+// of VALU issue).  |x| < 0.25: odd Taylor polynomial to x^9 (next term 9e-9 relative); otherwise 1 - 2 / (exp(2x) + 1) on
+// v_exp_f32 / v_rcp_f32 (absolute error ~1e-7 where |tanh| >= 0.24; exp overflow gives exactly +-1).
+__device__ __forceinline__ float lt_tanh(float x) {
+  const float s = x * x;
+  const float poly = x * (1.f + s * (-0.33333333f + s * (0.13333333f + s * (-0.053968254f + s * 0.021869488f))));
+  const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);          // exp(2x)
+  const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
+  return fabsf(x) < 0.25f ? poly : big;
+}
+
+__global__ void __launch_bounds__(256) ppo_linear_tanh_kernel(const float *__restrict__ X, const float *__restrict__ W,
+                                                              const float *__restrict__ bias, float *__restrict__ Y, int B, int O,
+                                                              int I, int vec) {
+  extern __shared__ float lt_lds[];
+  const int ld = I | 1;                                // odd row stride: lanes r = 0..31 hit 32 different banks
+  float *xs = lt_lds, *ws = lt_lds + LT_ROWS * ld;
+  const int b0 = blockIdx.x * LT_ROWS, o0 = blockIdx.y * LT_COLS;
+  const int nx = min(LT_ROWS, B - b0) * I, nw = min(LT_COLS, O - o0) * I;
+  const float *xg = X + (size_t)b0 * I, *wg = W + (size_t)o0 * I;
+  // both blocks are contiguous and 16-byte aligned in memory (64 | b0, 128 | o0): 16-byte loads, all requested before the
+  // first LDS write (a plain copy loop waits for every load before the next)
+  const bool odd = I & 1;                              // ld == I: the LDS image is the memory image
+  if (vec && nx == LT_ROWS * I && nw == LT_COLS * I) {
+    const float4 *x4 = (const float4 *)xg, *w4 = (const float4 *)wg;
+    const int n4x = (LT_ROWS * I) >> 2, n4 = n4x + ((LT_COLS * I) >> 2);
+    for (int base = 0; base < n4; base += 256 * 16) {  // one round trip up to I = 85, two beyond
+      float4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int t = base + u * 256 + (int)threadIdx.x;
+        if (t < n4) v[u] = t < n4x ? x4[t] : w4[t - n4x];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int t = base + u * 256 + (int)threadIdx.x;
+        if (t < n4) {
+          float *dst = t < n4x ? xs : ws;
+          const int e = 4 * (t < n4x ? t : t - n4x);
+          if (odd) {
+            *(float4 *)(dst + e) = v[u];
+          } else {                                     // a 16-byte group may straddle two rows (I even, >= 4)
+            const int row = e / I, c = e - row * I;
+            const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const int cc = c + q, rr = row + (cc >= I);
+              dst[rr * ld + (cc >= I ? cc - I : cc)] = vv[q];
+            }
+          }
+        }
+      }
+    }
+  } else {
+    auto fill = [&](float *dst, const float *src, int total, int valid) {
+      for (int base = 0; base < total; base += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int t = base + u * 256 + (int)threadIdx.x;
+          v[u] = t < valid ? src[t] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int t = base + u * 256 + (int)threadIdx.x;
+          if (t < total) dst[odd ? t : t + t / I] = v[u];
+        }
+      }
+    };
+    fill(xs, xg, LT_ROWS * I, nx);
+    fill(ws, wg, LT_COLS * I, nw);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int wr = (w & 1) * 32, wc = (w >> 1) * 64;
+  ppo_f16v acc0, acc1;
+#pragma unroll
+  for (int j = 0; j < 16; j++) acc0[j] = acc1[j] = 0.f;
+  const float *xa = xs + (wr + r) * ld + h, *wb0 = ws + (wc + r) * ld + h, *wb1 = ws + (wc + 32 + r) * ld + h;
+  const int K2 = I & ~1;
+  int k = 0;
+  for (; k + 8 <= K2; k += 8) {                        // twelve LDS reads requested, then eight matrix instructions
+    float a[4], p0[4], p1[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      a[u] = xa[k + 2 * u];
+      p0[u] = wb0[k + 2 * u];
+      p1[u] = wb1[k + 2 * u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], p0[u], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], p1[u], acc1, 0, 0, 0);
+    }
+  }
+  for (; k < K2; k += 2) {
+    const float a = xa[k];
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb0[k], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb1[k], acc1, 0, 0, 0);
+  }
+  if (I & 1) {                                         // odd K: the second half of the last k pair is zero
+    const float a = h == 0 ? xa[K2] : 0.f;
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h == 0 ? wb0[K2] : 0.f, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h == 0 ? wb1[K2] : 0.f, acc1, 0, 0, 0);
+  }
+  const int c0 = o0 + wc + r, c1 = c0 + 32;
+  const float bb0 = c0 < O ? bias[c0] : 0.f, bb1 = c1 < O ? bias[c1] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const int row = b0 + wr + (j >> 2) * 8 + h * 4 + (j & 3);
+    if (row < B) {
+      if (c0 < O) Y[(size_t)row * O + c0] = lt_tanh(acc0[j] + bb0);
+      if (c1 < O) Y[(size_t)row * O + c1] = lt_tanh(acc1[j] + bb1);
+    }
+  }
+}
+
+// Backward of that layer when its input needs no gradient (the observation): dW[o][i] += sum_b g[b][o] X[b][i] and
+// db[o] += sum_b g[b][o] with g = dY * (1 - Y^2) formed on the fly — the tanh-backward pass (read 2 x 16 MB, write 16 MB) and
+// the 16 MB intermediate disappear, and dY / Y are read once: a wave owns 32 outputs x ALL input tiles (NT x 32 columns).
+template <int NT>
+__global__ void __launch_bounds__(512) ppo_tanh_wgrad_kernel(const float *__restrict__ dY, const float *__restrict__ Yt,
+                                                             const float *__restrict__ X, float *dW, float *db, int B, int O, int I,
+                                                             int rows_per_group) {
+  // eight waves share one 32-output tile and split the group's rows, so the global float atomics carry one tile per WORKGROUP
+  __shared__ float part[8][1024];
+  __shared__ float dbpart[8][32];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int o0 = blockIdx.x * 32;
+  const int g0 = blockIdx.y * rows_per_group, g1 = min(B, g0 + rows_per_group);
+  const int per_wave = (((g1 - g0) + 7) / 8 + 31) & ~31;                 // multiple of the 32-row load group
+  const int wb0 = g0 + w * per_wave, wb1 = min(g1, wb0 + per_wave);
+  const bool oa = (o0 + r) < O;
+  bool ia[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) ia[t] = (t * 32 + r) < I;
+  ppo_f16v acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++)
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc[t][j] = 0.f;
+  float dbacc = 0.f;
+  constexpr int U = 16;
+  for (int b = wb0; b < wb1; b += 2 * U) {
+    float g[U], y[U], x[NT][U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int row = b + 2 * u + h;
+      const bool ra = row < wb1;
+      g[u] = (oa && ra) ? dY[(size_t)row * O + o0 + r] : 0.f;
+      y[u] = (oa && ra) ? Yt[(size_t)row * O + o0 + r] : 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; t++) x[t][u] = (ia[t] && ra) ? X[(size_t)row * I + t * 32 + r] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const float a = g[u] * (1.f - y[u] * y[u]);
+#pragma unroll
+      for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x[t][u], acc[t], 0, 0, 0);
+      dbacc += a;
+    }
+  }
+  // the eight partial tiles meet in LDS with plain stores, one input tile at a time, and every thread sums two elements
+  // (float atomics on LDS cost 30 us here: eight waves adding into the same 3 072 words)
+  const float v = dbacc + __shfl_xor(dbacc, 32);
+  if (h == 0) dbpart[w][r] = v;
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    if (t) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const int row = (j >> 2) * 8 + h * 4 + (j & 3);
+      part[w][row * 32 + r] = acc[t][j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int e = threadIdx.x + q * 512, row = e >> 5, c = t * 32 + (e & 31);
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; k++) sum += part[k][e];
+      if ((o0 + row) < O && c < I) atomicAdd(&dW[(size_t)(o0 + row) * I + c], sum);
+    }
+  }
+  if (threadIdx.x < 32 && (o0 + (int)threadIdx.x) < O) {
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) sum += dbpart[k][threadIdx.x];
+    atomicAdd(&db[o0 + threadIdx.x], sum);
+  }
+}
+
+// Backward of tanh for the layers that keep the library GEMMs: dZ = dY * (1 - Y^2) (dZ may alias dY) and db[o] += sum_b dZ[b][o]
+// in one pass — the framework's tanh-backward launch plus the separate column-sum read of dZ.
+__global__ void __launch_bounds__(256) ppo_tanh_bwd_colsum_kernel(const float *dY, const float *__restrict__ Yt, float *dZ, int B, int O,
+                                                                  int rows_per_block, float *db) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(B, r0 + rows_per_block);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < O) {
+    int r = r0 + g;
+    for (; r + 12 < r1; r += 16) {
+      const size_t i0 = (size_t)r * O + c, i1 = i0 + (size_t)4 * O, i2 = i0 + (size_t)8 * O, i3 = i0 + (size_t)12 * O;
+      const float g0 = dY[i0], g1 = dY[i1], g2 = dY[i2], g3 = dY[i3];
+      const float y0 = Yt[i0], y1 = Yt[i1], y2 = Yt[i2], y3 = Yt[i3];
+      const float z0 = g0 * (1.f - y0 * y0), z1 = g1 * (1.f - y1 * y1), z2 = g2 * (1.f - y2 * y2), z3 = g3 * (1.f - y3 * y3);
+      dZ[i0] = z0; dZ[i1] = z1; dZ[i2] = z2; dZ[i3] = z3;
+      s0 += z0; s1 += z1; s2 += z2; s3 += z3;
+    }
+    for (; r < r1; r += 4) {
+      const size_t i0 = (size_t)r * O + c;
+      const float y0 = Yt[i0], z0 = dY[i0] * (1.f - y0 * y0);
+      dZ[i0] = z0;
+      s0 += z0;
+    }
+  }
+  red[g][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0 && c < O) atomicAdd(&db[c], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
+// the same with 16-byte accesses (O a multiple of 4): a block owns 64 columns x 64 rows, a thread four columns x four rows
+__global__ void __launch_bounds__(256) ppo_tanh_bwd_colsum4_kernel(const float *dY, const float *__restrict__ Yt, float *dZ, int B, int O,
+                                                                   float *db) {
+  __shared__ float red[16][64];
+  const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cg * 4, r0 = blockIdx.y * 64 + rg;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < O) {
+    float4 g[4], y[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int r = r0 + 16 * u;
+      if (r < B) {
+        g[u] = *(const float4 *)(dY + (size_t)r * O + c);
+        y[u] = *(const float4 *)(Yt + (size_t)r * O + c);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int r = r0 + 16 * u;
+      if (r < B) {
+        float4 z;
+        z.x = g[u].x * (1.f - y[u].x * y[u].x);
+        z.y = g[u].y * (1.f - y[u].y * y[u].y);
+        z.z = g[u].z * (1.f - y[u].z * y[u].z);
+        z.w = g[u].w * (1.f - y[u].w * y[u].w);
+        *(float4 *)(dZ + (size_t)r * O + c) = z;
+        s.x += z.x; s.y += z.y; s.z += z.z; s.w += z.w;
+      }
+    }
+  }
+  red[rg][cg * 4 + 0] = s.x; red[rg][cg * 4 + 1] = s.y; red[rg][cg * 4 + 2] = s.z; red[rg][cg * 4 + 3] = s.w;
+  __syncthreads();
+  if (threadIdx.x < 64 && blockIdx.x * 64 + (int)threadIdx.x < O) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t += red[k][threadIdx.x];
+    atomicAdd(&db[blockIdx.x * 64 + threadIdx.x], t);
+  }
+}
+
+}  // namespace
+
+extern "C" int dm_linear_tanh(const float *X, const float *W, const float *bias, float *Y, int B, int O, int I, void *stream) {
+  if (!X || !W || !bias || !Y || B < 1 || O < 1 || I < 1 || I > LT_MAXI) return -22;
+  const size_t lds = (size_t)(LT_ROWS + LT_COLS) * (I | 1) * sizeof(float);         // <= 99 KB at I = 128
+  static bool attr_done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -5;
+  if (!attr_done[dev]) {
+    if (hipFuncSetAttribute((const void *)ppo_linear_tanh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) != hipSuccess)
+      return -5;
+    attr_done[dev] = true;
+  }
+  hipLaunchKernelGGL(ppo_linear_tanh_kernel, dim3((B + LT_ROWS - 1) / LT_ROWS, (O + LT_COLS - 1) / LT_COLS), dim3(256), lds,
+                     (hipStream_t)stream, X, W, bias, Y, B, O, I, ((((uintptr_t)X | (uintptr_t)W) & 15) == 0 && I >= 4) ? 1 : 0);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// dW [O x I] and db [O] must be zero on entry (stream-ordered).  I <= 128.
+extern "C" int dm_tanh_linear_wgrad(const float *dY, const float *Y, const float *X, float *dW, float *db, int B, int O, int I,
+                                    void *stream) {
+  if (!dY || !Y || !X || !dW || !db || B < 1 || O < 1 || I < 1 || I > 128) return -22;
+  const int ot = (O + 31) / 32, nt = (I + 31) / 32;
+  int groups = 1;                                      // workgroups per output tile: enough to cover the chip once
+  while (groups * 2 * ot <= 256 && B / (groups * 2) >= 256) groups *= 2;
+  const int rpg = (B + groups - 1) / groups;
+  const dim3 grid(ot, groups), block(512);
+  hipStream_t s = (hipStream_t)stream;
+  switch (nt) {
+    case 1: hipLaunchKernelGGL(ppo_tanh_wgrad_kernel<1>, grid, block, 0, s, dY, Y, X, dW, db, B, O, I, rpg); break;
+    case 2: hipLaunchKernelGGL(ppo_tanh_wgrad_kernel<2>, grid, block, 0, s, dY, Y, X, dW, db, B, O, I, rpg); break;
+    case 3: hipLaunchKernelGGL(ppo_tanh_wgrad_kernel<3>, grid, block, 0, s, dY, Y, X, dW, db, B, O, I, rpg); break;
+    default: hipLaunchKernelGGL(ppo_tanh_wgrad_kernel<4>, grid, block, 0, s, dY, Y, X, dW, db, B, O, I, rpg); break;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// dZ = dY * (1 - Y^2) (dZ may be dY), db[o] += column sums of dZ (db zeroed by the caller, stream-ordered).
+extern "C" int dm_tanh_bwd_colsum(const float *dY, const float *Y, float *dZ, float *db, int B, int O, void *stream) {
+  if (!dY || !Y || !dZ || !db || B < 1 || O < 1) return -22;
+  const int cb = (O + 63) / 64;
+  if ((O & 3) == 0 && ((uintptr_t)dY & 15) == 0 && ((uintptr_t)Y & 15) == 0 && ((uintptr_t)dZ & 15) == 0) {
+    hipLaunchKernelGGL(ppo_tanh_bwd_colsum4_kernel, dim3(cb, (B + 63) / 64), dim3(256), 0, (hipStream_t)stream, dY, Y, dZ, B, O, db);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+  }
+  int slices = 1;
+  while (slices * 2 * cb <= 2048 && B / (slices * 2) >= 32) slices *= 2;
+  const int rpb = (B + slices - 1) / slices;
+  hipLaunchKernelGGL(ppo_tanh_bwd_colsum_kernel, dim3(cb, slices), dim3(256), 0, (hipStream_t)stream, dY, Y, dZ, B, O, rpb, db);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Minibatch gather of the rollout buffer: out_x[r] = x[idx[r]] for the five per-sample arrays of PPO.train
 // (observations [n x D], actions [n x A], advantages, returns, old log-probs) in one launch instead of five
 // index_select kernels.  idx is int64 (torch.randperm).

@@ -101,6 +101,74 @@ class _HipLinearBf16Fn(torch.autograd.Function):
         return gx, None, None, None
 
 
+class _HipLinearTanhFn(torch.autograd.Function):
+    """tanh(x W^T + b) of a wide trunk ([1024,512]) with the activation fused around the GEMM (csrc/dm_ppo.hip):
+    first layer (x = observations, <= 128 wide, no input gradient): `dm_linear_tanh` forward, `dm_tanh_linear_wgrad` backward —
+    no activation pass, no dZ; deeper layers: library GEMM + in-place tanh forward, `dm_tanh_bwd_colsum` (tanh' and the bias
+    gradient in one pass) + library GEMMs backward.  Gradients go straight into the optimizer's flat arena."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, mod):
+        import ctypes as C
+        from . import _lib
+        first = x.shape[1] <= 128 and not x.requires_grad
+        if first:
+            y = torch.empty(x.shape[0], w.shape[0], device=x.device, dtype=torch.float32)
+            rc = _lib.load_library().dm_linear_tanh(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()),
+                                                    C.c_void_p(y.data_ptr()), x.shape[0], w.shape[0], x.shape[1],
+                                                    C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+            if rc != 0:
+                raise RuntimeError("dm_linear_tanh failed (%d)" % rc)
+        else:
+            y = torch.addmm(b, x, w.t()).tanh_()
+        ctx.save_for_backward(x, w, y)
+        ctx.mod, ctx.first = mod, first
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        import ctypes as C
+        from . import _lib
+        x, w, y = ctx.saved_tensors
+        gw, gb = ctx.mod._grad_arena
+        gy = gy.contiguous()
+        p = lambda t: C.c_void_p(t.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        L = _lib.load_library()
+        if ctx.first:
+            rc = L.dm_tanh_linear_wgrad(p(gy), p(y), p(x), p(gw), p(gb), x.shape[0], w.shape[0], w.shape[1], stream)
+            if rc != 0:
+                raise RuntimeError("dm_tanh_linear_wgrad failed (%d)" % rc)
+            return None, None, None, None
+        gz = torch.empty_like(gy)
+        rc = L.dm_tanh_bwd_colsum(p(gy), p(y), p(gz), p(gb), x.shape[0], w.shape[0], stream)
+        if rc != 0:
+            raise RuntimeError("dm_tanh_bwd_colsum failed (%d)" % rc)
+        torch.mm(gz.t(), x, out=gw)
+        gx = gz @ w if ctx.needs_input_grad[0] else None
+        return gx, None, None, None
+
+
+def _fused_tanh_trunk(seq, x):
+    """Run an nn.Sequential of (HipLinear, Tanh) pairs through `_HipLinearTanhFn` where it applies (wide fp32 layers of a CUDA
+    minibatch whose gradients live in the flat arena); anything else through the modules themselves."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        nxt = mods[i + 1] if i + 1 < len(mods) else None
+        if (isinstance(m, HipLinear) and isinstance(nxt, nn.Tanh) and m._bf16 is None and x.is_cuda and x.dim() == 2
+                and x.dtype == torch.float32 and x.is_contiguous() and x.shape[0] >= 1024 and x.shape[0] % 64 == 0
+                and torch.is_grad_enabled() and getattr(m, "_grad_arena", None) is not None and m.weight.shape[0] > 256
+                and ((x.shape[1] <= 128 and not x.requires_grad) or min(m.weight.shape) > 128)):
+            x = _HipLinearTanhFn.apply(x, m.weight, m.bias, m)
+            i += 2
+        else:
+            x = m(x)
+            i += 1
+    return x
+
+
 class HipLinear(nn.Linear):
     """nn.Linear whose weight / bias gradients bypass autograd's generic kernels when the batch is a large CUDA minibatch:
     layers up to 256 x 256 and skinny layers (one side <= 128) on `dm_linear_wgrad` (the library's K = 4096 GEMMs into small
@@ -909,12 +977,12 @@ class PPO:
                 self._vf_stream = torch.cuda.Stream(device=obs.device)
             self._vf_stream.wait_stream(cur)
             with torch.cuda.stream(self._vf_stream):
-                value = self.policy.value_net(self.policy.vf(obs)).squeeze(-1)
-            mean = self.policy.action_net(self.policy.pi(obs))
+                value = self.policy.value_net(_fused_tanh_trunk(self.policy.vf, obs)).squeeze(-1)
+            mean = self.policy.action_net(_fused_tanh_trunk(self.policy.pi, obs))
             cur.wait_stream(self._vf_stream)
         else:
-            mean = self.policy.action_net(self.policy.pi(obs))
-            value = self.policy.value_net(self.policy.vf(obs)).squeeze(-1)
+            mean = self.policy.action_net(_fused_tanh_trunk(self.policy.pi, obs))
+            value = self.policy.value_net(_fused_tanh_trunk(self.policy.vf, obs)).squeeze(-1)
         if mean.dtype != torch.float32:               # bf16 learner: the loss kernel reads fp32 heads
             mean, value = mean.float(), value.float()
         return mean, value

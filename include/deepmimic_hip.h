@@ -214,6 +214,17 @@ int dm_adam_clip_update(float *p, const float *g, float *m, float *v, int n, flo
  * nn.Linear layers of PPO.train [EXT] whose weight gradient stays on the library GEMM (layers beyond 256 units). */
 int dm_colsum(const float *Y, int B, int O, float *out, void *stream);
 
+/* Wide trunks ([1024,512], BASELINE configs 3-5) in SB3's PPO.train [EXT] (policy_kwargs of src/sb3_ppo.py:265), three fusions
+ * around the library GEMMs (csrc/dm_ppo.hip):
+ * dm_linear_tanh: Y[B x O] = tanh(X W^T + b) for the FIRST layer (X = observations [B x I], I <= 128): nn.Linear + nn.Tanh in one
+ *   launch, Y written once;
+ * dm_tanh_linear_wgrad: that layer's backward, dW[O x I] += (dY * (1 - Y^2))^T X, db[O] += its column sums (zero on
+ *   entry) — no dZ intermediate, no input gradient (observations need none);
+ * dm_tanh_bwd_colsum: dZ = dY * (1 - Y^2) (dZ may alias dY) and db[O] += column sums of dZ for the deeper layers. */
+int dm_linear_tanh(const float *X, const float *W, const float *bias, float *Y, int B, int O, int I, void *stream);
+int dm_tanh_linear_wgrad(const float *dY, const float *Y, const float *X, float *dW, float *db, int B, int O, int I, void *stream);
+int dm_tanh_bwd_colsum(const float *dY, const float *Y, float *dZ, float *db, int B, int O, void *stream);
+
 /* Rollout side of SB3's collect_rollouts [EXT] (driven by src/sb3_ppo.py:307-313), two launches per env step:
  * dm_policy_sample: act = mean + exp(log_std) * N(0,1) (counter-based generator: seed, env, counter[0], action index),
  *   logp of the diagonal Gaussian, act_env = clamp(act, lo, hi) (what DPEnv.step receives);

@@ -390,6 +390,43 @@ def test_hip_linear_wgrad_matches_torch():
             assert torch.allclose(gx, ref_x, rtol=1e-4, atol=1e-4)
 
 
+def test_fused_tanh_layer_kernels_match_torch():
+    """dm_linear_tanh / dm_tanh_linear_wgrad / dm_tanh_bwd_colsum (the activation fused around the GEMMs of the wide trunks)
+    against torch, for every observation width of the reference's envs and ragged sizes."""
+    import ctypes as C
+    import torch
+    from deepmimic_mujoco_amd import _lib
+    L = _lib.load_library()
+    dev = torch.device("cuda", 0)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for B, O, I in ((4096, 1024, 67), (2048, 1024, 72), (1024, 512, 85), (4096, 1024, 98), (1024, 300, 128), (1000, 77, 5)):
+        x = torch.randn(B, I, generator=g).to(dev)
+        w = (torch.randn(O, I, generator=g) / I ** 0.5).to(dev)
+        b = torch.randn(O, generator=g).to(dev)
+        y = torch.full((B, O), 7.0, device=dev)
+        assert L.dm_linear_tanh(p(x), p(w), p(b), p(y), B, O, I, st) == 0
+        ref = torch.tanh(torch.addmm(b, x, w.t()).double()).float()
+        assert float((y - ref).abs().max()) < 2e-5, (B, O, I, float((y - ref).abs().max()))
+        gy = torch.randn(B, O, generator=g).to(dev)
+        gz_ref = gy.double() * (1 - ref.double() ** 2)
+        gz, db = torch.empty_like(gy), torch.zeros(O, device=dev)
+        assert L.dm_tanh_bwd_colsum(p(gy), p(ref), p(gz), p(db), B, O, st) == 0
+        assert float((gz - gz_ref.float()).abs().max()) < 1e-6
+        assert float((db - gz_ref.sum(0).float()).abs().max()) < 3e-4 * float(gz_ref.sum(0).abs().max() + 1)
+        gy2 = gy.clone()                                              # in place
+        db2 = torch.zeros(O, device=dev)
+        assert L.dm_tanh_bwd_colsum(p(gy2), p(ref), p(gy2), p(db2), B, O, st) == 0 and torch.equal(gy2, gz)
+        dw, db3 = torch.zeros(O, I, device=dev), torch.zeros(O, device=dev)
+        assert L.dm_tanh_linear_wgrad(p(gy), p(ref), p(x), p(dw), p(db3), B, O, I, st) == 0
+        dw_ref = (gz_ref.t() @ x.double()).float()
+        assert float((dw - dw_ref).abs().max()) < 3e-4 * float(dw_ref.abs().max()), (B, O, I)
+        assert float((db3 - gz_ref.sum(0).float()).abs().max()) < 3e-4 * float(gz_ref.sum(0).abs().max() + 1)
+    assert L.dm_linear_tanh(p(x), p(w), p(b), p(y), 8, 8, 129, st) == -22
+    assert L.dm_tanh_linear_wgrad(p(gy), p(ref), p(x), p(dw), p(db3), 8, 8, 129, st) == -22
+
+
 def test_big_net_learner_step_matches_plain_autograd():
     """[1024,512]: the arena path (library GEMM written into the flat gradient buffer + dm_colsum, fused loss, flat Adam,
     value trunk on a second stream) gives the same parameters after three optimizer steps as plain autograd + torch Adam."""
