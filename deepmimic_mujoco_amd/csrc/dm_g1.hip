@@ -530,70 +530,84 @@ __device__ __forceinline__ double wmax_f64(double v) {
   v = fmax(v, dpp_f64<0x140>(v));   // row_mirror
   return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
-struct MeshPick { double best; int bo, bk; };
-__device__ __forceinline__ void pick_update(MeshPick &p, double sv, int so, int sk) {
-  if (sv > p.best || (sv == p.best && so < p.bo)) { p.best = sv; p.bo = so; p.bk = sk; }
-}
-// every lane scans vertex `lane` of up to four clusters (-1: none): independent loads, no cross-lane step
-__device__ __forceinline__ void scan4(const Geo &g, const double *dl, const int (&c)[4], MeshPick &p, const int lane) {
-  double x[4], y[4], z[4];
-  int o[4];
+constexpr int NCH = 2;            // cluster chunks of 64 per hull: hulls of up to 128 clusters (checked at create)
+struct MeshPick { double best, x, y, z; int bo, bk; };
+// every lane scans vertex `lane` of up to four clusters of hull A and four of hull B (-1: none): sixteen independent loads in
+// one round trip, no cross-lane step; the pick keeps the vertex itself, so no fetch follows the reduction
+struct Scan4 { double x[4], y[4], z[4]; int o[4]; };
+__device__ __forceinline__ void scan4_load(const Geo &g, const int (&c)[4], Scan4 &v, const int lane) {
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int k = 64 * (c[q] < 0 ? 0 : c[q]) + lane;
     const bool ok = c[q] >= 0;
-    x[q] = ok ? g.vert[3 * k] : 0.0; y[q] = ok ? g.vert[3 * k + 1] : 0.0; z[q] = ok ? g.vert[3 * k + 2] : 0.0;
-    o[q] = ok ? g.oidx[k] : 0x7fffffff;
+    v.x[q] = ok ? g.vert[3 * k] : 0.0; v.y[q] = ok ? g.vert[3 * k + 1] : 0.0; v.z[q] = ok ? g.vert[3 * k + 2] : 0.0;
+    v.o[q] = ok ? g.oidx[k] : 0x7fffffff;
   }
+}
+__device__ __forceinline__ void scan4_pick(const double *dl, const int (&c)[4], const Scan4 &v, MeshPick &p, const int lane) {
 #pragma unroll
   for (int q = 0; q < 4; q++)
-    if (o[q] != 0x7fffffff) pick_update(p, x[q] * dl[0] + y[q] * dl[1] + z[q] * dl[2], o[q], 64 * c[q] + lane);
+    if (v.o[q] != 0x7fffffff) {
+      const double sv = v.x[q] * dl[0] + v.y[q] * dl[1] + v.z[q] * dl[2];
+      if (sv > p.best || (sv == p.best && v.o[q] < p.bo)) { p.best = sv; p.bo = v.o[q]; p.bk = 64 * c[q] + lane;
+        p.x = v.x[q]; p.y = v.y[q]; p.z = v.z[q];
+      }
+    }
 }
 // the lanes' picks -> the wave's pick: the maximum value, and among equal values the lowest original index (one lane in all
-// but degenerate cases: a ballot and a v_readlane; ties walk the tied lanes)
+// but degenerate cases: a ballot and v_readlanes; ties walk the tied lanes)
 __device__ __forceinline__ void wave_pick(MeshPick &p) {
   const double vmax = wmax_f64(p.best);
   unsigned long long eq = __ballot(p.best == vmax);
   int l = __ffsll((long long)eq) - 1;
-  int bo = __builtin_amdgcn_readlane(p.bo, l), bk = __builtin_amdgcn_readlane(p.bk, l);
+  int bo = __builtin_amdgcn_readlane(p.bo, l);
   eq &= eq - 1;
   while (eq) {
-    l = __ffsll((long long)eq) - 1;
+    const int l2 = __ffsll((long long)eq) - 1;
     eq &= eq - 1;
-    const int o2 = __builtin_amdgcn_readlane(p.bo, l), k2 = __builtin_amdgcn_readlane(p.bk, l);
-    if (o2 < bo) { bo = o2; bk = k2; }
+    const int o2 = __builtin_amdgcn_readlane(p.bo, l2);
+    if (o2 < bo) { bo = o2; l = l2; }
   }
-  p.best = vmax; p.bo = bo; p.bk = bk;
+  p.best = vmax; p.bo = bo; p.bk = __builtin_amdgcn_readlane(p.bk, l);
+  p.x = readlane_f64(p.x, l); p.y = readlane_f64(p.y, l); p.z = readlane_f64(p.z, l);
 }
-__device__ __forceinline__ void scan_candidates(const Geo &g, const double *dl, const double (&ub)[3], const double bound, const int skip,
-                                                MeshPick &p, const int lane) {
+// the next (up to) four candidate clusters of a hull: bit sets of clusters lane + 64 m, consumed in ascending order
+__device__ __forceinline__ bool next4(unsigned long long (&todo)[NCH], int (&c)[4]) {
+  bool any = false;
 #pragma unroll
-  for (int m = 0; m < 3; m++) {
-    unsigned long long todo = __ballot(ub[m] >= bound && (lane + 64 * m) != skip);
-    while (todo) {
-      int c[4];
+  for (int q = 0; q < 4; q++) {
+    c[q] = -1;
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        c[q] = todo ? (__ffsll((long long)todo) - 1 + 64 * m) : -1;
-        todo &= todo - 1;
-      }
-      scan4(g, dl, c, p, lane);
-    }
+    for (int m = 0; m < NCH; m++)
+      if (c[q] < 0 && todo[m]) { c[q] = __ffsll((long long)todo[m]) - 1 + 64 * m; todo[m] &= todo[m] - 1; any = true; }
+  }
+  return any;
+}
+// cluster spheres of one hull for clusters lane + 64 m (loads only), then bounds ub[m] and the cluster with the largest centre . d
+struct ClusLoad { double c[NCH][4]; };
+__device__ __forceinline__ void cluster_load(const Geo &g, const bool on, ClusLoad &L, const int lane) {
+#pragma unroll
+  for (int m = 0; m < NCH; m++) {
+    const int c = lane + 64 * m;
+    const bool ok = on && c < g.nclus;
+    const double *cl = g.clus + 4 * (ok ? c : 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) L.c[m][i] = ok ? cl[i] : 0.0;
   }
 }
-// cluster bounds of one hull: ub[m] for clusters lane + 64 m, the cluster with the largest centre . d
-__device__ __forceinline__ void cluster_bounds(const Geo &g, const double *dl, const bool on, double (&ub)[3], int &top, const int lane) {
+__device__ __forceinline__ void cluster_bounds(const Geo &g, const double *dl, const bool on, const ClusLoad &L, double (&ub)[NCH], int &top,
+                                               const int lane) {
+  if (!on) { for (int m = 0; m < NCH; m++) ub[m] = -1e300; top = 0; return; }   // (wave-uniform) not a mesh: nothing to reduce
   const double dn = sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
   double best = -1e300;
   top = 0x7fffffff;
 #pragma unroll
-  for (int m = 0; m < 3; m++) {
+  for (int m = 0; m < NCH; m++) {
     const int c = lane + 64 * m;
     ub[m] = -1e300;
     if (on && c < g.nclus) {
-      const double *cl = g.clus + 4 * c;
-      const double dc = cl[0] * dl[0] + cl[1] * dl[1] + cl[2] * dl[2];
-      ub[m] = dc + cl[3] * dn;
+      const double dc = L.c[m][0] * dl[0] + L.c[m][1] * dl[1] + L.c[m][2] * dl[2];
+      ub[m] = dc + L.c[m][3] * dn;
       if (dc > best) { best = dc; top = c; }
     }
   }
@@ -611,32 +625,57 @@ __device__ __forceinline__ void cluster_bounds(const Geo &g, const double *dl, c
 }
 // Support vertices of up to two hulls at once, in local directions dlA / dlB.  The vertices are stored in compact clusters
 // (k-d leaves, padded to 64 slots) with a bounding sphere each.  Three dependent memory round trips for BOTH hulls together
-// (the narrowphase is one wave's latency chain: round trips are what it costs): (1) every cluster's centre . d and bound
-// centre . d + radius |d|; (2) the cluster with the largest centre . d is scanned: a true support value to prune with;
-// (3) the clusters whose bound still reaches it are scanned together, every lane keeping its own best, one wave reduction
-// at the end.  Exact; equal support values resolve to the lowest ORIGINAL vertex index, like a serial first-maximum scan.
-__device__ __forceinline__ void mesh_support_pair(const Geo &A, const double *dlA, const bool meshA, int &iA, const Geo &B,
-                                                  const double *dlB, const bool meshB, int &iB, const int lane) {
-  double ubA[3], ubB[3];
+// (the narrowphase is one wave's latency chain: round trips are what it costs; every load of a round is requested before the
+// first reduction of that round): (1) every cluster's centre . d and bound centre . d + radius |d|; (2) the cluster with
+// the largest centre . d is scanned: a true support value to prune with; (3) the clusters whose bound still reaches it are
+// scanned, four per trip, every lane keeping its own best and the vertex it belongs to, one wave reduction at the
+// end.  Exact; equal support values resolve to the lowest ORIGINAL vertex index, like a serial first-maximum scan.
+__device__ __forceinline__ void mesh_support_pair(const Geo &A, const double *dlA, const bool meshA, MeshPick &pa, const Geo &B,
+                                                  const double *dlB, const bool meshB, MeshPick &pb, const int lane) {
+  double ubA[NCH], ubB[NCH];
   int topA, topB;
-  cluster_bounds(A, dlA, meshA, ubA, topA, lane);
-  cluster_bounds(B, dlB, meshB, ubB, topB, lane);
-  MeshPick pa = {-1e300, 0x7fffffff, 0}, pb = {-1e300, 0x7fffffff, 0};
+  { ClusLoad LA, LB;
+    cluster_load(A, meshA, LA, lane);
+    cluster_load(B, meshB, LB, lane);
+    cluster_bounds(A, dlA, meshA, LA, ubA, topA, lane);
+    cluster_bounds(B, dlB, meshB, LB, ubB, topB, lane); }
+  pa = {-1e300, 0.0, 0.0, 0.0, 0x7fffffff, 0};
+  pb = pa;
   { const int ca[4] = {meshA ? topA : -1, -1, -1, -1}, cb[4] = {meshB ? topB : -1, -1, -1, -1};
-    scan4(A, dlA, ca, pa, lane);
-    scan4(B, dlB, cb, pb, lane); }
-  double ba = pa.best, bb = pb.best;
-  ba = wmax_f64(ba); bb = wmax_f64(bb);
-  if (meshA) scan_candidates(A, dlA, ubA, ba, topA, pa, lane);
-  if (meshB) scan_candidates(B, dlB, ubB, bb, topB, pb, lane);
-  wave_pick(pa);
-  wave_pick(pb);
-  iA = pa.bk; iB = pb.bk;
+    Scan4 va, vb;
+    scan4_load(A, ca, va, lane);
+    scan4_load(B, cb, vb, lane);
+    scan4_pick(dlA, ca, va, pa, lane);
+    scan4_pick(dlB, cb, vb, pb, lane); }
+  const double ba = meshA ? wmax_f64(pa.best) : 0.0, bb = meshB ? wmax_f64(pb.best) : 0.0;
+  unsigned long long todoA[NCH], todoB[NCH];
+#pragma unroll
+  for (int m = 0; m < NCH; m++) {
+    todoA[m] = meshA ? __ballot(ubA[m] >= ba && (lane + 64 * m) != topA) : 0ull;
+    todoB[m] = meshB ? __ballot(ubB[m] >= bb && (lane + 64 * m) != topB) : 0ull;
+  }
+  // (both hulls' candidates in ONE loop — eight clusters per trip — measured slower: 34 more live doubles spill)
+  for (;;) {
+    int ca[4];
+    if (!next4(todoA, ca)) break;
+    Scan4 va;
+    scan4_load(A, ca, va, lane);
+    scan4_pick(dlA, ca, va, pa, lane);
+  }
+  for (;;) {
+    int cb[4];
+    if (!next4(todoB, cb)) break;
+    Scan4 vb;
+    scan4_load(B, cb, vb, lane);
+    scan4_pick(dlB, cb, vb, pb, lane);
+  }
+  if (meshA) wave_pick(pa);
+  if (meshB) wave_pick(pb);
 }
 __device__ __forceinline__ int mesh_support_index(const Geo &g, const double *dl, const int lane) {
-  int i, j;
+  MeshPick i, j;
   mesh_support_pair(g, dl, true, i, g, dl, false, j, lane);
-  return i;
+  return i.bk;
 }
 
 // [EXT] mjccd_support for the analytic shapes (local direction dl -> local point p)
@@ -675,16 +714,16 @@ __device__ __forceinline__ void mpr_support(const Geo &a, const Geo &b, const do
   support_local(a, dla, pa);
   support_local(b, dlb, pb);
   if (ma || mb) {
-    int ia, ib;
+    MeshPick ka, kb;
 #ifdef G1_PROFILE
     const long long t0_ = clock64();
 #endif
-    mesh_support_pair(a, dla, ma, ia, b, dlb, mb, ib, lane);
+    mesh_support_pair(a, dla, ma, ka, b, dlb, mb, kb, lane);
 #ifdef G1_PROFILE
     if (lane == 0) { S.prof[13] += (unsigned)(clock64() - t0_); S.prof[12] += 1; }
 #endif
-    if (ma) { pa[0] = a.vert[3 * ia]; pa[1] = a.vert[3 * ia + 1]; pa[2] = a.vert[3 * ia + 2]; }
-    if (mb) { pb[0] = b.vert[3 * ib]; pb[1] = b.vert[3 * ib + 1]; pb[2] = b.vert[3 * ib + 2]; }
+    if (ma) { pa[0] = ka.x; pa[1] = ka.y; pa[2] = ka.z; }
+    if (mb) { pb[0] = kb.x; pb[1] = kb.y; pb[2] = kb.z; }
   }
   drot(s.v1, a.mat, pa);
   drot(s.v2, b.mat, pb);
@@ -2293,7 +2332,7 @@ static void g1_kd_split(const DmModelG1 &m, int a0, std::vector<int> &idx, int l
   g1_kd_split(m, a0, idx, lo, mid, leaves);
   g1_kd_split(m, a0, idx, mid, hi, leaves);
 }
-static void g1_build_meshes(const DmModelG1 &m, g1::Dev &T, std::vector<double> &verts, std::vector<int32_t> &oidx,
+static int g1_build_meshes(const DmModelG1 &m, g1::Dev &T, std::vector<double> &verts, std::vector<int32_t> &oidx,
                             std::vector<double> &clus) {
   int vadr = 0, cadr = 0;
   for (int me = 0; me < DM_NMESH; me++) {
@@ -2320,9 +2359,11 @@ static void g1_build_meshes(const DmModelG1 &m, g1::Dev &T, std::vector<double> 
       clus.push_back(cc[0]); clus.push_back(cc[1]); clus.push_back(cc[2]); clus.push_back(rad * (1 + 1e-9) + 1e-12);
     }
     const int nclus = (int)leaves.size();
+    if (nclus > 64 * g1::NCH) return -1;
     T.m_vnum[me] = nclus * 64; T.m_cnum[me] = nclus;
     vadr += nclus * 64; cadr += nclus;
   }
+  return 0;
 }
 
 static int g1_check_model(DmG1Engine *e, const DmModelG1 &m) {
@@ -2377,9 +2418,9 @@ extern "C" int dmg1_create(const void *model, size_t model_bytes, const DmG1Conf
   g1_build_tables(m, *T);
   std::vector<double> verts, clus;
   std::vector<int32_t> oidx;
-  g1_build_meshes(m, *T, verts, oidx, clus);
-  for (int me = 0; me < DM_NMESH; me++)
-    if (T->m_cnum[me] > 192) { delete T; delete e; fprintf(stderr, "dmg1_create: a hull has more than 192 vertex clusters\n"); return DM_EINVAL; }
+  if (g1_build_meshes(m, *T, verts, oidx, clus) != 0) {
+    delete T; delete e; fprintf(stderr, "dmg1_create: a hull has more than %d vertex clusters\n", 64 * g1::NCH); return DM_EINVAL;
+  }
   bool ok = hipMalloc(&e->dT, sizeof(g1::Dev)) == hipSuccess;
   if (ok) hipMemcpy(e->dT, T, sizeof(g1::Dev), hipMemcpyHostToDevice);
   delete T;

@@ -31,3 +31,8 @@ for lo, hi in ((0, 48), (48, 64), (64, 80), (80, 128), (128, 256)):
     m = (nefc >= lo) & (nefc < hi)
     if m.any():
         print("last-stage rows %3d..%3d: %5d envs, mean ticks %.2fM, PGS %.2fM, MPR %.2fM" % (lo, hi, int(m.sum()), tt[m].mean() / 1e6, d[m, 12].mean() / 1e6, d[m, 6].mean() / 1e6))
+top = tt >= tt.quantile(0.99)
+print("heaviest 1 %% of envs (%d): mean ticks %.2fM, rows %.0f, contacts %.0f" % (int(top.sum()), tt[top].mean() / 1e6, float(nefc[top].mean()), float(full[top, 203].mean())))
+for i, nm in enumerate(names):
+    if i != 13 and d[top, i].mean() > 0:
+        print("   %-22s %9.0f  %5.1f %%" % (nm, d[top, i].mean(), 100 * d[top, i].mean() / tt[top].mean()))
