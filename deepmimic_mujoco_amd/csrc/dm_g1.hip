@@ -1668,22 +1668,29 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
     float arow[64];
 #pragma unroll
     for (int i = 0; i < 64; i++) arow[i] = (i < nefc && lane < nefc) ? AR[i * MAXROW + lane] : 0.f;
+    // Every lane keeps the update its own row WOULD take (two instructions: fma + v_med3 against the row's bounds), so a sweep
+    // step broadcasts one value — the owner's force change — instead of five, and its dependent chain is fma, med3, sub,
+    // v_readlane, fma.  The cost decrease of the sweep is summed over the lanes afterwards (each row changes once per sweep:
+    // the change is f_after - f_before, the residual it saw is captured when its step passes).
     float res0 = res[0], f0 = fr[0];
     const float ainv0 = dinv[0], aii0 = diag[0], fl0 = lm[0];
+    const float lo0 = fl0 >= 0.f ? -fl0 : 0.f, hi0 = fl0 >= 0.f ? fl0 : __builtin_inff();
     while (iter < max_iter) {
-      float improvement = 0;
+      const float fstart = f0;
+      float seen = 0.f;
       StaticFor<0, 64>::run([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         if (i >= nefc) return false;
-        const float rs_ = bcast(res0, i), old_ = bcast(f0, i), ai_ = bcast(ainv0, i), fl_ = bcast(fl0, i), aii_ = bcast(aii0, i);
-        float f_ = fmaf(-rs_, ai_, old_);
-        f_ = (fl_ >= 0.f) ? fminf(fmaxf(f_, -fl_), fl_) : fmaxf(f_, 0.f);
-        const float dl_ = f_ - old_;
-        improvement -= dl_ * fmaf(0.5f * dl_, aii_, rs_);
-        f0 = (lane == i) ? f_ : f0;
+        const float cand = __builtin_amdgcn_fmed3f(fmaf(-res0, ainv0, f0), lo0, hi0);
+        const float dl_ = bcast(cand - f0, i);
+        const bool me = lane == i;
+        seen = me ? res0 : seen;
+        f0 = me ? cand : f0;
         res0 = fmaf(arow[i], dl_, res0);
         return true;
       });
+      const float dl0 = f0 - fstart;
+      const float improvement = wsum(lane < nefc ? -dl0 * fmaf(0.5f * dl0, aii0, seen) : 0.f);
       iter++;
       if (improvement * T.pgs_scale < T.tolerance) break;
     }
@@ -1697,16 +1704,18 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
     for (int i = 0; i < 64; i++) { ar0[i] = AR[i * MAXROW + lane]; ar1[i] = (lane + 64 < nefc) ? AR[i * MAXROW + lane + 64] : 0.f; }
     float res0 = res[0], res1 = res[1], f0 = fr[0], f1 = fr[1];
     const float ainv0 = dinv[0], aii0 = diag[0], fl0 = lm[0], ainv1 = dinv[1], aii1 = diag[1], fl1 = lm[1];
+    const float lo0 = fl0 >= 0.f ? -fl0 : 0.f, hi0 = fl0 >= 0.f ? fl0 : __builtin_inff();
+    const float lo1 = fl1 >= 0.f ? -fl1 : 0.f, hi1 = fl1 >= 0.f ? fl1 : __builtin_inff();
     while (iter < max_iter) {
-      float improvement = 0;
+      const float fs0 = f0, fs1 = f1;
+      float seen0 = 0.f, seen1 = 0.f;
       StaticFor<0, 64>::run([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        const float rs_ = bcast(res0, i), old_ = bcast(f0, i), ai_ = bcast(ainv0, i), fl_ = bcast(fl0, i), aii_ = bcast(aii0, i);
-        float f_ = fmaf(-rs_, ai_, old_);
-        f_ = (fl_ >= 0.f) ? fminf(fmaxf(f_, -fl_), fl_) : fmaxf(f_, 0.f);
-        const float dl_ = f_ - old_;
-        improvement -= dl_ * fmaf(0.5f * dl_, aii_, rs_);
-        f0 = (lane == i) ? f_ : f0;
+        const float cand = __builtin_amdgcn_fmed3f(fmaf(-res0, ainv0, f0), lo0, hi0);
+        const float dl_ = bcast(cand - f0, i);
+        const bool me = lane == i;
+        seen0 = me ? res0 : seen0;
+        f0 = me ? cand : f0;
         res0 = fmaf(ar0[i], dl_, res0);
         res1 = fmaf(ar1[i], dl_, res1);
         return true;
@@ -1723,17 +1732,18 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
         for (int q = 0; q < PF; q++) {
           const int src = i0 + q - 64;
           if (i0 + q < nefc) {
-            const float rs_ = bcast(res1, src), old_ = bcast(f1, src), ai_ = bcast(ainv1, src), fl_ = bcast(fl1, src), aii_ = bcast(aii1, src);
-            float f_ = fmaf(-rs_, ai_, old_);
-            f_ = (fl_ >= 0.f) ? fminf(fmaxf(f_, -fl_), fl_) : fmaxf(f_, 0.f);
-            const float dl_ = f_ - old_;
-            improvement -= dl_ * fmaf(0.5f * dl_, aii_, rs_);
-            f1 = (lane == src) ? f_ : f1;
+            const float cand = __builtin_amdgcn_fmed3f(fmaf(-res1, ainv1, f1), lo1, hi1);
+            const float dl_ = bcast(cand - f1, src);
+            const bool me = lane == src;
+            seen1 = me ? res1 : seen1;
+            f1 = me ? cand : f1;
             res0 = fmaf(a0[q], dl_, res0);
             res1 = fmaf(a1[q], dl_, res1);
           }
         }
       }
+      const float dl0 = f0 - fs0, dl1 = f1 - fs1;
+      const float improvement = wsum(-dl0 * fmaf(0.5f * dl0, aii0, seen0) + (lane + 64 < nefc ? -dl1 * fmaf(0.5f * dl1, aii1, seen1) : 0.f));
       iter++;
       if (improvement * T.pgs_scale < T.tolerance) break;
     }
