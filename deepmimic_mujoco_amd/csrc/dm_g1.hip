@@ -1668,29 +1668,31 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
     float arow[64];
 #pragma unroll
     for (int i = 0; i < 64; i++) arow[i] = (i < nefc && lane < nefc) ? AR[i * MAXROW + lane] : 0.f;
-    // Every lane keeps the update its own row WOULD take (two instructions: fma + v_med3 against the row's bounds), so a sweep
-    // step broadcasts one value — the owner's force change — instead of five, and its dependent chain is fma, med3, sub,
-    // v_readlane, fma.  The cost decrease of the sweep is summed over the lanes afterwards (each row changes once per sweep:
-    // the change is f_after - f_before, the residual it saw is captured when its step passes).
-    float res0 = res[0], f0 = fr[0];
-    const float ainv0 = dinv[0], aii0 = diag[0], fl0 = lm[0];
+    // Lane j's force changes only at step j of a sweep, so a sweep carries the residual alone, scaled: g = -r / A_jj with the
+    // lane's row of A pre-multiplied by -1 / A_jj.  The change its row WOULD take is then med3(g, lo - f, hi - f) (unilateral
+    // rows: lo = 0, hi = inf; friction-loss rows: -+ the bound), the two bounds constant within the sweep.  A step is
+    // v_med3, v_readlane, fma (+ the owner recording the g it saw): one broadcast instead of five, a three-instruction
+    // dependent chain.  Forces and the cost decrease (mj_solPGS "improvement") are committed once per sweep.
+    float f0 = fr[0];
+    const float aii0 = diag[0], fl0 = lm[0], nainv0 = -dinv[0];
     const float lo0 = fl0 >= 0.f ? -fl0 : 0.f, hi0 = fl0 >= 0.f ? fl0 : __builtin_inff();
+    float g0 = res[0] * nainv0;
+#pragma unroll
+    for (int i = 0; i < 64; i++) arow[i] *= nainv0;
     while (iter < max_iter) {
-      const float fstart = f0;
-      float seen = 0.f;
+      const float nlo = lo0 - f0, nhi = hi0 - f0;
+      float seen = g0;
       StaticFor<0, 64>::run([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         if (i >= nefc) return false;
-        const float cand = __builtin_amdgcn_fmed3f(fmaf(-res0, ainv0, f0), lo0, hi0);
-        const float dl_ = bcast(cand - f0, i);
-        const bool me = lane == i;
-        seen = me ? res0 : seen;
-        f0 = me ? cand : f0;
-        res0 = fmaf(arow[i], dl_, res0);
+        const float dl_ = bcast(__builtin_amdgcn_fmed3f(g0, nlo, nhi), i);
+        seen = (lane == i) ? g0 : seen;
+        g0 = fmaf(arow[i], dl_, g0);
         return true;
       });
-      const float dl0 = f0 - fstart;
-      const float improvement = wsum(lane < nefc ? -dl0 * fmaf(0.5f * dl0, aii0, seen) : 0.f);
+      const float dl0 = __builtin_amdgcn_fmed3f(seen, nlo, nhi);
+      const float improvement = -wsum(lane < nefc ? dl0 * aii0 * (0.5f * dl0 - seen) : 0.f);   // dl (dl A_ii / 2 + r), r = -g A_ii
+      f0 = (dl0 == nlo) ? lo0 : ((dl0 == nhi) ? hi0 : f0 + dl0);                                 // exactly on the bound when clamped
       iter++;
       if (improvement * T.pgs_scale < T.tolerance) break;
     }
@@ -1702,22 +1704,23 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
     float ar0[64], ar1[64];
 #pragma unroll
     for (int i = 0; i < 64; i++) { ar0[i] = AR[i * MAXROW + lane]; ar1[i] = (lane + 64 < nefc) ? AR[i * MAXROW + lane + 64] : 0.f; }
-    float res0 = res[0], res1 = res[1], f0 = fr[0], f1 = fr[1];
-    const float ainv0 = dinv[0], aii0 = diag[0], fl0 = lm[0], ainv1 = dinv[1], aii1 = diag[1], fl1 = lm[1];
+    float f0 = fr[0], f1 = fr[1];
+    const float aii0 = diag[0], fl0 = lm[0], aii1 = diag[1], fl1 = lm[1], nainv0 = -dinv[0], nainv1 = -dinv[1];
     const float lo0 = fl0 >= 0.f ? -fl0 : 0.f, hi0 = fl0 >= 0.f ? fl0 : __builtin_inff();
     const float lo1 = fl1 >= 0.f ? -fl1 : 0.f, hi1 = fl1 >= 0.f ? fl1 : __builtin_inff();
+    float g0 = res[0] * nainv0, g1 = res[1] * nainv1;
+#pragma unroll
+    for (int i = 0; i < 64; i++) { ar0[i] *= nainv0; ar1[i] *= nainv1; }
+    const bool has1 = lane + 64 < nefc;
     while (iter < max_iter) {
-      const float fs0 = f0, fs1 = f1;
-      float seen0 = 0.f, seen1 = 0.f;
+      const float nlo0 = lo0 - f0, nhi0 = hi0 - f0, nlo1 = lo1 - f1, nhi1 = hi1 - f1;
+      float seen0 = g0, seen1 = g1;
       StaticFor<0, 64>::run([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        const float cand = __builtin_amdgcn_fmed3f(fmaf(-res0, ainv0, f0), lo0, hi0);
-        const float dl_ = bcast(cand - f0, i);
-        const bool me = lane == i;
-        seen0 = me ? res0 : seen0;
-        f0 = me ? cand : f0;
-        res0 = fmaf(ar0[i], dl_, res0);
-        res1 = fmaf(ar1[i], dl_, res1);
+        const float dl_ = bcast(__builtin_amdgcn_fmed3f(g0, nlo0, nhi0), i);
+        seen0 = (lane == i) ? g0 : seen0;
+        g0 = fmaf(ar0[i], dl_, g0);
+        g1 = fmaf(ar1[i], dl_, g1);
         return true;
       });
       for (int i0 = 64; i0 < nefc; i0 += PF) {
@@ -1726,24 +1729,23 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
         for (int q = 0; q < PF; q++) {
           const int i = i0 + q;
           a0[q] = (i < nefc) ? AR[i * MAXROW + lane] : 0.f;
-          a1[q] = (i < nefc && lane + 64 < nefc) ? AR[i * MAXROW + lane + 64] : 0.f;
+          a1[q] = (i < nefc && has1) ? AR[i * MAXROW + lane + 64] : 0.f;
         }
 #pragma unroll
         for (int q = 0; q < PF; q++) {
           const int src = i0 + q - 64;
           if (i0 + q < nefc) {
-            const float cand = __builtin_amdgcn_fmed3f(fmaf(-res1, ainv1, f1), lo1, hi1);
-            const float dl_ = bcast(cand - f1, src);
-            const bool me = lane == src;
-            seen1 = me ? res1 : seen1;
-            f1 = me ? cand : f1;
-            res0 = fmaf(a0[q], dl_, res0);
-            res1 = fmaf(a1[q], dl_, res1);
+            const float dl_ = bcast(__builtin_amdgcn_fmed3f(g1, nlo1, nhi1), src);
+            seen1 = (lane == src) ? g1 : seen1;
+            g0 = fmaf(a0[q] * nainv0, dl_, g0);
+            g1 = fmaf(a1[q] * nainv1, dl_, g1);
           }
         }
       }
-      const float dl0 = f0 - fs0, dl1 = f1 - fs1;
-      const float improvement = wsum(-dl0 * fmaf(0.5f * dl0, aii0, seen0) + (lane + 64 < nefc ? -dl1 * fmaf(0.5f * dl1, aii1, seen1) : 0.f));
+      const float dl0 = __builtin_amdgcn_fmed3f(seen0, nlo0, nhi0), dl1 = has1 ? __builtin_amdgcn_fmed3f(seen1, nlo1, nhi1) : 0.f;
+      const float improvement = -wsum(dl0 * aii0 * (0.5f * dl0 - seen0) + (has1 ? dl1 * aii1 * (0.5f * dl1 - seen1) : 0.f));
+      f0 = (dl0 == nlo0) ? lo0 : ((dl0 == nhi0) ? hi0 : f0 + dl0);
+      if (has1) f1 = (dl1 == nlo1) ? lo1 : ((dl1 == nhi1) ? hi1 : f1 + dl1);
       iter++;
       if (improvement * T.pgs_scale < T.tolerance) break;
     }
