@@ -1619,7 +1619,17 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
     const int r = lane + 64 * m;
     if (m < nr && r < nefc) {
       float s = 0;
-      for (int c = 0; c < nefc; c++) s += AR[c * MAXROW + r] * e_f[c];
+      for (int c0 = 0; c0 < nefc; c0 += 8) {             // eight column loads in flight (a plain loop waits for each)
+        float a[8], fc[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const bool ok = c0 + q < nefc;
+          a[q] = ok ? AR[(c0 + q) * MAXROW + r] : 0.f;
+          fc[q] = ok ? e_f[c0 + q] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) s = fmaf(a[q], fc[q], s);
+      }
       fr[m] = e_f[r];
       cost += fr[m] * (0.5f * s + e_b[r]);
       res[m] = e_b[r] + s;
@@ -1792,12 +1802,23 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
 #pragma unroll
   for (int m = 0; m < 4; m++) { const int r = lane + 64 * m; if (m < nr && r < nefc) e_f[r] = fr[m]; }
   SYNC();
-  // qfrc_constraint = J^T f
-  for (int k = 0; k < NV; k++) {
+  // qfrc_constraint = J^T f: lane k owns dof k and walks its row of J^T (eight loads in flight; 43 wave reductions of row
+  // products were 1 700 instructions per evaluation)
+  if (lane < NV) {
+    const float *jk = JT + lane * MAXROW;
     float s = 0;
-    for (int r = lane; r < nefc; r += 64) s += JT[k * MAXROW + r] * e_f[r];
-    s = wsum(s);
-    if (lane == 0) { S.qfc[k] = s; S.tmp[k] = s; }
+    for (int r0 = 0; r0 < nefc; r0 += 8) {
+      float a[8], fc[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const bool ok = r0 + q < nefc;
+        a[q] = ok ? jk[r0 + q] : 0.f;
+        fc[q] = ok ? e_f[r0 + q] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) s = fmaf(a[q], fc[q], s);
+    }
+    S.qfc[lane] = s; S.tmp[lane] = s;
   }
   SYNC();
   solve_m(T, S.tmp, lane);
