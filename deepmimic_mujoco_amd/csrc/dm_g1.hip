@@ -65,6 +65,7 @@ struct Dev {   // read-only model tables (global memory, fp32)
   int32_t m_vadr[32], m_vnum[32], m_cadr[32], m_cnum[32];   // vertex range and cluster range of each mesh
   double m_center[32][3];
   uint8_t tri_a[128], tri_b[128];
+  uint32_t f_tgt[44][64];   // factorisation step k, ancestor pairs p = lane (low half) and lane + 64 (high half): the qLD entry updated
 };
 
 struct Lds {   // per-env working set (one wave): 19.2 KB, eight waves per CU
@@ -333,6 +334,35 @@ __device__ __noinline__ void com_pos(const Dev &T, const int lane) {   // [EXT] 
   SYNC();
 }
 
+// x <- L^-T x for one constraint row held in registers: the dof tree is compile-time (dm_g1_topology.h), so every index is
+// static; the factor entries are wave-uniform LDS reads
+template <int I, int J, int OFF>
+struct RowAnc {
+  static __device__ __forceinline__ void run(float (&x)[NV], const float xi, const float *L) {
+    if constexpr (J >= 0) {
+      x[J] = fmaf(-L[g1topo::MADR[I] + OFF], xi, x[J]);
+      RowAnc<I, (J >= 0 ? g1topo::PARENT[J >= 0 ? J : 0] : -1), OFF + 1>::run(x, xi, L);
+    }
+  }
+};
+template <int I>
+struct RowSolve {
+  static __device__ __forceinline__ void run(float (&x)[NV], const float *L) {
+    RowAnc<I, g1topo::PARENT[I], 1>::run(x, x[I], L);
+    if constexpr (I > 0) RowSolve<I - 1>::run(x, L);
+  }
+};
+// compile-time loop with early exit: f(integral_constant<int, I>) returns false to stop
+template <int I, int N>
+struct StaticFor {
+  template <class F>
+  static __device__ __forceinline__ void run(F &&f) {
+    if constexpr (I < N) {
+      if (f(std::integral_constant<int, I>{})) StaticFor<I + 1, N>::run(f);
+    }
+  }
+};
+
 __device__ __noinline__ void crb_factor(const Dev &T, const int lane) {   // [EXT] mj_crb + mj_factorM
   if (lane < NB) {
     float acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -356,35 +386,47 @@ __device__ __noinline__ void crb_factor(const Dev &T, const int lane) {   // [EX
     for (int q = 0; q < 6; q++) v += cd[q] * buf[q];
     S.qLD[adr] = v;
     const int n = T.d_nanc[i];
-    for (int a = 0; a < n; a++) {
-      const int j = T.d_anc[i][a];
-      float s = 0;
-      for (int q = 0; q < 6; q++) s += S.cdof[j][q] * buf[q];
-      S.qLD[adr + 1 + a] = s;
+    const uint4 aw = *reinterpret_cast<const uint4 *>(T.d_anc[i]);   // the whole ancestor list in one load (a loop over T.d_anc[i][a]
+    const uint32_t awv[4] = {aw.x, aw.y, aw.z, aw.w};                  // waits for one global load per ancestor)
+#pragma unroll
+    for (int a = 0; a < 14; a++) {
+      if (a < n) {
+        const int j = (awv[a >> 2] >> (8 * (a & 3))) & 255;
+        float s = 0;
+        for (int q = 0; q < 6; q++) s += S.cdof[j][q] * buf[q];
+        S.qLD[adr + 1 + a] = s;
+      }
     }
   }
   SYNC();
-  // L^T D L, rows of dof k: [k, parent(k), grand-parent, ...]; step k updates the rows of its ancestors
-  for (int k = NV - 1; k >= 0; k--) {
-    const int n = T.d_nanc[k], kk = T.d_madr[k];
-    if (n > 0) {
-      const float dk = S.qLD[kk];
-      const int np = n * (n + 1) / 2;
-      for (int p = lane; p < np; p += 64) {
-        const int a = T.tri_a[p], c = T.tri_b[p];   // a <= c < n: ancestor i = anc[a], column j = anc[c]
-        const int i = T.d_anc[k][a];
-        S.qLD[T.d_madr[i] + (c - a)] -= S.qLD[kk + 1 + c] * (S.qLD[kk + 1 + a] / dk);
-      }
-      SYNC();
-      if (lane < n) S.qLD[kk + 1 + lane] = S.qLD[kk + 1 + lane] / dk;
-      SYNC();
+  // L^T D L, rows of dof k: [k, parent(k), grand-parent, ...]; step k updates the rows of its ancestors.  The dof tree is
+  // compile-time (dm_g1_topology.h): per step the only run-time table is the target entry of the lane's ancestor pair, and
+  // those (43 steps x up to 105 pairs) are requested in one batch before the first step — a loop over T.d_anc / T.d_madr was
+  // three dependent global loads per step.
+  uint32_t tgt[NV];
+#pragma unroll
+  for (int k = 1; k < NV; k++) tgt[k] = T.f_tgt[k][lane];
+  const int ta0 = T.tri_a[lane], tb0 = T.tri_b[lane], ta1 = T.tri_a[lane + 64], tb1 = T.tri_b[lane + 64];
+  StaticFor<0, NV - 1>::run([&](auto kc) {
+    constexpr int k = NV - 1 - decltype(kc)::value;     // NV-1 .. 1
+    constexpr int n = g1topo::NANC[k], kk = g1topo::MADR[k], np = n * (n + 1) / 2;
+    const float dk = S.qLD[kk];
+    if (lane < np) S.qLD[tgt[k] & 0xffff] -= S.qLD[kk + 1 + tb0] * (S.qLD[kk + 1 + ta0] / dk);
+    if constexpr (np > 64) {
+      if (lane + 64 < np) S.qLD[tgt[k] >> 16] -= S.qLD[kk + 1 + tb1] * (S.qLD[kk + 1 + ta1] / dk);
     }
-  }
+    SYNC();
+    if (lane < n) S.qLD[kk + 1 + lane] = S.qLD[kk + 1 + lane] / dk;
+    SYNC();
+    return true;
+  });
   if (lane < NV) { const float d = S.qLD[T.d_madr[lane]]; S.dinv[lane] = 1.f / d; S.dsq[lane] = 1.f / sqrtf(d); }
   SYNC();
 }
 
-// x <- M^-1 x for an LDS vector
+// x <- M^-1 x for an LDS vector.  (The same solve on 43 registers with static indices, as the constraint rows use, measured
+// SLOWER here — +1 ms per launch: ~1 700 straight-line instructions executed once are 200 instruction-cache misses, the loop
+// below stays resident.)
 __device__ __noinline__ void solve_m(const Dev &T, float *x, const int lane) {
   for (int i = NV - 1; i >= 0; i--) {
     const int n = T.d_nanc[i];
@@ -1490,34 +1532,6 @@ __device__ __noinline__ int make_constraint(const Dev &T, float *JT, float *RW, 
   return nefc;
 }
 
-// x <- L^-T x for one constraint row held in registers: the dof tree is compile-time (dm_g1_topology.h), so every index is
-// static; the factor entries are wave-uniform LDS reads
-template <int I, int J, int OFF>
-struct RowAnc {
-  static __device__ __forceinline__ void run(float (&x)[NV], const float xi, const float *L) {
-    if constexpr (J >= 0) {
-      x[J] = fmaf(-L[g1topo::MADR[I] + OFF], xi, x[J]);
-      RowAnc<I, (J >= 0 ? g1topo::PARENT[J >= 0 ? J : 0] : -1), OFF + 1>::run(x, xi, L);
-    }
-  }
-};
-template <int I>
-struct RowSolve {
-  static __device__ __forceinline__ void run(float (&x)[NV], const float *L) {
-    RowAnc<I, g1topo::PARENT[I], 1>::run(x, x[I], L);
-    if constexpr (I > 0) RowSolve<I - 1>::run(x, L);
-  }
-};
-// compile-time loop with early exit: f(integral_constant<int, I>) returns false to stop
-template <int I, int N>
-struct StaticFor {
-  template <class F>
-  static __device__ __forceinline__ void run(F &&f) {
-    if constexpr (I < N) {
-      if (f(std::integral_constant<int, I>{})) StaticFor<I + 1, N>::run(f);
-    }
-  }
-};
 __device__ __forceinline__ float bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 // A = J M^-1 J^T + R into the per-env scratch.  Up to 128 rows: lane r (and r + 64) keeps its row of B = D^-1/2 L^-T J^T in
@@ -2345,6 +2359,19 @@ static void g1_build_tables(const DmModelG1 &m, g1::Dev &T) {
   int p = 0;
   for (int b = 0; b < 15 && p < 128; b++)   // pairs (a <= c), c-major: index p -> (a, c)
     for (int a = 0; a <= b && p < 128; a++) { T.tri_a[p] = (uint8_t)a; T.tri_b[p] = (uint8_t)b; p++; }
+  for (int k = 0; k < NV; k++) {
+    const int n = T.d_nanc[k], np = n * (n + 1) / 2;
+    for (int l = 0; l < 64; l++) {
+      uint32_t w = 0;
+      for (int hf = 0; hf < 2; hf++) {
+        const int q = l + 64 * hf;
+        uint32_t t = 0;
+        if (q < np) { const int a = T.tri_a[q], c = T.tri_b[q]; t = (uint32_t)(T.d_madr[T.d_anc[k][a]] + (c - a)); }
+        w |= t << (16 * hf);
+      }
+      T.f_tgt[k][l] = w;
+    }
+  }
 }
 
 // Reorder every hull into compact clusters: a k-d partition (median split along the longest extent) down to leaves of at
