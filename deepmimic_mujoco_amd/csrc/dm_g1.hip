@@ -425,8 +425,8 @@ __device__ __noinline__ void crb_factor(const Dev &T, const int lane) {   // [EX
 }
 
 // x <- M^-1 x for an LDS vector.  (The same solve on 43 registers with static indices, as the constraint rows use, measured
-// SLOWER here — +1 ms per launch: ~1 700 straight-line instructions executed once are 200 instruction-cache misses, the loop
-// below stays resident.)
+// SLOWER here — +1 ms per launch, ~100 k cycles per call: ~1 700 straight-line instructions with 800 factor reads from LDS
+// executed once, against this resident loop; cause not isolated.)
 __device__ __noinline__ void solve_m(const Dev &T, float *x, const int lane) {
   for (int i = NV - 1; i >= 0; i--) {
     const int n = T.d_nanc[i];
