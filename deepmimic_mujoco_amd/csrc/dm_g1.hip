@@ -334,6 +334,7 @@ __device__ __noinline__ void com_pos(const Dev &T, const int lane) {   // [EXT] 
   SYNC();
 }
 
+__device__ __forceinline__ float bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 // x <- L^-T x for one constraint row held in registers: the dof tree is compile-time (dm_g1_topology.h), so every index is
 // static; the factor entries are wave-uniform LDS reads
 template <int I, int J, int OFF>
@@ -424,26 +425,48 @@ __device__ __noinline__ void crb_factor(const Dev &T, const int lane) {   // [EX
   SYNC();
 }
 
-// x <- M^-1 x for an LDS vector.  (The same solve on 43 registers with static indices, as the constraint rows use, measured
-// SLOWER here — +1 ms per launch, ~100 k cycles per call: ~1 700 straight-line instructions with 800 factor reads from LDS
-// executed once, against this resident loop; cause not isolated.)
-__device__ __noinline__ void solve_m(const Dev &T, float *x, const int lane) {
-  for (int i = NV - 1; i >= 0; i--) {
-    const int n = T.d_nanc[i];
-    if (lane < n) x[T.d_anc[i][lane]] -= S.qLD[T.d_madr[i] + 1 + lane] * x[i];
-    if (n) SYNC();
-  }
-  if (lane < NV) x[lane] *= S.dinv[lane];
-  SYNC();
-  for (int i = 0; i < NV; i++) {
-    const int n = T.d_nanc[i];
-    if (n) {
-      float p = (lane < n) ? S.qLD[T.d_madr[i] + 1 + lane] * x[T.d_anc[i][lane]] : 0.f;
-      p = wsum(p);
-      if (lane == 0) x[i] -= p;
-      SYNC();
+// x <- M^-1 x for an LDS vector, M = L^T D L on the compile-time dof tree: lane j keeps x_j in a register.  L^-T: dofs in
+// descending order, x_i broadcast (v_readlane, static lane) to its ancestors — the ancestors of a dof are a chain, so the factor
+// entry lane j needs is qLD[MADR[i] + NANC[i] - nanc_j] and "is an ancestor" is a compile-time lane mask.  L^-1: dofs in
+// ascending order, the final x_j broadcast to its descendants (column-oriented, no reduction).  ~450 instructions with
+// two-instruction dependent steps; the tree walk through T.d_nanc / T.d_anc it replaces (a table load, LDS read-modify-writes
+// and a wave reduction per dof) took ~100 k cycles per call, eight calls per env-step.  (A static solve with the whole vector in
+// 43 registers of every lane, as the constraint rows use, was slower still: +1 ms per launch.)
+constexpr uint64_t g1_anc_mask(int i) {
+  uint64_t m = 0;
+  for (int j = g1topo::PARENT[i]; j >= 0; j = g1topo::PARENT[j]) m |= 1ull << j;
+  return m;
+}
+constexpr uint64_t g1_desc_mask(int j) {
+  uint64_t m = 0;
+  for (int i = 0; i < g1topo::NV; i++) if ((g1_anc_mask(i) >> j) & 1) m |= 1ull << i;
+  return m;
+}
+__device__ __noinline__ void solve_m(const Dev &T, float *xl, const int lane) {
+  const int lk = lane < NV ? lane : 0;
+  const int nl = T.d_nanc[lk], ml = T.d_madr[lk] + nl;
+  float x = xl[lk];
+  StaticFor<0, NV - 1>::run([&](auto ic) {
+    constexpr int i = NV - 1 - decltype(ic)::value;            // NV-1 .. 1
+    constexpr uint64_t mask = g1_anc_mask(i);
+    constexpr int base = g1topo::MADR[i] + g1topo::NANC[i];
+    const float xi = bcast(x, i);
+    if ((mask >> lane) & 1) x = fmaf(-S.qLD[base - nl], xi, x);
+    return true;
+  });
+  x *= S.dinv[lk];
+  StaticFor<0, NV - 1>::run([&](auto jc) {
+    constexpr int j = decltype(jc)::value;                     // 0 .. NV-2
+    constexpr uint64_t mask = g1_desc_mask(j);
+    if constexpr (mask != 0) {
+      const float xj = bcast(x, j);
+      if ((mask >> lane) & 1) x = fmaf(-S.qLD[ml - g1topo::NANC[j]], xj, x);
     }
-  }
+    return true;
+  });
+  SYNC();
+  if (lane < NV) xl[lane] = x;
+  SYNC();
 }
 
 // ------------------------------------------------------------------------------------------ velocity stage
@@ -1532,7 +1555,6 @@ __device__ __noinline__ int make_constraint(const Dev &T, float *JT, float *RW, 
   return nefc;
 }
 
-__device__ __forceinline__ float bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 // A = J M^-1 J^T + R into the per-env scratch.  Up to 128 rows: lane r (and r + 64) keeps its row of B = D^-1/2 L^-T J^T in
 // 43 registers (solved with static indices), and A[i][:] is 43 broadcasts of row i (v_readlane: scalar operands) times the
