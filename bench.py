@@ -131,6 +131,26 @@ def g1_record(local_rank, n=4096, steps=20, warmup=5, with_cpu=False):
     except Exception as e:  # noqa: BLE001
         rec["valu"] = {"error": repr(e)[:200]}
     eng.close()
+    # the same at 16 384 envs: at 4 096 the launch lasts as long as its heaviest env (longest-first order, two rounds); with more
+    # envs per GPU the mean cost is what counts
+    nb = 4 * n
+    eng = G1HipEngine(nb, device=local_rank, auto_reset=True, seed=3)
+    eng.load_clip(mc)
+    outb = eng.alloc_outputs()
+    eng.reset(outb["obs"])
+    actb = [torch.rand(nb, NACT, device=eng.device, generator=g) * 2 - 1 for _ in range(4)]
+    for t in range(warmup):
+        eng.step(actb[t % 4], outb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(steps // 2):
+        eng.step(actb[t % 4], outb)
+    torch.cuda.synchronize()
+    dtb = time.perf_counter() - t0
+    rec["larger_batch"] = {"envs_per_gpu": nb, "env_steps_per_s": nb * (steps // 2) / dtb, "ms_per_step": dtb / (steps // 2) * 1e3,
+                           "kernel_ms_last": eng.last_kernel_ms()}
+    eng.close()
+    del outb, actb
     # DPCombinedEnv() as src/sb3_ppo.py:277-278 trains it: walk / run / getup state machine on the G1, RSI auto-reset
     from deepmimic_mujoco_amd.g1 import HipG1CombinedVecEnv
     venv = HipG1CombinedVecEnv(n, device=local_rank, seed=3)
