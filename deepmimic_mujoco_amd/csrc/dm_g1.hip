@@ -95,6 +95,7 @@ struct Lds {   // per-env working set (one wave): 19.2 KB, eight waves per CU
       int32_t geoi[2][6];    // type, nvert, nclus, vertex start, cluster start, pad
       double rc[8][7];       // its contacts: dist, pos 3, normal 3
       double poly[2][16][3]; // box-box polygons
+      double mpr_ps[4][9];   // MPR portal (v0..v3: v, v1, v2): wave-uniform state, 72 VGPRs if kept per lane
     } co;
   } u;
 };
@@ -858,7 +859,8 @@ __device__ __forceinline__ int mpr_penetration(const Geo &a, const Geo &b, doubl
   enum { V1, V2, DISCOVER, REFINE, PENETR, HINT };
   constexpr double SEP_EPS = 1e-9;
   sep_valid = false;
-  Sup ps[4], sv;
+  Sup *ps = reinterpret_cast<Sup *>(&S.u.co.mpr_ps[0][0]);   // (every lane writes the same values)
+  Sup sv;
   double d[3], va[3], vb[3], dot;
   for (int i = 0; i < 3; i++) { ps[0].v1[i] = a.center[i]; ps[0].v2[i] = b.center[i]; ps[0].v[i] = a.center[i] - b.center[i]; }
   if (ccd_zero(ps[0].v[0]) && ccd_zero(ps[0].v[1]) && ccd_zero(ps[0].v[2])) ps[0].v[0] += CCD_EPS * 10;
