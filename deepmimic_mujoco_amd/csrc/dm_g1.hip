@@ -1730,11 +1730,14 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
     while (iter < max_iter) {
       const float nlo = lo0 - f0, nhi = hi0 - f0;
       float seen = g0;
+      int lane_s = lane;
+      asm volatile("" : "+v"(lane_s));   // keeps the per-row lane compares inside the sweep (else 64 SGPR pairs of masks spill)
       StaticFor<0, 64>::run([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         if (i >= nefc) return false;
         const float dl_ = bcast(__builtin_amdgcn_fmed3f(g0, nlo, nhi), i);
-        seen = (lane == i) ? g0 : seen;
+        seen = (lane_s == i) ? g0 : seen;
+        asm volatile("" : "+v"(seen));   // select NOW: left alone the compiler keeps all 64 intermediate g alive and spills A
         g0 = fmaf(arow[i], dl_, g0);
         return true;
       });
@@ -1763,10 +1766,13 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
     while (iter < max_iter) {
       const float nlo0 = lo0 - f0, nhi0 = hi0 - f0, nlo1 = lo1 - f1, nhi1 = hi1 - f1;
       float seen0 = g0, seen1 = g1;
+      int lane_s = lane;
+      asm volatile("" : "+v"(lane_s));
       StaticFor<0, 64>::run([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const float dl_ = bcast(__builtin_amdgcn_fmed3f(g0, nlo0, nhi0), i);
-        seen0 = (lane == i) ? g0 : seen0;
+        seen0 = (lane_s == i) ? g0 : seen0;
+        asm volatile("" : "+v"(seen0));
         g0 = fmaf(ar0[i], dl_, g0);
         g1 = fmaf(ar1[i], dl_, g1);
         return true;
@@ -1784,7 +1790,8 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
           const int src = i0 + q - 64;
           if (i0 + q < nefc) {
             const float dl_ = bcast(__builtin_amdgcn_fmed3f(g1, nlo1, nhi1), src);
-            seen1 = (lane == src) ? g1 : seen1;
+            seen1 = (lane_s == src) ? g1 : seen1;
+            asm volatile("" : "+v"(seen1));
             g0 = fmaf(a0[q] * nainv0, dl_, g0);
             g1 = fmaf(a1[q] * nainv1, dl_, g1);
           }
