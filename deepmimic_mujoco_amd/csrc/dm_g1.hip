@@ -1564,9 +1564,10 @@ __device__ __noinline__ int make_constraint(const Dev &T, float *JT, float *RW, 
 __device__ __noinline__ void project_constraint(const Dev &T, const float *JT, float *BT, float *AR, const float *RW,
                                                 const int nefc, const int lane) {
   const float *e_R = RW;
-  if (nefc <= 128) {
-    // rows in chunks of 64: the lanes' rows of B in 43 registers each; A[i][j] for i in the same chunk by broadcasts of row
-    // i, for i in the other chunk from the rows that chunk stored in the B^T scratch (wave-uniform loads)
+  if (nefc <= MAXROW) {
+    // rows in chunks of 64 (up to four): the lanes' rows of B in 43 registers each; A[i][j] for i in the same chunk by
+    // broadcasts of row i, for i in an EARLIER chunk from the rows that chunk stored in the B^T scratch (wave-uniform loads),
+    // written both ways
     const int nchunk = (nefc + 63) >> 6;
     for (int cj = 0; cj < nchunk; cj++) {
       const int j = lane + 64 * cj;
@@ -1591,8 +1592,8 @@ __device__ __noinline__ void project_constraint(const Dev &T, const float *JT, f
         for (int k = 0; k < NV; k++) s0 = fmaf(bcast(x[k], l), x[k], s0);
         if (on) AR[i * MAXROW + j] = s0 + ((i == j) ? rj : 0.f);
       }
-      if (cj == 1) {                    // cross block: rows of chunk 0 (in the scratch) against this chunk's columns, both ways
-        for (int i = 0; i < 64; i++) {
+      if (cj >= 1) {                    // cross blocks: rows of the earlier chunks (in the scratch) against this chunk's columns, both ways
+        for (int i = 0; i < 64 * cj; i++) {
           float s0 = 0;
 #pragma unroll
           for (int k = 0; k < NV; k++) s0 = fmaf(BT[k * MAXROW + i], x[k], s0);
@@ -1603,26 +1604,6 @@ __device__ __noinline__ void project_constraint(const Dev &T, const float *JT, f
     SYNC();
     return;
   }
-  for (int r = lane; r < nefc; r += 64) {   // each lane solves its own row: x <- D^-1/2 L^-T x
-    for (int k = 0; k < NV; k++) BT[k * MAXROW + r] = JT[k * MAXROW + r];
-    for (int i = NV - 1; i >= 0; i--) {
-      const float xi = BT[i * MAXROW + r];
-      if (xi != 0.f) {
-        const int n = T.d_nanc[i], a0 = T.d_madr[i] + 1;
-        for (int a = 0; a < n; a++) BT[T.d_anc[i][a] * MAXROW + r] -= S.qLD[a0 + a] * xi;
-      }
-    }
-    for (int k = 0; k < NV; k++) BT[k * MAXROW + r] *= S.dsq[k];
-  }
-  SYNC();
-  for (int i = 0; i < nefc; i++)
-    for (int j = lane; j < nefc; j += 64) {
-      float s = 0;
-      for (int k = 0; k < NV; k++) s += BT[k * MAXROW + i] * BT[k * MAXROW + j];
-      if (i == j) s += e_R[i];
-      AR[i * MAXROW + j] = s;
-    }
-  SYNC();
 }
 
 // [EXT] mj_fwdConstraint + mj_solPGS: dual PGS, rows unilateral (limits, pyramid edges) or boxed (friction loss)
@@ -1690,26 +1671,6 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
   PROF(11);
   constexpr int PF = 16;
   int iter = 0;
-  // One sweep step for a row owned by lane `src` of register set M: the owner's residual, force, A_ii, 1 / A_ii and bound
-  // are broadcast (v_readlane with a uniform lane) and EVERY lane computes the new force — no divergent branch and no LDS
-  // permute in the sweep's dependent chain; then one FMA per resident row set on the residuals.
-#define PGS_STEP(M, SRC, A0, A1)                                                                   \
-  {                                                                                                \
-    const float rs_ = bcast(res[M], SRC), old_ = bcast(fr[M], SRC), ai_ = bcast(dinv[M], SRC);     \
-    const float fl_ = bcast(lm[M], SRC), aii_ = bcast(diag[M], SRC);                               \
-    float f_ = fmaf(-rs_, ai_, old_);                                                              \
-    f_ = (fl_ >= 0.f) ? fminf(fmaxf(f_, -fl_), fl_) : fmaxf(f_, 0.f);                              \
-    const float dl_ = f_ - old_;                                                                   \
-    improvement -= dl_ * fmaf(0.5f * dl_, aii_, rs_);                                              \
-    fr[M] = (lane == (SRC)) ? f_ : fr[M];                                                          \
-    res[0] = fmaf(A0, dl_, res[0]);                                                                \
-    res[1] = fmaf(A1, dl_, res[1]);                                                                \
-    if (nr > 2 && dl_ != 0.f) {                                                                    \
-      const float *row_ = AR + ((SRC) + 64 * M) * MAXROW;                                          \
-      if (lane + 128 < nefc) res[2] += row_[lane + 128] * dl_;                                     \
-      if (nr > 3 && lane + 192 < nefc) res[3] += row_[lane + 192] * dl_;                           \
-    }                                                                                              \
-  }
   if (nefc <= 64) {
     // up to 64 rows (nine evaluations in ten): lane j keeps its row of A in 64 registers, the sweep is unrolled over the rows
     // with static lanes and static register indices — no memory and no dynamic lane select in the sweep's dependent chain
@@ -1806,43 +1767,65 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
     }
     fr[0] = f0; fr[1] = f1;
   } else {
-  const int n0 = nefc < 64 ? nefc : 64, n1 = nefc < 128 ? nefc : 128;
-  while (iter < max_iter) {
-    float improvement = 0;
-    for (int i0 = 0; i0 < n0; i0 += PF) {      // rows 0..63: register set 0
-      float a0[PF], a1[PF];
+    // 129..256 rows (bodies lying on the floor with many mesh / floor contacts — the DPCombinedEnv getup phases): four rows per
+    // lane, the same scaled-residual step; the four A columns of a row are requested a block of PF rows ahead (the block's
+    // owner register set is uniform: PF divides 64)
+    float g[4], f[4], lo[4], hi[4], nainv[4], aii[4];
+    bool has[4];
 #pragma unroll
-      for (int q = 0; q < PF; q++) {
-        const int i = i0 + q;
-        a0[q] = (i < n0 && lane < nefc) ? AR[i * MAXROW + lane] : 0.f;
-        a1[q] = (nr > 1 && i < n0 && lane + 64 < nefc) ? AR[i * MAXROW + lane + 64] : 0.f;
+    for (int m = 0; m < 4; m++) {
+      has[m] = m < nr && lane + 64 * m < nefc;
+      f[m] = fr[m]; aii[m] = diag[m]; nainv[m] = -dinv[m];
+      lo[m] = lm[m] >= 0.f ? -lm[m] : 0.f;
+      hi[m] = lm[m] >= 0.f ? lm[m] : __builtin_inff();
+      g[m] = res[m] * nainv[m];
+    }
+    while (iter < max_iter) {
+      float nlo[4], nhi[4], seen[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++) { nlo[m] = lo[m] - f[m]; nhi[m] = hi[m] - f[m]; seen[m] = g[m]; }
+      int lane_s = lane;
+      asm volatile("" : "+v"(lane_s));
+      for (int i0 = 0; i0 < nefc; i0 += PF) {
+        float a[4][PF];
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+          const int i = i0 + q;
+#pragma unroll
+          for (int m = 0; m < 4; m++) a[m][q] = (i < nefc && has[m]) ? AR[i * MAXROW + lane + 64 * m] : 0.f;
+        }
+#define PGS_BLOCK(M)                                                                        \
+        _Pragma("unroll") for (int q = 0; q < PF; q++) {                                    \
+          const int src = (i0 + q) & 63;                                                    \
+          if (i0 + q < nefc) {                                                              \
+            const float dl_ = bcast(__builtin_amdgcn_fmed3f(g[M], nlo[M], nhi[M]), src);    \
+            seen[M] = (lane_s == src) ? g[M] : seen[M];                                     \
+            asm volatile("" : "+v"(seen[M]));                                               \
+            _Pragma("unroll") for (int m = 0; m < 4; m++) g[m] = fmaf(a[m][q] * nainv[m], dl_, g[m]); \
+          }                                                                                 \
+        }
+        switch (i0 >> 6) {
+          case 0: PGS_BLOCK(0) break;
+          case 1: PGS_BLOCK(1) break;
+          case 2: PGS_BLOCK(2) break;
+          default: PGS_BLOCK(3) break;
+        }
+#undef PGS_BLOCK
       }
+      float imp = 0.f;
 #pragma unroll
-      for (int q = 0; q < PF; q++)
-        if (i0 + q < n0) PGS_STEP(0, i0 + q, a0[q], a1[q])
-    }
-    for (int i0 = 64; i0 < n1; i0 += PF) {     // rows 64..127: register set 1
-      float a0[PF], a1[PF];
-#pragma unroll
-      for (int q = 0; q < PF; q++) {
-        const int i = i0 + q;
-        a0[q] = (i < n1) ? AR[i * MAXROW + lane] : 0.f;
-        a1[q] = (i < n1 && lane + 64 < nefc) ? AR[i * MAXROW + lane + 64] : 0.f;
+      for (int m = 0; m < 4; m++) {
+        const float dl = has[m] ? __builtin_amdgcn_fmed3f(seen[m], nlo[m], nhi[m]) : 0.f;
+        imp += dl * aii[m] * (0.5f * dl - seen[m]);
+        if (has[m]) f[m] = (dl == nlo[m]) ? lo[m] : ((dl == nhi[m]) ? hi[m] : f[m] + dl);
       }
+      const float improvement = -wsum(imp);
+      iter++;
+      if (improvement * T.pgs_scale < T.tolerance) break;
+    }
 #pragma unroll
-      for (int q = 0; q < PF; q++)
-        if (i0 + q < n1) PGS_STEP(1, i0 + q - 64, a0[q], a1[q])
-    }
-    for (int i = 128; i < nefc; i++) {         // rows 128..255 (rare): straight from the scratch
-      const float *row = AR + i * MAXROW;
-      const float x0 = (lane < nefc) ? row[lane] : 0.f, x1 = (lane + 64 < nefc) ? row[lane + 64] : 0.f;
-      if (i < 192) PGS_STEP(2, i - 128, x0, x1) else PGS_STEP(3, i - 192, x0, x1)
-    }
-    iter++;
-    if (improvement * T.pgs_scale < T.tolerance) break;   // (uniform: every lane accumulated the same sum)
+    for (int m = 0; m < 4; m++) fr[m] = f[m];
   }
-  }
-#undef PGS_STEP
   PROF(12);
 #pragma unroll
   for (int m = 0; m < 4; m++) { const int r = lane + 64 * m; if (m < nr && r < nefc) e_f[r] = fr[m]; }

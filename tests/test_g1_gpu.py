@@ -52,11 +52,37 @@ def _states(n, seed=0):
 def test_g1_forward_evaluation_matches_the_oracle():
     """set_state + forward on 32 states: body poses, unconstrained acceleration, the contact list (geoms, distance, position,
     normal, in order), the row count and the constrained acceleration."""
+    q, v = _states(32)
+    ncons, nefcs = _forward_parity(q, v, "G1 forward parity:")
+    assert max(ncons) >= 8 and min(ncons) == 0 or max(ncons) >= 8
+
+
+def test_g1_forward_evaluation_with_more_than_128_rows():
+    """Robots pressed face-down into the floor with folded limbs: 20+ contacts, 129..256 constraint rows — the four-rows-per-lane
+    PGS and the four-chunk A = J M^-1 J^T (the DPCombinedEnv getup phases live here)."""
+    rng = np.random.default_rng(11)
+    mc = _clip("getup_facedown")
+    qs, vs = [], []
+    for i in range(24):
+        fr = int(rng.integers(0, 40))
+        q, v = np.array(mc.data_config[fr]), np.array(mc.data_vel[fr]) * 0.0
+        q[2] -= rng.uniform(0.015, 0.05)
+        q[7:] += rng.uniform(-0.35, 0.35, 37)
+        v = rng.normal(size=43) * 0.3
+        qs.append(q)
+        vs.append(v)
+    # (centimetres of interpenetration: MPR's portal is ill-conditioned there — DESIGN §10 — and one contact normal in ~400 differs in
+    # the second digit between fp32 and fp64 body poses; positions, distances, row counts and accelerations are held as elsewhere)
+    ncons, nefcs = _forward_parity(np.array(qs), np.array(vs), "G1 forward parity, many rows:", cnrm_tol=0.1)
+    print("   rows per state", nefcs)
+    assert sum(1 for x in nefcs if x > 128) >= 4 and max(nefcs) <= 256
+
+
+def _forward_parity(q, v, label, cnrm_tol=2e-3):
     import torch
     from deepmimic_mujoco_amd.g1 import G1HipEngine
     from oracle import oracle_g1 as og
-    n = 32
-    q, v = _states(n)
+    n = len(q)
     eng = G1HipEngine(n, auto_reset=False)
     eng.load_clip(_clip("walk"))
     dbg = eng.enable_debug()
@@ -65,7 +91,7 @@ def test_g1_forward_evaluation_matches_the_oracle():
     torch.cuda.synchronize()
     dbg = dbg.cpu().numpy()
     worst = dict(xpos=0.0, qas=0.0, qacc=0.0, cdist=0.0, cpos=0.0, cnrm=0.0)
-    ncons, flips = [], 0
+    ncons, nefcs, flips = [], [], 0
     for i in range(n):
         s = og.G1Sim()
         s.set_caps(48, 256)
@@ -89,15 +115,16 @@ def test_g1_forward_evaluation_matches_the_oracle():
             worst["cpos"] = max(worst["cpos"], np.abs(r[3:6] - c["pos"]).max())
             worst["cnrm"] = max(worst["cnrm"], np.abs(r[6:9] - c["frame"][0]).max())
         assert int(d[204]) == s.geti("nefc"), (i, d[204], s.geti("nefc"))
+        nefcs.append(int(d[204]))
         qa = s.get("qacc")
         worst["qacc"] = max(worst["qacc"], np.abs(d[160:203] - qa).max() / max(1.0, np.abs(qa).max()))
-    print("G1 forward parity:", {k: float(v) for k, v in worst.items()}, "ncon", ncons, "contact-set flips", flips)
+    print(label, {k: float(v) for k, v in worst.items()}, "ncon", ncons, "contact-set flips", flips)
     assert flips <= 2
     assert worst["xpos"] < 2e-6 and worst["qas"] < 2e-4
-    assert worst["cdist"] < 2e-5 and worst["cpos"] < 2e-4 and worst["cnrm"] < 2e-3
+    assert worst["cdist"] < 2e-5 and worst["cpos"] < 2e-4 and worst["cnrm"] < cnrm_tol
     assert worst["qacc"] < 5e-3
-    assert max(ncons) >= 8 and min(ncons) == 0 or max(ncons) >= 8
     eng.close()
+    return ncons, nefcs
 
 
 def _teacher_forced(n, steps, act_scale, seed, stride=4):
