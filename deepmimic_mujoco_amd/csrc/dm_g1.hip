@@ -738,6 +738,11 @@ __device__ __forceinline__ void mesh_support_pair(const Geo &A, const double *dl
   if (meshA) wave_pick(pa);
   if (meshB) wave_pick(pb);
 }
+__device__ __forceinline__ int mesh_support_index(const Geo &g, const double *dl, const int lane) {
+  MeshPick i, j;
+  mesh_support_pair(g, dl, true, i, g, dl, false, j, lane);
+  return i.bk;
+}
 
 // [EXT] mjccd_support for the analytic shapes (local direction dl -> local point p)
 __device__ __forceinline__ void support_local(const Geo &g, const double *dl, double *p) {
@@ -1069,30 +1074,20 @@ __device__ __forceinline__ int np_plane_cylinder(Con *c, const Geo &p, const Geo
 // restatement of the multi-contact rule, identical to the oracle's)
 __device__ __noinline__ int np_plane_mesh(Con *c, const Geo &p, const Geo &g, const int lane) {
   double normal[3] = {p.mat[2], p.mat[5], p.mat[8]}, t1[3] = {p.mat[0], p.mat[3], p.mat[6]}, t2[3] = {p.mat[1], p.mat[4], p.mat[7]};
-  // the four support queries (straight down, then three tilted directions): the first alone (most pairs end there: no
-  // contact), the second and third TOGETHER in the two slots of the pair routine (one set of round trips), the fourth alone;
-  // every pick carries its vertex
-  double dl[4][3];
+  int used[4], n = 0;
   for (int k = 0; k < 4; k++) {
-    double dw[3];
+    double dw[3], dl[3];
     if (k == 0) for (int i = 0; i < 3; i++) dw[i] = -normal[i];
     else {
       const double ang = 2.0 * 3.14159265358979323846 * (k - 1) / 3.0, ca = 0.3 * cos(ang), sa = 0.3 * sin(ang);
       for (int i = 0; i < 3; i++) dw[i] = -normal[i] + ca * t1[i] + sa * t2[i];
     }
-    drot_t(dl[k], g.mat, dw);
-  }
-  MeshPick pk[4], dummy;
-  int used[4], n = 0;
-  for (int k = 0; k < 4; k++) {
-    if (k == 0) mesh_support_pair(g, dl[0], true, pk[0], g, dl[0], false, dummy, lane);
-    else if (k == 1) mesh_support_pair(g, dl[1], true, pk[1], g, dl[2], true, pk[2], lane);
-    else if (k == 3) mesh_support_pair(g, dl[3], true, pk[3], g, dl[3], false, dummy, lane);
-    const int vi = pk[k].bk;
+    drot_t(dl, g.mat, dw);
+    const int vi = mesh_support_index(g, dl, lane);
     bool dup = false;
     for (int j = 0; j < n; j++) dup |= used[j] == vi;
     if (dup) continue;
-    double v[3], dif[3], vl[3] = {pk[k].x, pk[k].y, pk[k].z};
+    double v[3], dif[3], vl[3] = {g.vert[3 * vi], g.vert[3 * vi + 1], g.vert[3 * vi + 2]};
     drot(v, g.mat, vl);
     for (int i = 0; i < 3; i++) v[i] += g.pos[i];
     dsub(dif, v, p.pos);
