@@ -1583,21 +1583,30 @@ __device__ __noinline__ void project_constraint(const Dev &T, const float *JT, f
         for (int k = 0; k < NV; k++) if (on) BT[k * MAXROW + j] = x[k];
         SYNC();
       }
+      // A is stored SCALED for the PGS sweep: entry (i, j) x -1 / A_jj, the factor of the lane that owns column j (the sweep
+      // carries g_j = -r_j / A_jj); the diagonal itself goes to the spare row 43 of the B^T scratch
       const float rj = on ? e_R[j] : 0.f;
+      float ajj = rj;
+#pragma unroll
+      for (int k = 0; k < NV; k++) ajj = fmaf(x[k], x[k], ajj);
+      const float nj = on ? -1.f / ajj : 0.f;
+      if (on) BT[NV * MAXROW + j] = ajj;
+      if (nchunk > 1) SYNC();
       const int i0 = 64 * cj, i1 = (i0 + 64 < nefc) ? i0 + 64 : nefc;
       for (int i = i0; i < i1; i++) {   // rows of the same chunk: broadcasts
         const int l = i & 63;
         float s0 = 0;
 #pragma unroll
         for (int k = 0; k < NV; k++) s0 = fmaf(bcast(x[k], l), x[k], s0);
-        if (on) AR[i * MAXROW + j] = s0 + ((i == j) ? rj : 0.f);
+        if (on) AR[i * MAXROW + j] = (i == j) ? -1.f : s0 * nj;
       }
       if (cj >= 1) {                    // cross blocks: rows of the earlier chunks (in the scratch) against this chunk's columns, both ways
         for (int i = 0; i < 64 * cj; i++) {
           float s0 = 0;
 #pragma unroll
           for (int k = 0; k < NV; k++) s0 = fmaf(BT[k * MAXROW + i], x[k], s0);
-          if (on) { AR[i * MAXROW + j] = s0; AR[j * MAXROW + i] = s0; }
+          const float ni = -1.f / BT[NV * MAXROW + i];
+          if (on) { AR[i * MAXROW + j] = s0 * nj; AR[j * MAXROW + i] = s0 * ni; }
         }
       }
     }
@@ -1607,7 +1616,8 @@ __device__ __noinline__ void project_constraint(const Dev &T, const float *JT, f
 }
 
 // [EXT] mj_fwdConstraint + mj_solPGS: dual PGS, rows unilateral (limits, pyramid edges) or boxed (friction loss)
-__device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const float *AR, float *RW, const int nefc, const int lane, const int max_iter) {
+__device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const float *BT, const float *AR, float *RW, const int nefc, const int lane,
+                                             const int max_iter) {
   float *e_R = RW, *e_b = RW + MAXROW, *e_f = RW + 2 * MAXROW, *e_lim = RW + 3 * MAXROW;
   const int32_t *e_meta = (const int32_t *)(RW + 4 * MAXROW);
   if (nefc == 0) {
@@ -1649,10 +1659,11 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
 #pragma unroll
         for (int q = 0; q < 8; q++) s = fmaf(a[q], fc[q], s);
       }
+      diag[m] = BT[NV * MAXROW + r];
+      s *= -diag[m];                                     // A is stored x -1 / A_rr (project_constraint)
       fr[m] = e_f[r];
       cost += fr[m] * (0.5f * s + e_b[r]);
       res[m] = e_b[r] + s;
-      diag[m] = AR[r * MAXROW + r];
     }
   }
   cost = wsum(cost);
@@ -1686,8 +1697,6 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
     const float aii0 = diag[0], fl0 = lm[0], nainv0 = -dinv[0];
     const float lo0 = fl0 >= 0.f ? -fl0 : 0.f, hi0 = fl0 >= 0.f ? fl0 : __builtin_inff();
     float g0 = res[0] * nainv0;
-#pragma unroll
-    for (int i = 0; i < 64; i++) arow[i] *= nainv0;
     while (iter < max_iter) {
       const float nlo = lo0 - f0, nhi = hi0 - f0;
       float seen = g0;
@@ -1721,8 +1730,6 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
     const float lo0 = fl0 >= 0.f ? -fl0 : 0.f, hi0 = fl0 >= 0.f ? fl0 : __builtin_inff();
     const float lo1 = fl1 >= 0.f ? -fl1 : 0.f, hi1 = fl1 >= 0.f ? fl1 : __builtin_inff();
     float g0 = res[0] * nainv0, g1 = res[1] * nainv1;
-#pragma unroll
-    for (int i = 0; i < 64; i++) { ar0[i] *= nainv0; ar1[i] *= nainv1; }
     const bool has1 = lane + 64 < nefc;
     while (iter < max_iter) {
       const float nlo0 = lo0 - f0, nhi0 = hi0 - f0, nlo1 = lo1 - f1, nhi1 = hi1 - f1;
@@ -1753,8 +1760,8 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
             const float dl_ = bcast(__builtin_amdgcn_fmed3f(g1, nlo1, nhi1), src);
             seen1 = (lane_s == src) ? g1 : seen1;
             asm volatile("" : "+v"(seen1));
-            g0 = fmaf(a0[q] * nainv0, dl_, g0);
-            g1 = fmaf(a1[q] * nainv1, dl_, g1);
+            g0 = fmaf(a0[q], dl_, g0);
+            g1 = fmaf(a1[q], dl_, g1);
           }
         }
       }
@@ -1801,7 +1808,7 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
             const float dl_ = bcast(__builtin_amdgcn_fmed3f(g[M], nlo[M], nhi[M]), src);    \
             seen[M] = (lane_s == src) ? g[M] : seen[M];                                     \
             asm volatile("" : "+v"(seen[M]));                                               \
-            _Pragma("unroll") for (int m = 0; m < 4; m++) g[m] = fmaf(a[m][q] * nainv[m], dl_, g[m]); \
+            _Pragma("unroll") for (int m = 0; m < 4; m++) g[m] = fmaf(a[m][q], dl_, g[m]); \
           }                                                                                 \
         }
         switch (i0 >> 6) {
@@ -1878,7 +1885,7 @@ __device__ __noinline__ void forward(const Launch &P, const Dev &T, const int en
   if (!(P.pad & 4)) project_constraint(T, JT, BT, AR, RW, nefc, lane);
   PROF(9);
   if (P.pad & 16) nefc = 0;
-  fwd_constraint(T, JT, AR, RW, nefc, lane, (P.pad & 1) ? 0 : T.iterations);
+  fwd_constraint(T, JT, BT, AR, RW, nefc, lane, (P.pad & 1) ? 0 : T.iterations);
   PROF(10);
 }
 
