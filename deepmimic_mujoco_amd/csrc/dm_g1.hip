@@ -2429,10 +2429,31 @@ static int g1_build_meshes(const DmModelG1 &m, g1::Dev &T, std::vector<double> &
       const int cnt = lf.second - lf.first;
       for (int k = lf.first; k < lf.second; k++) for (int i = 0; i < 3; i++) cc[i] += m.mesh_vert[a0 + idx[k]][i];
       for (int i = 0; i < 3; i++) cc[i] /= cnt;
+      auto radius_at = [&](const double *c3) {
+        double r = 0;
+        for (int k = lf.first; k < lf.second; k++) {
+          double d2 = 0;
+          for (int i = 0; i < 3; i++) { const double df = m.mesh_vert[a0 + idx[k]][i] - c3[i]; d2 += df * df; }
+          r = fmax(r, sqrt(d2));
+        }
+        return r;
+      };
+      rad = radius_at(cc);
+      {   // a tighter enclosing sphere (Badoiu-Clarkson steps towards the farthest vertex): fewer clusters survive the bound test
+        double c2[3] = {cc[0], cc[1], cc[2]};
+        for (int it = 1; it <= 200; it++) {
+          int far = lf.first; double best = -1;
+          for (int k = lf.first; k < lf.second; k++) {
+            double d2 = 0;
+            for (int i = 0; i < 3; i++) { const double df = m.mesh_vert[a0 + idx[k]][i] - c2[i]; d2 += df * df; }
+            if (d2 > best) { best = d2; far = k; }
+          }
+          for (int i = 0; i < 3; i++) c2[i] += (m.mesh_vert[a0 + idx[far]][i] - c2[i]) / (it + 1);
+          const double r2 = radius_at(c2);
+          if (r2 < rad) { rad = r2; for (int i = 0; i < 3; i++) cc[i] = c2[i]; }
+        }
+      }
       for (int k = lf.first; k < lf.second; k++) {
-        double d2 = 0;
-        for (int i = 0; i < 3; i++) { const double df = m.mesh_vert[a0 + idx[k]][i] - cc[i]; d2 += df * df; }
-        rad = fmax(rad, sqrt(d2));
         for (int i = 0; i < 3; i++) verts.push_back(m.mesh_vert[a0 + idx[k]][i]);
         oidx.push_back(idx[k]);
       }
