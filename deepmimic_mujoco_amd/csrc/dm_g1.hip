@@ -650,15 +650,15 @@ __device__ __forceinline__ bool next4(unsigned long long (&todo)[NCH], int (&c)[
   return any;
 }
 // cluster spheres of one hull for clusters lane + 64 m (loads only), then bounds ub[m] and the cluster with the largest centre . d
-struct ClusLoad { double c[NCH][4]; };
+struct ClusLoad { double c[NCH][7]; };   // centre 3 | sphere radius | half extents of the box about the centre 3
 __device__ __forceinline__ void cluster_load(const Geo &g, const bool on, ClusLoad &L, const int lane) {
 #pragma unroll
   for (int m = 0; m < NCH; m++) {
     const int c = lane + 64 * m;
     const bool ok = on && c < g.nclus;
-    const double *cl = g.clus + 4 * (ok ? c : 0);
+    const double *cl = g.clus + 8 * (ok ? c : 0);
 #pragma unroll
-    for (int i = 0; i < 4; i++) L.c[m][i] = ok ? cl[i] : 0.0;
+    for (int i = 0; i < 7; i++) L.c[m][i] = ok ? cl[i] : 0.0;
   }
 }
 __device__ __forceinline__ void cluster_bounds(const Geo &g, const double *dl, const bool on, const ClusLoad &L, double (&ub)[NCH], int &top,
@@ -673,7 +673,8 @@ __device__ __forceinline__ void cluster_bounds(const Geo &g, const double *dl, c
     ub[m] = -1e300;
     if (on && c < g.nclus) {
       const double dc = L.c[m][0] * dl[0] + L.c[m][1] * dl[1] + L.c[m][2] * dl[2];
-      ub[m] = dc + L.c[m][3] * dn;
+      // the tighter of two bounds: the enclosing sphere, and the box about the same centre (flat patches of the hull surface)
+      ub[m] = dc + fmin(L.c[m][3] * dn, L.c[m][4] * fabs(dl[0]) + L.c[m][5] * fabs(dl[1]) + L.c[m][6] * fabs(dl[2]));
       if (dc > best) { best = dc; top = c; }
     }
   }
@@ -1300,7 +1301,7 @@ __device__ __forceinline__ void view_geo(const Launch &P, int slot, Geo &o) {
   o.pos = &S.u.co.geo[slot][0]; o.mat = &S.u.co.geo[slot][3]; o.size = &S.u.co.geo[slot][12]; o.center = &S.u.co.geo[slot][15];
   o.vert = P.mesh_vert + 3 * (size_t)S.u.co.geoi[slot][3];
   o.oidx = P.mesh_oidx + S.u.co.geoi[slot][3];
-  o.clus = P.mesh_clus + 4 * (size_t)S.u.co.geoi[slot][4];
+  o.clus = P.mesh_clus + 8 * (size_t)S.u.co.geoi[slot][4];
 }
 
 __device__ __forceinline__ void make_frame(float *f) {   // [EXT] mju_makeFrame
@@ -2459,6 +2460,11 @@ static int g1_build_meshes(const DmModelG1 &m, g1::Dev &T, std::vector<double> &
       }
       for (int k = cnt; k < 64; k++) { verts.push_back(0); verts.push_back(0); verts.push_back(0); oidx.push_back(0x7fffffff); }
       clus.push_back(cc[0]); clus.push_back(cc[1]); clus.push_back(cc[2]); clus.push_back(rad * (1 + 1e-9) + 1e-12);
+      double hx[3] = {0, 0, 0};
+      for (int k = lf.first; k < lf.second; k++)
+        for (int i = 0; i < 3; i++) hx[i] = fmax(hx[i], fabs(m.mesh_vert[a0 + idx[k]][i] - cc[i]));
+      for (int i = 0; i < 3; i++) clus.push_back(hx[i] * (1 + 1e-9) + 1e-12);
+      clus.push_back(0.0);
     }
     const int nclus = (int)leaves.size();
     if (nclus > 64 * g1::NCH) return -1;
