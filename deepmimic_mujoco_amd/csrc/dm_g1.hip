@@ -2406,7 +2406,7 @@ static void g1_kd_split(const DmModelG1 &m, int a0, std::vector<int> &idx, int l
     for (int i = 0; i < 3; i++) { mn[i] = fmin(mn[i], m.mesh_vert[a0 + idx[k]][i]); mx[i] = fmax(mx[i], m.mesh_vert[a0 + idx[k]][i]); }
   int ax = 0;
   for (int i = 1; i < 3; i++) if (mx[i] - mn[i] > mx[ax] - mn[ax]) ax = i;
-  const int mid = (lo + hi) / 2;
+  const int half = (hi - lo) / 2, mid = lo + ((half + 63) / 64) * 64 < hi ? lo + ((half + 63) / 64) * 64 : (lo + hi) / 2;   // left side: full leaves
   std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi, [&](int p, int q) {
     const double vp = m.mesh_vert[a0 + p][ax], vq = m.mesh_vert[a0 + q][ax];
     return vp < vq || (vp == vq && p < q);
