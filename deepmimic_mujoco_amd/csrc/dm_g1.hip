@@ -571,13 +571,7 @@ __device__ __forceinline__ void drot_t(double *r, const double *m, const double 
 __device__ __forceinline__ double dclamp(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 __device__ __forceinline__ void dsub(double *r, const double *a, const double *b) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
 
-// Support vertices of up to two hulls at once, in local directions dlA / dlB.  The vertices are stored in clusters of 64
-// with a bounding sphere each.  Two dependent memory round trips for BOTH hulls together (the narrowphase is one wave's
-// latency chain, so round trips are what it costs): (1) every cluster's centre . d: the largest is a lower bound of the
-// support value (a cluster's centre is the mean of its vertices), centre . d + radius |d| an upper bound per cluster;
-// (2) all clusters whose upper bound reaches the lower bound are scanned, every lane keeping its own best — no cross-lane
-// step between the loads — and one wave reduction ends it.  Exact; equal support values resolve to the lowest ORIGINAL
-// vertex index, as a serial first-maximum scan would.
+// ---- support mapping of a hull (see mesh_support_pair below)
 // wave maximum of a double, uniform in every lane: four DPP steps inside each row of 16 lanes (both dwords moved with the same
 // control), then the four row maxima through v_readlane — ~25 instructions instead of six LDS-permute round trips
 template <int CTRL>
@@ -691,9 +685,9 @@ __device__ __forceinline__ void cluster_bounds(const Geo &g, const double *dl, c
   top = t;
 }
 // Support vertices of up to two hulls at once, in local directions dlA / dlB.  The vertices are stored in compact clusters
-// (k-d leaves, padded to 64 slots) with a bounding sphere each.  Three dependent memory round trips for BOTH hulls together
+// (k-d leaves, padded to 64 slots) with a bounding sphere and box each.  Three dependent memory round trips for BOTH hulls together
 // (the narrowphase is one wave's latency chain: round trips are what it costs; every load of a round is requested before the
-// first reduction of that round): (1) every cluster's centre . d and bound centre . d + radius |d|; (2) the cluster with
+// first reduction of that round): (1) every cluster's centre . d and bound centre . d + min(radius |d|, box term); (2) the cluster with
 // the largest centre . d is scanned: a true support value to prune with; (3) the clusters whose bound still reaches it are
 // scanned, four per trip, every lane keeping its own best and the vertex it belongs to, one wave reduction at the
 // end.  Exact; equal support values resolve to the lowest ORIGINAL vertex index, like a serial first-maximum scan.
@@ -2396,9 +2390,10 @@ static void g1_build_tables(const DmModelG1 &m, g1::Dev &T) {
   }
 }
 
-// Reorder every hull into compact clusters: a k-d partition (median split along the longest extent) down to leaves of at
-// most 64 vertices; a leaf occupies 64 vertex slots (unused slots carry the invalid original index 0x7fffffff) and has a
-// bounding sphere around the mean of its vertices.
+// Reorder every hull into compact clusters: a k-d partition along the longest extent, split so that the left side is a whole
+// number of 64-vertex leaves (every leaf but one per hull is full); a leaf occupies 64 vertex slots (unused slots carry the
+// invalid original index 0x7fffffff) and has two bounds: an enclosing sphere (centre shrunk from the mean of the vertices by
+// Badoiu-Clarkson steps) and a box about the same centre.
 static void g1_kd_split(const DmModelG1 &m, int a0, std::vector<int> &idx, int lo, int hi, std::vector<std::pair<int, int>> &leaves) {
   if (hi - lo <= 64) { leaves.push_back({lo, hi}); return; }
   double mn[3] = {1e30, 1e30, 1e30}, mx[3] = {-1e30, -1e30, -1e30};
