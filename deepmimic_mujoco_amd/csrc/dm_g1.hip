@@ -1587,13 +1587,43 @@ __device__ __noinline__ void project_constraint(const Dev &T, const float *JT, f
       const float nj = on ? -1.f / ajj : 0.f;
       if (on) BT[NV * MAXROW + j] = ajj;
       if (nchunk > 1) SYNC();
-      const int i0 = 64 * cj, i1 = (i0 + 64 < nefc) ? i0 + 64 : nefc;
-      for (int i = i0; i < i1; i++) {   // rows of the same chunk: broadcasts
-        const int l = i & 63;
-        float s0 = 0;
+      // rows of the same chunk: the 64 x 64 block B B^T on the matrix pipe — four 32 x 32 sub-blocks of v_mfma_f32_32x32x2f32
+      // over 22 k pairs.  The instruction wants lane (r, h) to supply B[row r][k0 + h]: one v_permlane32_swap of (x[k0], x[k0 + 1])
+      // yields the operand of rows 0..31 (lower half keeps x[k0], upper half receives the lower half's x[k0 + 1]) AND that of rows
+      // 32..63 (the other result).  88 MFMAs + 22 swaps instead of 64 x (43 v_readlane + 43 FMA).
+      {
+        typedef float f16v __attribute__((ext_vector_type(16)));
+        f16v acc00, acc01, acc10, acc11;
 #pragma unroll
-        for (int k = 0; k < NV; k++) s0 = fmaf(bcast(x[k], l), x[k], s0);
-        if (on) AR[i * MAXROW + j] = (i == j) ? -1.f : s0 * nj;
+        for (int v = 0; v < 16; v++) acc00[v] = acc01[v] = acc10[v] = acc11[v] = 0.f;
+        StaticFor<0, (NV + 1) / 2>::run([&](auto kc) {
+          constexpr int k0 = decltype(kc)::value * 2;
+          const float xa = x[k0], xb = (k0 + 1 < NV) ? x[k0 + 1 < NV ? k0 + 1 : 0] : 0.f;
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xa), __float_as_uint(xb), false, false);
+          const float op0 = __uint_as_float(sw[0]), op1 = __uint_as_float(sw[1]);
+          acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(op0, op0, acc00, 0, 0, 0);
+          acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(op0, op1, acc01, 0, 0, 0);
+          acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(op1, op0, acc10, 0, 0, 0);
+          acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(op1, op1, acc11, 0, 0, 0);
+          return true;
+        });
+        // result fragment: lane (c, h) holds D[row = 8 (v / 4) + 4 h + v % 4][col = c] of its sub-block; column j's scale
+        // -1 / A_jj lives in lane j: both halves fetched with one swap
+        const auto nsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(nj), __float_as_uint(nj), false, false);
+        const float n0 = __uint_as_float(nsw[0]), n1 = __uint_as_float(nsw[1]);   // of columns c and 32 + c
+        const int c = lane & 31, h = lane >> 5, base = 64 * cj;
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+          const int r = 8 * (v / 4) + 4 * h + (v % 4);
+#pragma unroll
+          for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+            for (int jb = 0; jb < 2; jb++) {
+              const int i = base + 32 * ib + r, jj = base + 32 * jb + c;
+              const float val = ib == 0 ? (jb == 0 ? acc00[v] : acc01[v]) : (jb == 0 ? acc10[v] : acc11[v]);
+              if (i < nefc && jj < nefc) AR[i * MAXROW + jj] = (i == jj) ? -1.f : val * (jb == 0 ? n0 : n1);
+            }
+        }
       }
       if (cj >= 1) {                    // cross blocks: rows of the earlier chunks (in the scratch) against this chunk's columns, both ways
         for (int i = 0; i < 64 * cj; i++) {
