@@ -1625,13 +1625,53 @@ __device__ __noinline__ void project_constraint(const Dev &T, const float *JT, f
             }
         }
       }
-      if (cj >= 1) {                    // cross blocks: rows of the earlier chunks (in the scratch) against this chunk's columns, both ways
-        for (int i = 0; i < 64 * cj; i++) {
-          float s0 = 0;
+      // cross blocks: an earlier chunk's rows (operand fragments loaded straight from the B^T scratch in the layout the
+      // instruction wants) against this chunk's, on the matrix pipe as well; pass 0 gives the block A[ci][cj], pass 1 its
+      // transpose A[cj][ci] with the operands exchanged, so both are stored with coalesced rows
+      for (int ci = 0; ci < cj; ci++) {
+        typedef float f16v __attribute__((ext_vector_type(16)));
+        const int c = lane & 31, h = lane >> 5;
+        const auto nsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(nj), __float_as_uint(nj), false, false);
+        const float ncj[2] = {__uint_as_float(nsw[0]), __uint_as_float(nsw[1])};          // columns of this chunk
+        const float nci[2] = {-1.f / BT[NV * MAXROW + 64 * ci + c], -1.f / BT[NV * MAXROW + 64 * ci + 32 + c]};   // of chunk ci (full)
 #pragma unroll
-          for (int k = 0; k < NV; k++) s0 = fmaf(BT[k * MAXROW + i], x[k], s0);
-          const float ni = -1.f / BT[NV * MAXROW + i];
-          if (on) { AR[i * MAXROW + j] = s0 * nj; AR[j * MAXROW + i] = s0 * ni; }
+        for (int pass = 0; pass < 2; pass++) {
+          f16v d00, d01, d10, d11;
+#pragma unroll
+          for (int v = 0; v < 16; v++) d00[v] = d01[v] = d10[v] = d11[v] = 0.f;
+          StaticFor<0, (NV + 1) / 2>::run([&](auto kc) {
+            constexpr int k0 = decltype(kc)::value * 2;
+            const float xa = x[k0], xb = (k0 + 1 < NV) ? x[k0 + 1 < NV ? k0 + 1 : 0] : 0.f;
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xa), __float_as_uint(xb), false, false);
+            const float oj0 = __uint_as_float(sw[0]), oj1 = __uint_as_float(sw[1]);
+            const bool kv = k0 + h < NV;
+            const float oi0 = kv ? BT[(k0 + h) * MAXROW + 64 * ci + c] : 0.f, oi1 = kv ? BT[(k0 + h) * MAXROW + 64 * ci + 32 + c] : 0.f;
+            if (pass == 0) {
+              d00 = __builtin_amdgcn_mfma_f32_32x32x2f32(oi0, oj0, d00, 0, 0, 0);
+              d01 = __builtin_amdgcn_mfma_f32_32x32x2f32(oi0, oj1, d01, 0, 0, 0);
+              d10 = __builtin_amdgcn_mfma_f32_32x32x2f32(oi1, oj0, d10, 0, 0, 0);
+              d11 = __builtin_amdgcn_mfma_f32_32x32x2f32(oi1, oj1, d11, 0, 0, 0);
+            } else {
+              d00 = __builtin_amdgcn_mfma_f32_32x32x2f32(oj0, oi0, d00, 0, 0, 0);
+              d01 = __builtin_amdgcn_mfma_f32_32x32x2f32(oj0, oi1, d01, 0, 0, 0);
+              d10 = __builtin_amdgcn_mfma_f32_32x32x2f32(oj1, oi0, d10, 0, 0, 0);
+              d11 = __builtin_amdgcn_mfma_f32_32x32x2f32(oj1, oi1, d11, 0, 0, 0);
+            }
+            return true;
+          });
+          const int rbase = 64 * (pass == 0 ? ci : cj), cbase = 64 * (pass == 0 ? cj : ci);
+#pragma unroll
+          for (int v = 0; v < 16; v++) {
+            const int r = 8 * (v / 4) + 4 * h + (v % 4);
+#pragma unroll
+            for (int a2 = 0; a2 < 2; a2++)
+#pragma unroll
+              for (int b2 = 0; b2 < 2; b2++) {
+                const int i = rbase + 32 * a2 + r, jj = cbase + 32 * b2 + c;
+                const float val = a2 == 0 ? (b2 == 0 ? d00[v] : d01[v]) : (b2 == 0 ? d10[v] : d11[v]);
+                if (i < nefc && jj < nefc) AR[i * MAXROW + jj] = val * (pass == 0 ? ncj[b2] : nci[b2]);
+              }
+          }
         }
       }
     }
