@@ -66,11 +66,16 @@ struct Dev {   // read-only model tables (global memory, fp32)
   double m_center[32][3];
   uint8_t tri_a[128], tri_b[128];
   uint32_t f_tgt[44][64];   // factorisation step k, ancestor pairs p = lane (low half) and lane + 64 (high half): the qLD entry updated
+  // fp64 copies of everything the pose chain of a body and the narrowphase read: the narrowphase is fp64, and so are its inputs
+  // (a convex-convex contact normal depends discontinuously on the poses; fp32 poses moved it in ~3 % of thrashing env-steps)
+  double timestep_d, qpos0_d[NQ], b_pos_d[40][3], b_quat_d[40][4], d_axis_d[44][3], g_pos_d[96][3], g_mat_d[96][9], g_size_d[96][3];
 };
 
 struct Lds {   // per-env working set (one wave): 19.2 KB, eight waves per CU
   float qpos[NQ], qvel[44], warm[44], ctrl[40];
   float xpos[40][3], xquat[40][4], xmat[40][9], xipos[40][3];
+  float xpos_lo[40][3], xquat_lo[40][4];   // body pose in fp64 = (double)x + (double)x_lo: the fp32 consumers read the rounded value
+  float x0q_lo[4];                         // the same for the normalised root quaternion the RK stages start from
   float xaxis[44][3];
   float gpos[96][3], gmat[NCG][9];   // rotation only of the geoms that collide (Dev::g_ci)
   float com[4];
@@ -97,6 +102,10 @@ struct Lds {   // per-env working set (one wave): 19.2 KB, eight waves per CU
       double poly[2][16][3]; // box-box polygons
       double mpr_ps[4][9];   // MPR portal (v0..v3: v, v1, v2): wave-uniform state, 72 VGPRs if kept per lane
     } co;
+    struct {   // low words of the RK stage's qpos: written by integrate_pos, read at the top of kinematics — between two evaluations,
+      char skip[5680];   // when `sm` is dead; placed behind the end of `co` (the last contacts stay readable for the observation)
+      float qlo[NQ];
+    } rk;
   } u;
 };
 
@@ -104,6 +113,8 @@ struct Lds {   // per-env working set (one wave): 19.2 KB, eight waves per CU
 // register allocation, and all of them address it as LDS (ds_* instructions), not through generic pointers.
 __shared__ Lds g_S;
 #define S g_S
+static_assert(sizeof(Lds) <= 20480, "eight waves per CU need <= 20 480 B of LDS per env");
+static_assert(sizeof(((Lds *)0)->u.co) <= 5680 && sizeof(((Lds *)0)->u.rk) <= sizeof(((Lds *)0)->u.sm), "rk.qlo sits behind co, inside sm");
 
 struct ClipDev {
   const float *rows;    // L x CLIP_ROW
@@ -234,50 +245,90 @@ __device__ __host__ __forceinline__ uint32_t hash32(uint64_t seed, uint32_t env,
 #endif
 
 // ------------------------------------------------------------------------------------------ position stage
-__device__ __noinline__ void kinematics(const Dev &T, const int lane) {   // [EXT] mj_kinematics
+// fp64 helpers of the pose chain
+__device__ __forceinline__ void dquat_mul(double *r, const double *a, const double *b) {
+  const double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  const double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  const double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  const double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+__device__ __forceinline__ void dquat2mat(double *m, const double *q) {
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+__device__ __forceinline__ void dquat_normalize(double *q) {
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; }
+  else { q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n; }
+}
+__device__ __forceinline__ void split_hi_lo(const double x, float &hi, float &lo) { hi = (float)x; lo = (float)(x - (double)hi); }
+
+// [EXT] mj_kinematics.  The pose chain (xpos, xquat) runs in fp64 and is kept as (fp32 value, fp32 remainder): the narrowphase
+// is fp64 and takes its geom poses from it (stage_geo); everything else reads the rounded fp32 arrays.  `qlo`: the evaluation
+// belongs to RK stage 2..4, whose qpos carries low words (integrate_pos).
+__device__ __noinline__ void kinematics(const Dev &T, const int lane, const bool qlo) {
   if (lane == 0) {
     S.xpos[0][0] = S.xpos[0][1] = S.xpos[0][2] = 0;
     S.xquat[0][0] = 1; S.xquat[0][1] = S.xquat[0][2] = S.xquat[0][3] = 0;
+    for (int i = 0; i < 3; i++) S.xpos_lo[0][i] = 0;
+    for (int i = 0; i < 4; i++) S.xquat_lo[0][i] = 0;
     for (int i = 0; i < 9; i++) S.xmat[0][i] = (i % 4 == 0) ? 1.f : 0.f;
     S.xipos[0][0] = S.xipos[0][1] = S.xipos[0][2] = 0;
+  }
+  // the body's own joint rotation, all bodies at once (one fp64 sincos per lane, outside the level loop)
+  double ql[4] = {1, 0, 0, 0}, rq[4] = {1, 0, 0, 0}, rp[3] = {0, 0, 0};
+  if (lane >= 2 && lane < NB) {
+    const int k = T.b_dof[lane];   // the body's single hinge; joint anchor = body origin
+    const double ang = ((double)S.qpos[k + 1] + (qlo ? (double)S.u.rk.qlo[k + 1] : 0.0)) - T.qpos0_d[k + 1];
+    double sn, cs;
+    sincos(0.5 * ang, &sn, &cs);
+    ql[0] = cs; ql[1] = T.d_axis_d[k][0] * sn; ql[2] = T.d_axis_d[k][1] * sn; ql[3] = T.d_axis_d[k][2] * sn;
+  } else if (lane == 1) {   // free root: MuJoCo normalises the stored quaternion in place
+    for (int i = 0; i < 4; i++) rq[i] = (double)S.qpos[3 + i] + (qlo ? (double)S.u.rk.qlo[3 + i] : 0.0);
+    for (int i = 0; i < 3; i++) rp[i] = (double)S.qpos[i] + (qlo ? (double)S.u.rk.qlo[i] : 0.0);
+    dquat_normalize(rq);
   }
   SYNC();
   for (int L = 1; L <= T.maxdepth; L++) {
     if (lane >= 1 && lane < NB && T.b_depth[lane] == L) {
       const int b = lane, p = T.b_parent[b];
-      float pos[3], q[4];
-      if (b == 1) {   // free root: MuJoCo normalises the stored quaternion in place
-        float qq[4] = {S.qpos[3], S.qpos[4], S.qpos[5], S.qpos[6]};
-        quat_normalize(qq);
-        for (int i = 0; i < 4; i++) { S.qpos[3 + i] = qq[i]; q[i] = qq[i]; }
-        for (int i = 0; i < 3; i++) pos[i] = S.qpos[i];
+      double pos[3], q[4];
+      if (b == 1) {
+        for (int i = 0; i < 4; i++) {   // x0q_lo: low words of the quaternion the RK stages start from (stage 1 only)
+          float hi, l;
+          split_hi_lo(rq[i], hi, l);
+          q[i] = rq[i]; S.qpos[3 + i] = hi;
+          if (!qlo) S.x0q_lo[i] = l;
+        }
+        for (int i = 0; i < 3; i++) pos[i] = rp[i];
       } else {
-        float t[3], bp[3] = {T.b_pos[b][0], T.b_pos[b][1], T.b_pos[b][2]};
-        mat_vec(t, S.xmat[p], bp);
-        for (int i = 0; i < 3; i++) pos[i] = S.xpos[p][i] + t[i];
-        float pq[4] = {S.xquat[p][0], S.xquat[p][1], S.xquat[p][2], S.xquat[p][3]};
-        float bq[4] = {T.b_quat[b][0], T.b_quat[b][1], T.b_quat[b][2], T.b_quat[b][3]};
-        quat_mul(q, pq, bq);
-        const int k = T.b_dof[b];   // the body's single hinge; joint anchor = body origin
-        float ax[3] = {T.d_axis[k][0], T.d_axis[k][1], T.d_axis[k][2]}, wa[3];
-        quat_rot(wa, q, ax);
-        for (int i = 0; i < 3; i++) S.xaxis[k][i] = wa[i];
-        const float ang = S.qpos[k + 1] - T.qpos0[k + 1];
-        float sn, cs;
-        sincosf(0.5f * ang, &sn, &cs);
-        float ql[4] = {cs, ax[0] * sn, ax[1] * sn, ax[2] * sn}, qn[4];
-        quat_mul(qn, q, ql);
+        double pq[4], pm[9];
+        for (int i = 0; i < 4; i++) pq[i] = (double)S.xquat[p][i] + (double)S.xquat_lo[p][i];
+        dquat2mat(pm, pq);
+        for (int i = 0; i < 3; i++)
+          pos[i] = ((double)S.xpos[p][i] + (double)S.xpos_lo[p][i]) +
+                   (pm[3 * i] * T.b_pos_d[b][0] + pm[3 * i + 1] * T.b_pos_d[b][1] + pm[3 * i + 2] * T.b_pos_d[b][2]);
+        dquat_mul(q, pq, T.b_quat_d[b]);
+        const int k = T.b_dof[b];
+        double qm[9];
+        dquat2mat(qm, q);
+        for (int i = 0; i < 3; i++)
+          S.xaxis[k][i] = (float)(qm[3 * i] * T.d_axis_d[k][0] + qm[3 * i + 1] * T.d_axis_d[k][1] + qm[3 * i + 2] * T.d_axis_d[k][2]);
+        double qn[4];
+        dquat_mul(qn, q, ql);
         for (int i = 0; i < 4; i++) q[i] = qn[i];
       }
-      quat_normalize(q);
-      float m[9];
-      quat2mat(m, q);
-      for (int i = 0; i < 3; i++) S.xpos[b][i] = pos[i];
-      for (int i = 0; i < 4; i++) S.xquat[b][i] = q[i];
-      for (int i = 0; i < 9; i++) S.xmat[b][i] = m[i];
-      float ip[3] = {T.b_ipos[b][0], T.b_ipos[b][1], T.b_ipos[b][2]}, t[3];
-      mat_vec(t, m, ip);
-      for (int i = 0; i < 3; i++) S.xipos[b][i] = pos[i] + t[i];
+      dquat_normalize(q);
+      double m[9];
+      dquat2mat(m, q);
+      for (int i = 0; i < 3; i++) split_hi_lo(pos[i], S.xpos[b][i], S.xpos_lo[b][i]);
+      for (int i = 0; i < 4; i++) split_hi_lo(q[i], S.xquat[b][i], S.xquat_lo[b][i]);
+      for (int i = 0; i < 9; i++) S.xmat[b][i] = (float)m[i];
+      for (int i = 0; i < 3; i++)
+        S.xipos[b][i] = (float)(pos[i] + ((double)T.b_ipos[b][0] * m[3 * i] + (double)T.b_ipos[b][1] * m[3 * i + 1] + (double)T.b_ipos[b][2] * m[3 * i + 2]));
     }
     SYNC();
   }
@@ -591,7 +642,12 @@ __device__ __forceinline__ double wmax_f64(double v) {
   return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 constexpr int NCH = 2;            // cluster chunks of 64 per hull: hulls of up to 128 clusters (checked at create)
-struct MeshPick { double best, x, y, z; int bo, bk; };
+// Support ties (oracle/dm_convex.h "ties"): MPR queries a hull along its portal normal, in which two hull vertices tie EXACTLY by
+// construction at every edge-edge / face-vertex contact; "first strict maximum" is then decided by the last bit of two dot
+// products and ends in a different contact normal.  Rule (both sides): values within SUP_TIE of the maximum are tied, the
+// lowest ORIGINAL vertex index wins.  A lane keeps its best value and the lowest-index vertex within SUP_TIE of it.
+constexpr double SUP_TIE = 1e-12;
+struct MeshPick { double best, cv, x, y, z; int bo, bk; };   // best value | candidate: value, vertex, original index, slot
 // every lane scans vertex `lane` of up to four clusters of hull A and four of hull B (-1: none): sixteen independent loads in
 // one round trip, no cross-lane step; the pick keeps the vertex itself, so no fetch follows the reduction
 struct Scan4 { double x[4], y[4], z[4]; int o[4]; };
@@ -609,16 +665,20 @@ __device__ __forceinline__ void scan4_pick(const double *dl, const int (&c)[4], 
   for (int q = 0; q < 4; q++)
     if (v.o[q] != 0x7fffffff) {
       const double sv = v.x[q] * dl[0] + v.y[q] * dl[1] + v.z[q] * dl[2];
-      if (sv > p.best || (sv == p.best && v.o[q] < p.bo)) { p.best = sv; p.bo = v.o[q]; p.bk = 64 * c[q] + lane;
+      const bool up = sv > p.best;
+      // new candidate: a new best whose window the old candidate left (or that has the lower index), or a lower index inside the window
+      if (up ? (!(p.cv >= sv - SUP_TIE) || v.o[q] < p.bo) : (sv >= p.best - SUP_TIE && v.o[q] < p.bo)) {
+        p.cv = sv; p.bo = v.o[q]; p.bk = 64 * c[q] + lane;
         p.x = v.x[q]; p.y = v.y[q]; p.z = v.z[q];
       }
+      if (up) p.best = sv;
     }
 }
 // the lanes' picks -> the wave's pick: the maximum value, and among equal values the lowest original index (one lane in all
 // but degenerate cases: a ballot and v_readlanes; ties walk the tied lanes)
 __device__ __forceinline__ void wave_pick(MeshPick &p) {
   const double vmax = wmax_f64(p.best);
-  unsigned long long eq = __ballot(p.best == vmax);
+  unsigned long long eq = __ballot(p.cv >= vmax - SUP_TIE);   // never empty: the lane that holds the maximum has best - SUP_TIE <= cv <= best
   int l = __ffsll((long long)eq) - 1;
   int bo = __builtin_amdgcn_readlane(p.bo, l);
   eq &= eq - 1;
@@ -700,7 +760,7 @@ __device__ __forceinline__ void mesh_support_pair(const Geo &A, const double *dl
     cluster_load(B, meshB, LB, lane);
     cluster_bounds(A, dlA, meshA, LA, ubA, topA, lane);
     cluster_bounds(B, dlB, meshB, LB, ubB, topB, lane); }
-  pa = {-1e300, 0.0, 0.0, 0.0, 0x7fffffff, 0};
+  pa = {-1e300, -1e300, 0.0, 0.0, 0.0, 0x7fffffff, 0};
   pb = pa;
   { const int ca[4] = {meshA ? topA : -1, -1, -1, -1}, cb[4] = {meshB ? topB : -1, -1, -1, -1};
     Scan4 va, vb;
@@ -712,8 +772,8 @@ __device__ __forceinline__ void mesh_support_pair(const Geo &A, const double *dl
   unsigned long long todoA[NCH], todoB[NCH];
 #pragma unroll
   for (int m = 0; m < NCH; m++) {
-    todoA[m] = meshA ? __ballot(ubA[m] >= ba && (lane + 64 * m) != topA) : 0ull;
-    todoB[m] = meshB ? __ballot(ubB[m] >= bb && (lane + 64 * m) != topB) : 0ull;
+    todoA[m] = meshA ? __ballot(ubA[m] >= ba - SUP_TIE && (lane + 64 * m) != topA) : 0ull;
+    todoB[m] = meshB ? __ballot(ubB[m] >= bb - SUP_TIE && (lane + 64 * m) != topB) : 0ull;
   }
   // (both hulls' candidates in ONE loop — eight clusters per trip — measured slower: 34 more live doubles spill)
   for (;;) {
@@ -748,9 +808,9 @@ __device__ __forceinline__ void support_local(const Geo &g, const double *dl, do
   } else if (g.type == DM_GEOM_CYLINDER) {
     const double n = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
     if (n > MINVAL) { p[0] = dl[0] * g.size[0] / n; p[1] = dl[1] * g.size[0] / n; }
-    p[2] = dl[2] >= 0 ? g.size[1] : -g.size[1];
+    p[2] = dl[2] * g.size[1] >= -0.5 * SUP_TIE ? g.size[1] : -g.size[1];
   } else if (g.type == DM_GEOM_BOX) {
-    for (int i = 0; i < 3; i++) p[i] = dl[i] >= 0 ? g.size[i] : -g.size[i];
+    for (int i = 0; i < 3; i++) p[i] = dl[i] * g.size[i] >= -0.5 * SUP_TIE ? g.size[i] : -g.size[i];
   }
 }
 
@@ -1269,21 +1329,31 @@ __device__ __noinline__ int np_box_box(Con *c, const Geo &A, const Geo &Bx, doub
   return cnt;
 }
 
-// stage geom g of the current pair in LDS slot `slot` (lanes 0..17 write one double each)
+// stage geom g of the current pair in LDS slot `slot` (lanes 0..17 write one double each): the geom's pose in fp64 from the
+// fp64 pose of its body (kinematics) and the fp64 model tables
 __device__ __forceinline__ void stage_geo(const Dev &T, int g, int slot, const int lane) {
-  const int type = T.g_type[g], me = T.g_mesh[g];
+  const int type = T.g_type[g], me = T.g_mesh[g], b = T.g_body[g];
   double v = 0;
-  if (lane < 3) v = S.gpos[g][lane];
-  else if (lane < 12) v = S.gmat[T.g_ci[g]][lane - 3];
-  else if (lane < 15) v = T.g_size[g][lane - 12];
-  else if (lane < 18) {
-    const int i = lane - 15;
-    v = S.gpos[g][i];
-    if (type == DM_GEOM_MESH)
-      v += (double)S.gmat[T.g_ci[g]][3 * i] * T.m_center[me][0] + (double)S.gmat[T.g_ci[g]][3 * i + 1] * T.m_center[me][1] +
-           (double)S.gmat[T.g_ci[g]][3 * i + 2] * T.m_center[me][2];
+  if (lane < 18) {
+    double bq[4], R[9];
+    for (int i = 0; i < 4; i++) bq[i] = (double)S.xquat[b][i] + (double)S.xquat_lo[b][i];
+    dquat2mat(R, bq);
+    if (lane >= 12 && lane < 15) v = T.g_size_d[g][lane - 12];
+    else if (lane >= 3 && lane < 12) {
+      const int i = (lane - 3) / 3, j = (lane - 3) % 3;
+      v = R[3 * i] * T.g_mat_d[g][j] + R[3 * i + 1] * T.g_mat_d[g][3 + j] + R[3 * i + 2] * T.g_mat_d[g][6 + j];
+    } else {
+      const int i = lane < 3 ? lane : lane - 15;
+      v = ((double)S.xpos[b][i] + (double)S.xpos_lo[b][i]) +
+          (R[3 * i] * T.g_pos_d[g][0] + R[3 * i + 1] * T.g_pos_d[g][1] + R[3 * i + 2] * T.g_pos_d[g][2]);
+      if (lane >= 15 && type == DM_GEOM_MESH) {
+        double gm[3];
+        for (int j = 0; j < 3; j++) gm[j] = R[3 * i] * T.g_mat_d[g][j] + R[3 * i + 1] * T.g_mat_d[g][3 + j] + R[3 * i + 2] * T.g_mat_d[g][6 + j];
+        v += gm[0] * T.m_center[me][0] + gm[1] * T.m_center[me][1] + gm[2] * T.m_center[me][2];
+      }
+    }
+    S.u.co.geo[slot][lane] = v;
   }
-  if (lane < 18) S.u.co.geo[slot][lane] = v;
   if (lane == 0) {
     const bool mesh = type == DM_GEOM_MESH;
     S.u.co.geoi[slot][0] = type; S.u.co.geoi[slot][1] = mesh ? T.m_vnum[me] : 0; S.u.co.geoi[slot][2] = mesh ? T.m_cnum[me] : 0;
@@ -1928,11 +1998,11 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
   SYNC();
 }
 
-__device__ __noinline__ void forward(const Launch &P, const Dev &T, const int env, const int lane) {
+__device__ __noinline__ void forward(const Launch &P, const Dev &T, const int env, const int lane, const bool qlo) {
   float *JT = P.jt + (size_t)env * 44 * MAXROW, *BT = P.bt + (size_t)env * 44 * MAXROW, *AR = P.ar + (size_t)env * MAXROW * MAXROW;
   float *RW = P.rows + (size_t)env * 5 * MAXROW;
   PROF(15);
-  kinematics(T, lane);
+  kinematics(T, lane, qlo);
   com_pos(T, lane);
   PROF(0);
   crb_factor(T, lane);
@@ -1954,22 +2024,41 @@ __device__ __noinline__ void forward(const Launch &P, const Dev &T, const int en
   PROF(10);
 }
 
-__device__ void integrate_pos(const float *q0, const float *vel, const float h, const int lane) {   // [EXT] mj_integratePos
+// [EXT] mj_integratePos from the step's start state x0q (+ the low words of its normalised root quaternion), in fp64.  `lo`: keep
+// the low words of the result for the next evaluation's pose chain (RK stages 2..4); the step's final state is the rounded value.
+__device__ void integrate_pos(const Dev &T, const float *vel, const double a, const bool lo, const int lane) {
+  const double h = a * T.timestep_d;
   if (lane == 0) {
-    for (int i = 0; i < 3; i++) S.qpos[i] = q0[i] + h * vel[i];
-    float w[3] = {vel[3], vel[4], vel[5]};
-    float n = sqrtf(dot3(w, w));
-    if (n < MINVALF) { w[0] = 1; w[1] = w[2] = 0; } else { w[0] /= n; w[1] /= n; w[2] /= n; }
-    const float ang = h * n;
-    float sn, cs;
-    sincosf(0.5f * ang, &sn, &cs);
-    float qr[4] = {cs, w[0] * sn, w[1] * sn, w[2] * sn}, qo[4] = {q0[3], q0[4], q0[5], q0[6]}, qn[4];
-    quat_normalize(qo);
-    quat_mul(qn, qo, qr);
-    quat_normalize(qn);
-    for (int i = 0; i < 4; i++) S.qpos[3 + i] = qn[i];
+    for (int i = 0; i < 3; i++) {
+      float hi, l;
+      split_hi_lo((double)S.x0q[i] + h * (double)vel[i], hi, l);
+      S.qpos[i] = hi;
+      if (lo) S.u.rk.qlo[i] = l;
+    }
+    double w[3] = {(double)vel[3], (double)vel[4], (double)vel[5]};
+    double n = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    if (n < MINVAL) { w[0] = 1; w[1] = w[2] = 0; n = 0; } else { w[0] /= n; w[1] /= n; w[2] /= n; }
+    const double ang = h * n;
+    double sn, cs;
+    sincos(0.5 * ang, &sn, &cs);
+    double qr[4] = {cs, w[0] * sn, w[1] * sn, w[2] * sn}, qo[4], qn[4];
+    for (int i = 0; i < 4; i++) qo[i] = (double)S.x0q[3 + i] + (double)S.x0q_lo[i];
+    dquat_normalize(qo);
+    dquat_mul(qn, qo, qr);
+    dquat_normalize(qn);
+    for (int i = 0; i < 4; i++) {
+      float hi, l;
+      split_hi_lo(qn[i], hi, l);
+      S.qpos[3 + i] = hi;
+      if (lo) S.u.rk.qlo[3 + i] = l;
+    }
   }
-  if (lane >= 6 && lane < NV) S.qpos[lane + 1] = q0[lane + 1] + h * vel[lane];
+  if (lane >= 6 && lane < NV) {
+    float hi, l;
+    split_hi_lo((double)S.x0q[lane + 1] + h * (double)vel[lane], hi, l);
+    S.qpos[lane + 1] = hi;
+    if (lo) S.u.rk.qlo[lane + 1] = l;
+  }
 }
 
 extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
@@ -2048,11 +2137,16 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
   int stage = 0;   // RK4 stage of the evaluation about to run (MODE_STEP); every other mode runs one evaluation
   for (;;) {
     if (!sim_err) {
-      forward(P, T, env, lane);   // the only call site: the evaluation is ~20 k instructions
+      forward(P, T, env, lane, mode == MODE_STEP && !after_reset && stage > 0);   // the only call site: the evaluation is ~20 k instructions
       work += 4000 + S.info[1] * (8 + 6 * S.info[3]) + 3000 * ((S.info[6] >> 16) & 0xFF);   // fixed part, rows x sweeps, MPR pairs
       if (mode == MODE_STEP && !after_reset) {   // [EXT] mj_step with mj_RungeKutta(4): A = (1/2, 1/2, 1), B = (1/6, 1/3, 1/3, 1/6)
         const float Bw = (stage == 0 || stage == 3) ? 1.f / 6 : 1.f / 3;
         stage_ncon |= ((unsigned)S.info[0] & 0xFF) << (8 * stage); stage_nefc_lo |= ((unsigned)S.info[1] & 0xFF) << (8 * stage);
+        if (P.debug) {   // 24-bit hash of the stage's contact list (geom pairs in order): the parity tests hold the index SETS bit-exact
+          unsigned hsh = 0;
+          for (int c = 0; c < S.info[0]; c++) hsh = (hsh * 131u + (unsigned)S.u.co.c_g1[c] * 97u + (unsigned)S.u.co.c_g2[c] + 1u) & 0xFFFFFFu;
+          if (lane == 0) P.debug[(size_t)env * DMG1_DEBUG_STRIDE + 1012 + stage] = (float)hsh;
+        }
         if (stage == 0) {
           const bool badv = (lane < NV) && !(fabsf(S.qacc[lane]) <= MAXVALF);   // mj_checkAcc
           sim_err = __any(badv);
@@ -2072,14 +2166,14 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
           if (stage < 3) {
             if (lane < NV) S.tmp[lane] = dq;
             SYNC();
-            integrate_pos(S.x0q, S.tmp, h, lane);
+            integrate_pos(T, S.tmp, 1.0, true, lane);
             if (lane < NV) S.qvel[lane] = S.x0v[lane] + h * dv;
             SYNC();
             stage++;
             continue;
           }
           if (lane < NV) S.qvel[lane] = S.x0v[lane] + h * S.accv[lane];
-          integrate_pos(S.x0q, S.accq, h, lane);
+          integrate_pos(T, S.accq, 1.0, false, lane);
           SYNC();
         }
       } else if (mode == MODE_FORCED && !after_reset) {
@@ -2378,13 +2472,15 @@ static void g1_build_tables(const DmModelG1 &m, g1::Dev &T) {
   for (int i = 0; i < 4; i++) T.ee_geom[i] = m.ee_geom[i];
   for (int i = 0; i < 8; i++) T.extra_geom[i] = m.extra_geom[i];
   for (int i = 0; i < NREW; i++) { T.rew_q[i] = m.rew_qposadr[i]; T.rew_v[i] = m.rew_dofadr[i]; T.rew_j[i] = m.rew_jnt[i]; }
-  for (int i = 0; i < NQ; i++) T.qpos0[i] = (float)m.qpos0[i];
+  for (int i = 0; i < NQ; i++) { T.qpos0[i] = (float)m.qpos0[i]; T.qpos0_d[i] = m.qpos0[i]; }
+  T.timestep_d = m.timestep;
   int maxd = 0;
   for (int b = 0; b < NB; b++) {
     T.b_parent[b] = m.body_parent[b]; T.b_depth[b] = m.body_depth[b]; T.b_dof[b] = m.body_dofadr[b];
     if (m.body_depth[b] > maxd) maxd = m.body_depth[b];
     for (int i = 0; i < 3; i++) { T.b_pos[b][i] = (float)m.body_pos[b][i]; T.b_ipos[b][i] = (float)m.body_ipos[b][i]; }
-    for (int i = 0; i < 4; i++) T.b_quat[b][i] = (float)m.body_quat[b][i];
+    for (int i = 0; i < 4; i++) { T.b_quat[b][i] = (float)m.body_quat[b][i]; T.b_quat_d[b][i] = m.body_quat[b][i]; }
+    for (int i = 0; i < 3; i++) T.b_pos_d[b][i] = m.body_pos[b][i];
     for (int i = 0; i < 6; i++) T.b_inertia[b][i] = (float)m.body_inertia[b][i];
     T.b_mass[b] = (float)m.body_mass[b]; T.b_invw[b] = (float)m.body_invweight0[b][0];
   }
@@ -2397,7 +2493,7 @@ static void g1_build_tables(const DmModelG1 &m, g1::Dev &T) {
     for (int j = m.dof_parent[k]; j >= 0; j = m.dof_parent[j]) T.d_anc[k][n++] = (uint8_t)j;
     T.d_nanc[k] = n;
     const int j = m.dof_jnt[k];
-    for (int i = 0; i < 3; i++) T.d_axis[k][i] = (float)m.jnt_axis[j][i];
+    for (int i = 0; i < 3; i++) { T.d_axis[k][i] = (float)m.jnt_axis[j][i]; T.d_axis_d[k][i] = m.jnt_axis[j][i]; }
     T.d_arm[k] = (float)m.dof_armature[k]; T.d_damp[k] = (float)m.dof_damping[k]; T.d_invw[k] = (float)m.dof_invweight0[k];
     T.d_floss[k] = (float)m.dof_frictionloss[k];
     T.d_lo[k] = (float)m.jnt_range[j][0]; T.d_hi[k] = (float)m.jnt_range[j][1];
@@ -2413,13 +2509,16 @@ static void g1_build_tables(const DmModelG1 &m, g1::Dev &T) {
   }
   for (int g = 0; g < NG; g++) {
     T.g_body[g] = m.geom_body[g]; T.g_type[g] = m.geom_type[g]; T.g_mesh[g] = m.geom_mesh[g];
-    for (int i = 0; i < 3; i++) { T.g_pos[g][i] = (float)m.geom_pos[g][i]; T.g_size[g][i] = (float)m.geom_size[g][i]; }
+    for (int i = 0; i < 3; i++) {
+      T.g_pos[g][i] = (float)m.geom_pos[g][i]; T.g_size[g][i] = (float)m.geom_size[g][i];
+      T.g_pos_d[g][i] = m.geom_pos[g][i]; T.g_size_d[g][i] = m.geom_size[g][i];
+    }
     const double *q = m.geom_quat[g];
     const double w = q[0], x = q[1], y = q[2], z = q[3];
     const double M[9] = {w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y),
                          2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x),
                          2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z};
-    for (int i = 0; i < 9; i++) T.g_mat[g][i] = (float)M[i];
+    for (int i = 0; i < 9; i++) { T.g_mat[g][i] = (float)M[i]; T.g_mat_d[g][i] = M[i]; }
     T.g_rbound[g] = (float)m.geom_rbound[g]; T.g_mu[g] = (float)m.geom_friction[g][0];
     const double *zs = m.geom_size[g];
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};

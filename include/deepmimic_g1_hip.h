@@ -94,7 +94,9 @@ int dmg1_set_motion(DmG1Handle h, const int32_t *motion, void *stream);
 
 /* Parity-test hook: per-env dump of the last forward evaluation, float[N*DMG1_DEBUG_STRIDE] (NULL switches it off):
  *  [0:117) xpos | [117:160) qacc_smooth | [160:203) qacc | 203 ncon | 204 nefc | 205 solver_iter | 206 nlimit | 207 overflow |
- *  [208:208+48*9) per contact: dist, geom1, geom2, pos3, normal3 | [640:640+256) efc_force */
+ *  [208:208+48*9) per contact: dist, geom1, geom2, pos3, normal3 | [640:640+256) efc_force |
+ *  after a step, per RK stage k = 0..3: 1000+k contacts, 1004+k rows (low byte), 1012+k a 24-bit hash of the stage's contact
+ *  list h <- (131 h + 97 geom1 + geom2 + 1) mod 2^24 (the oracle keeps the same: "stage_chash<k>") */
 int dmg1_set_debug(DmG1Handle h, float *debug);
 
 /* Kernel time of the last dmg1_step in ms (HIP events on the launch stream), or < 0. */

@@ -9,6 +9,18 @@
  * and the two plane routines the G1 model needs (mjc_PlaneCylinder, mjc_PlaneConvex for a mesh).
  * PARITY UNPINNED: nothing in the reference tree holds a golden contact; tests check it against the analytic
  * primitive routines of dm_oracle.c on penetrating pairs and against geometric invariants.
+ *
+ * Ties (the one deliberate deviation from the literal routine, TW.support_tie = 1e-12; 0 restores the literal scan).
+ * MPR queries a hull in the normal direction of its current portal.  Whenever two portal vertices a_i - b, a_j - b share
+ * the witness b on one shape (every edge-edge and face-vertex contact reaches that state), a_i and a_j have EXACTLY the
+ * same support value in that direction by construction, so libccd's "first strict maximum" is decided by the last bit of
+ * two dot products — and the two choices end in different final portals, whose closest points to the origin differ in
+ * depth by percents and in direction in the second digit.  Measured on this oracle alone (tests/test_g1_oracle.py): the
+ * contact normal of a hand-on-hip pose of the walk clip flips between two values under 1e-15 perturbations of qpos, in
+ * half of the trials.  Real MuJoCo makes that choice by the rounding of its own build, so neither value is "MuJoCo's";
+ * a parity check against ANY second implementation needs a rule that does not depend on the last bit: support values
+ * within 1e-12 m of the maximum are tied and the lowest vertex index wins (box corners / cylinder caps: the positive
+ * side).  The HIP engine applies the same rule (csrc/dm_g1.hip: scan4_pick / wave_pick / support_local).
  */
 #ifndef DM_CONVEX_H
 #define DM_CONVEX_H
@@ -24,6 +36,21 @@ typedef struct CvxGeom {
   int nvert;
   double center[3];               /* world interior point (geom centre; hull centroid for a mesh) */
 } CvxGeom;
+
+/* support vertex of a hull in the local direction dl: the first strict maximum ([EXT] mjc_MeshSupport without the hill-climb
+ * graph), then — see "ties" above — the lowest index among the vertices within TW.support_tie of it */
+static int mesh_support_index(const double *vert, int nvert, const double *dl) {
+  int best = 0;
+  double bd = -1e300;
+  for (int k = 0; k < nvert; k++) {
+    double s = dot3(vert + 3 * k, dl);
+    if (s > bd) { bd = s; best = k; }
+  }
+  if (TW.support_tie > 0)
+    for (int k = 0; k < best; k++)
+      if (dot3(vert + 3 * k, dl) >= bd - TW.support_tie) return k;
+  return best;
+}
 
 static void cvx_support(const CvxGeom *g, const double *dir, double *out) { /* [EXT] mjccd_support */
   double dl[3], p[3] = {0, 0, 0};
@@ -43,19 +70,14 @@ static void cvx_support(const CvxGeom *g, const double *dir, double *out) { /* [
     case DM_GEOM_CYLINDER: {
       double n = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
       if (n > MINVAL) { p[0] = dl[0] * g->size[0] / n; p[1] = dl[1] * g->size[0] / n; }
-      p[2] = dl[2] >= 0 ? g->size[1] : -g->size[1];
+      p[2] = dl[2] * g->size[1] >= -0.5 * TW.support_tie ? g->size[1] : -g->size[1];   /* the two caps differ by 2 dl_z size */
       break;
     }
     case DM_GEOM_BOX:
-      for (int i = 0; i < 3; i++) p[i] = dl[i] >= 0 ? g->size[i] : -g->size[i];
+      for (int i = 0; i < 3; i++) p[i] = dl[i] * g->size[i] >= -0.5 * TW.support_tie ? g->size[i] : -g->size[i];
       break;
     case DM_GEOM_MESH: {
-      int best = 0;
-      double bd = -1e300;
-      for (int k = 0; k < g->nvert; k++) {
-        double s = dot3(g->vert + 3 * k, dl);
-        if (s > bd) { bd = s; best = k; }
-      }
+      int best = mesh_support_index(g->vert, g->nvert, dl);
       memcpy(p, g->vert + 3 * best, sizeof p);
       break;
     }
@@ -331,15 +353,6 @@ static int c_plane_cylinder(RawCon *c, double margin, const double *ppos, const 
 /* [EXT] mjc_PlaneConvex for a mesh: the support vertex towards the plane (the documented contact), then the support vertices
  * of three directions tilted by 0.3 around the plane normal (120 degrees apart), kept when they are other vertices and within
  * the margin: four contacts at most.  LOW-CONFIDENCE restatement of MuJoCo's multi-contact rule for plane-mesh pairs. */
-static int mesh_support_index(const double *vert, int nvert, const double *dl) {
-  int best = 0;
-  double bd = -1e300;
-  for (int k = 0; k < nvert; k++) {
-    double s = dot3(vert + 3 * k, dl);
-    if (s > bd) { bd = s; best = k; }
-  }
-  return best;
-}
 static int c_plane_mesh(RawCon *c, double margin, const double *ppos, const double *pmat, const double *gpos,
                         const double *gmat, const double *vert, int nvert) {
   double normal[3] = {pmat[2], pmat[5], pmat[8]}, t1[3] = {pmat[0], pmat[3], pmat[6]}, t2[3] = {pmat[1], pmat[4], pmat[7]};

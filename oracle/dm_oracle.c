@@ -37,14 +37,17 @@ static struct {
   double solref_limit;   /* > 0: time constant of joint-limit rows only (solreflimit) */
   double mu_scale;       /* multiplies the contact friction coefficient */
   double stale_ws;       /* 1: RK stages 2..4 warm-start from what the step found (later MuJoCo saves qacc_warmstart in mj_advance) */
-} TW = {1, 2, 0, 1, 0, 1, 0, 1, 0};
+  double support_tie;    /* support mappings: candidates within this distance of the maximum count as tied and the lowest vertex index
+                          * (box / cylinder: the positive side) wins.  0 = libccd / MuJoCo literally: the first strict maximum, i.e.
+                          * a tie is decided by the last bit of the dot products.  See dm_convex.h "ties". */
+} TW = {1, 2, 0, 1, 0, 1, 0, 1, 0, 1e-12};
 
 int dmo_set_tweak(const char *name, double v) {
   if (!strcmp(name, "reset")) { TW.refsafe = 1; TW.redge = 2; TW.warmstart = 0; TW.pgs_early_exit = 1; TW.planebox_all = 0;
-                                TW.diag_scale = 1; TW.solref_limit = 0; TW.mu_scale = 1; TW.stale_ws = 0; return 0; }
+                                TW.diag_scale = 1; TW.solref_limit = 0; TW.mu_scale = 1; TW.stale_ws = 0; TW.support_tie = 1e-12; return 0; }
 #define TWK(nm) if (!strcmp(name, #nm)) { TW.nm = v; return 0; }
   TWK(refsafe) TWK(redge) TWK(warmstart) TWK(pgs_early_exit) TWK(planebox_all) TWK(diag_scale) TWK(solref_limit)
-  TWK(mu_scale) TWK(stale_ws)
+  TWK(mu_scale) TWK(stale_ws) TWK(support_tie)
 #undef TWK
   return -1;
 }
@@ -1094,13 +1097,19 @@ static void integrate_pos(const DmModel *m, double *qpos, const double *qvel, do
   }
 }
 
+static int32_t contact_hash(const DmoData *d) { /* test diagnostics: the contact index list of an evaluation, in order */
+  uint32_t h = 0;
+  for (int c = 0; c < d->ncon; c++) h = (h * 131u + (uint32_t)d->contact[c].geom1 * 97u + (uint32_t)d->contact[c].geom2 + 1u) & 0xFFFFFFu;
+  return (int32_t)h;
+}
+
 int dmo_step(const DmModel *m, DmoData *d) { /* [EXT] mj_step with mj_RungeKutta(4) */
   if (bad(d->qpos, NQ) || bad(d->qvel, NV)) return 1;
   double ws0[NV];
   memcpy(ws0, d->qacc_warmstart, sizeof ws0); /* warm start as the step found it (TW.stale_ws only) */
   forward_nocheck(m, d);
   if (bad(d->qacc, NV)) return 1;
-  d->stage_ncon[0] = d->ncon; d->stage_nefc[0] = d->nefc;
+  d->stage_ncon[0] = d->ncon; d->stage_nefc[0] = d->nefc; d->stage_chash[0] = contact_hash(d);
   double h = m->timestep;
   if (m->integrator == DM_INT_RK4) {
     static const double A[3][3] = {{0.5, 0, 0}, {0, 0.5, 0}, {0, 0, 1}};
@@ -1124,7 +1133,7 @@ int dmo_step(const DmModel *m, DmoData *d) { /* [EXT] mj_step with mj_RungeKutta
       d->time = t0 + Ct[i - 1] * h;
       if (TW.stale_ws) memcpy(d->qacc_warmstart, ws0, sizeof ws0);
       forward_nocheck(m, d);
-      d->stage_ncon[i] = d->ncon; d->stage_nefc[i] = d->nefc;
+      d->stage_ncon[i] = d->ncon; d->stage_nefc[i] = d->nefc; d->stage_chash[i] = contact_hash(d);
       memcpy(F[i], d->qacc, sizeof X0v);
     }
     double dq[NV], dv[NV];
@@ -1587,6 +1596,7 @@ int dmo_get_int(const DmoData *d, const char *name) {
   if (!strcmp(name, "maxrow")) return d->maxrow;
   if (!strncmp(name, "stage_ncon", 10)) return d->stage_ncon[name[10] - '0'];
   if (!strncmp(name, "stage_nefc", 10)) return d->stage_nefc[name[10] - '0'];
+  if (!strncmp(name, "stage_chash", 11)) return d->stage_chash[name[11] - '0'];
   return -1;
 }
 int dmo_model_sizeof(void) { return (int)sizeof(DmModel); }

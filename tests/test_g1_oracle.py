@@ -266,6 +266,65 @@ def test_plane_mesh_first_contact_is_the_lowest_hull_vertex(lib):
     assert multi > 0
 
 
+def test_plane_mesh_contacts_do_not_depend_on_the_vertex_order(lib):
+    """the plane-mesh contact set (a restatement of MuJoCo >= 2.1's mjc_PlaneConvex multi-contact rule, from
+    its documentation only: LOW CONFIDENCE) is a set of hull vertices within the margin that contains the deepest one (test above)
+    and is a function of the geometry alone: the same contacts for any order of the vertex array (generic orientations: no ties)."""
+    g, _ = og.g1_model()
+    rng = np.random.default_rng(16)
+    ppos, pmat = np.zeros(3), np.ascontiguousarray(np.eye(3))
+    for name in ("pelvis", "torso_link", "left_palm_link"):
+        v = np.ascontiguousarray(g.mesh_vert[g.mesh_names.index(name)], np.float64)
+        for _ in range(10):
+            M = np.ascontiguousarray(_rot(rng))
+            x = np.array([0.1, 0.2, -(v @ M.T)[:, 2].min() - rng.uniform(0.0, 0.004)])
+            sets = []
+            for perm in (np.arange(len(v)), rng.permutation(len(v)), np.arange(len(v))[::-1]):
+                vp, out = np.ascontiguousarray(v[perm]), np.zeros(28)
+                n = lib.dmo_plane_mesh(_p(ppos), _p(pmat), _p(x), _p(M), _p(vp), len(vp), 0.0, _p(out))
+                sets.append(sorted(tuple(np.round(r, 12)) for r in out[:7 * n].reshape(-1, 7)))
+            assert sets[0] == sets[1] == sets[2] and len(sets[0]) >= 1
+
+
+def test_mpr_support_tie_is_structural_and_the_tie_rule_removes_it(walk):
+    """The finding behind r3's G1 parity (oracle/dm_convex.h "ties"): frame 14 of the walk clip has the right hand's
+    finger hull 9 mm inside the hip hull (an edge-edge contact).  With libccd's literal support scan (support_tie = 0) the ORACLE
+    ITSELF returns one of two contacts (depth 8.90 / 9.09 mm, normals 0.035 apart) depending on 1e-13 perturbations of the joint
+    angles: when two portal vertices share a witness, two hull vertices tie exactly along the portal normal and the last bit of
+    the dot products picks.  With the tie rule (the default) the contact is a function of the pose again."""
+    mc, _ = walk
+    q0 = np.asarray(mc.data_config[14], np.float64).astype(np.float32).astype(np.float64)
+    v0 = np.asarray(mc.data_vel[14], np.float64).astype(np.float32).astype(np.float64)
+    L = og.lib()
+
+    def normals(tie):
+        assert L.dmo_set_tweak(b"support_tie", tie) == 0
+        rng = np.random.default_rng(0)
+        out = []
+        for k in range(16):
+            q = q0.copy()
+            q[7:] += rng.normal(size=37) * (1e-13 if k else 0.0)
+            s = og.G1Sim()
+            s.set_caps(48, 256)
+            assert s.set_state(q, v0) == 0
+            c = [c for c in s.contacts() if (c["geom1"], c["geom2"]) == (23, 85)]
+            assert len(c) == 1
+            out.append(np.concatenate([[c[0]["dist"]], c[0]["frame"][0]]))
+        return np.array(out)
+
+    try:
+        lit = normals(0.0)
+        rule = normals(1e-12)
+    finally:
+        L.dmo_set_tweak(b"reset", 0.0)
+    spread_lit = np.abs(lit - lit[0]).max(axis=1)
+    print("literal scan: distinct contacts", len({tuple(np.round(r, 6)) for r in lit}), "max spread", spread_lit.max(),
+          "| tie rule: max spread", np.abs(rule - rule[0]).max())
+    assert (spread_lit > 1e-2).sum() >= 3 and (spread_lit < 1e-9).sum() >= 3      # two answers, both frequent
+    assert np.abs(rule - rule[0]).max() < 1e-9                                    # one answer
+    assert min(np.abs(lit - rule[0]).max(axis=1)) < 1e-9                          # ... which is one of the literal scan's two
+
+
 # ------------------------------------------------------------------------------------------ dynamics
 def _comvel(g, q, v):
     k = mjcf.forward_kinematics_general(g, q)
