@@ -40,6 +40,13 @@ def _newest_pmc():
     return vals, os.path.basename(path)
 
 
+def _newest_g1_pmc():
+    import glob
+    import re
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*_g1*_pmc_g1_step_kernel.csv"))
+    return max(files, key=lambda f: tuple(int(x) for x in re.findall(r"\d+", os.path.basename(f)))) if files else None
+
+
 def measured_traffic_bytes():
     """HBM bytes per launch of dm_step_kernel from the committed PMC profile."""
     try:
@@ -108,14 +115,34 @@ def g1_record(local_rank, n=4096, steps=20, warmup=5, with_cpu=False):
         eng.step(acts[t % 8], out)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    kms = eng.last_kernel_ms()
+    kms_list = []
+    for t in range(10):           # kernel time: ten more steps, each read back (a host sync per step, outside the timed window)
+        eng.step(acts[t % 8], out)
+        torch.cuda.synchronize()
+        kms_list.append(eng.last_kernel_ms())
+    kms = float(np.mean(kms_list))
+    G1_ALGO_BYTES = 4 * (44 + 43 + 43 + 23 + 4 + 44 + 43 + 43 + 85 + 1 + 5 + 2 + 2)     # state row in / out, action, outputs: 1 528 B
     rec = {"robot": "unitree_g1 (43 DoF, 32 convex meshes, friction loss)", "envs_per_gpu": n, "steps": steps,
+           "window": "steps %d..%d after reset (throughput), %d..%d (kernel time)" % (warmup, warmup + steps - 1, warmup + steps, warmup + steps + 9),
            "env_steps_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3, "kernel": "g1_step_kernel",
-           "kernel_ms_last": eng.last_kernel_ms(), "done_fraction_last_step": float(out["done"].float().mean()),
+           "kernel_ms": kms, "done_fraction_last_step": float(out["done"].float().mean()),
            "reference_published_env_steps_per_s": 1390, "note": "auxiliary: SURVEY 8f-2 (next row), not the headline metric"}
+    pmc_path, traffic = _newest_g1_pmc(), None
+    try:
+        import csv
+        v = {r["counter"]: float(r["mean_per_dispatch_over_last_10_dispatches"]) for r in csv.DictReader(open(pmc_path))}
+        traffic = (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        pass
+    ach = n * G1_ALGO_BYTES / (kms * 1e-3) / 1e9
+    rec["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                       "traffic": traffic, "kernel": "g1_step_kernel", "kernel_ms": kms, "kernel_launches_timed": len(kms_list),
+                       "algorithmic_bytes_per_env_step": G1_ALGO_BYTES,
+                       "note": "nominal bound like the humanoid's: the kernel is latency / issue bound (valu below); traffic from "
+                               "profiles/%s" % os.path.basename(pmc_path or "-")}
     try:   # what bounds g1_step_kernel: instruction issue / latency, from the committed PMC file of the same command
         import csv
-        path = os.path.join(ROOT, "profiles", "r02_g1_pmc_g1_step_kernel.csv")
+        path = _newest_g1_pmc()
         v = {r["counter"]: float(r["mean_per_dispatch_over_last_10_dispatches"]) for r in csv.DictReader(open(path))}
         w = v["SQ_WAVES"]
         wave_cycles = 4.0 * v["SQ_WAVE_CYCLES"] / w
@@ -126,8 +153,8 @@ def g1_record(local_rank, n=4096, steps=20, warmup=5, with_cpu=False):
                        "issue_frac_launch": n * (v["SQ_INSTS_VALU"] / w) * 2.0 / (1024 * launch_cycles),
                        "wait_frac": v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], "resident_waves_per_simd": 2,
                        "hbm_bytes_per_env_step": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 / n,
-                       "algorithmic_bytes_per_env_step": 4 * (44 + 43 + 43 + 23 + 4 + 44 + 43 + 43 + 85 + 1 + 5 + 2 + 2),
-                       "counters_from": "profiles/r02_g1_pmc_g1_step_kernel.csv"}
+                       "algorithmic_bytes_per_env_step": G1_ALGO_BYTES,
+                       "counters_from": "profiles/" + os.path.basename(path)}
     except Exception as e:  # noqa: BLE001
         rec["valu"] = {"error": repr(e)[:200]}
     eng.close()
@@ -148,7 +175,7 @@ def g1_record(local_rank, n=4096, steps=20, warmup=5, with_cpu=False):
     torch.cuda.synchronize()
     dtb = time.perf_counter() - t0
     rec["larger_batch"] = {"envs_per_gpu": nb, "env_steps_per_s": nb * (steps // 2) / dtb, "ms_per_step": dtb / (steps // 2) * 1e3,
-                           "kernel_ms_last": eng.last_kernel_ms()}
+                           "kernel_ms_last": eng.last_kernel_ms(), "window": "steps %d..%d after reset" % (warmup, warmup + steps // 2 - 1)}
     eng.close()
     del outb, actb
     # DPCombinedEnv() as src/sb3_ppo.py:277-278 trains it: walk / run / getup state machine on the G1, RSI auto-reset
@@ -163,7 +190,8 @@ def g1_record(local_rank, n=4096, steps=20, warmup=5, with_cpu=False):
         o = venv.step_tensor(acts[t % 8] * 0.25)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    rec["dp_combined_env"] = {"env_steps_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3,
+    rec["dp_combined_env"] = {"window": "steps %d..%d after an RSI reset (the cost drifts upwards over hundreds of steps as robots fall)" % (warmup, warmup + steps - 1),
+                              "env_steps_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3,
                               "done_fraction_last_step": float(o["done"].float().mean()), "mean_reward": float(o["rew"].mean())}
     venv.close()
     if with_cpu:   # the fp64 G1 oracle on 16 host threads, bounded sample of the same workload (checker code: CPU leg only)
@@ -175,13 +203,22 @@ def g1_record(local_rank, n=4096, steps=20, warmup=5, with_cpu=False):
         L.dmo_bench_steps.restype = C.c_double
         _, cm = og.g1_model()
         clip = og.G1Clip(*mc.tables())
-        threads, nenv, nst = 16, 2, 60
-        with ThreadPoolExecutor(threads) as ex:
-            t0 = time.perf_counter()
-            list(ex.map(lambda k: L.dmo_bench_steps(C.byref(cm), C.byref(clip.c), nenv, nst, 77 + k), range(threads)))
-            dtc = time.perf_counter() - t0
-        rec["cpu_baseline"] = {"value": threads * nenv * nst / dtc, "unit": "env-steps/s", "cores": threads, "kind": "port",
-                               "sample": "%d threads x %d envs x %d random-torque steps, walk clip, fp64 G1 oracle" % (threads, nenv, nst)}
+        limit, affinity, quota = cpu_share()
+        t0 = time.perf_counter()
+        L.dmo_bench_steps(C.byref(cm), C.byref(clip.c), 1, 20, 76)
+        rate1 = 20 / (time.perf_counter() - t0)                  # single-thread rate, to size the sample
+
+        def run(c, seconds):
+            nenv, nst = 2, max(10, min(200, int(rate1 * seconds / 2)))
+            with ThreadPoolExecutor(c) as ex:
+                t0 = time.perf_counter()
+                list(ex.map(lambda k: L.dmo_bench_steps(C.byref(cm), C.byref(clip.c), nenv, nst, 77 + k), range(c)))
+                dtc = time.perf_counter() - t0
+            return c * nenv * nst, dtc, "%d threads x %d envs x %d random-torque steps, walk clip, fp64 G1 oracle" % (c, nenv, nst)
+        cores, rate, txt, calib = best_thread_count(run, limit, 9.0)
+        rec["cpu_baseline"] = {"value": rate, "unit": "env-steps/s", "cores": cores, "kind": "port", "affinity_cores": affinity,
+                               "cgroup_cpu_quota": quota, "thread_calibration_env_steps_per_s": calib,
+                               "single_thread_value": rate1, "sample": txt}
     return rec
 
 
@@ -195,12 +232,27 @@ def ppo_loop_record(args, dev, local_rank, rank, world, launched, barrier):
     from deepmimic_mujoco_amd.ppo import PPO
     motion = "spinkick" if world > 1 else "walk"
     rec = {"motion": motion, "envs_per_gpu": args.envs, "horizon": 32, "epochs": 20, "minibatch": 4096, "n_gpus": world,
-           "timed_iterations": args.ppo_iters}
+           "timed_iterations": args.ppo_iters, "window": "PPO iterations 1..%d (iteration 0 untimed: graph capture), 32 env steps each, "
+                                                         "fresh envs, untrained policy" % args.ppo_iters}
     for arch, mdt in (((256, 128), torch.float32), ((1024, 512), torch.float32), ((1024, 512), torch.bfloat16)):
         key = "%d,%d" % arch + ("" if mdt == torch.float32 else " bf16-gemm")     # bf16-gemm: auxiliary mixed-precision learner option
+        env = ppo = err = None
         try:
             env = HipDeepMimicVecEnv(args.envs, motion=motion, device=local_rank, seed=1234 + 7919 * rank)
             ppo = PPO(env, net_arch=arch, n_steps=32, batch_size=4096, n_epochs=20, seed=0, mlp_dtype=mdt)
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)[:300]
+        if launched and world > 1:   # every rank must enter this net's collectives, or none (a rank that failed to build would
+            okt = torch.tensor([0 if err else 1], device=dev if args.dist_backend == "nccl" else "cpu")   # leave the others waiting)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if int(okt.item()) == 0 and err is None:
+                err = "another rank failed to build this net"
+        if err is not None:
+            rec[key] = {"error": err}
+            if env is not None:
+                env.close()
+            continue
+        try:
             ppo.train(ppo.collect_rollouts())                    # untimed: captures the graphs
             torch.cuda.synchronize()
             barrier()
@@ -251,18 +303,13 @@ def ppo_loop_record(args, dev, local_rank, rank, world, launched, barrier):
     return rec
 
 
-def cpu_baseline(model, mocap, budget_s=12.0):
-    """Oracle DPEnv.step() on the host cores: one thread per core of this process's CPU share (each thread owns
-    its envs, as one SubprocVecEnv worker does), bounded sample of the same workload."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle.oracle import OracleClip, bench_steps
-    clip = OracleClip(*mocap.tables())
+def cpu_share():
+    """(thread limit, affinity size, cgroup quota) of this process: the affinity mask, capped by the cgroup CPU quota when one
+    is set (the one-GPU box shows 256 cores in the mask and grants 16 of them: 256 threads there run at half the rate of 16)."""
     try:
         affinity = len(os.sched_getaffinity(0))
     except AttributeError:
         affinity = os.cpu_count() or 1
-    # threads actually used = the CPU share of this process: the affinity mask, capped by the cgroup CPU quota when one is
-    # set (the one-GPU box shows 256 cores in the mask and grants 16 of them: 256 threads there run at half the rate of 16)
     quota = None
     for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
         try:
@@ -275,30 +322,52 @@ def cpu_baseline(model, mocap, budget_s=12.0):
             break
         except Exception:
             continue
-    limit = max(1, affinity if quota is None else min(affinity, int(quota + 0.999)))
+    return max(1, affinity if quota is None else min(affinity, int(quota + 0.999))), affinity, quota
+
+
+def best_thread_count(run, limit, budget_s):
+    """A container may grant fewer CPUs than its affinity mask shows without any quota file saying so: time the same bounded
+    sample (`run(threads, seconds) -> (env-steps, wall seconds, sample text)`) at the mask size and at 64 / 16 threads and
+    keep the best.  Returns (threads, rate, sample text, {threads: rate})."""
+    cand = sorted({c for c in (16, 64, limit) if c <= limit} | {limit}, reverse=True)
+    calib, best = {}, None
+    for c in cand:
+        n, dt, txt = run(c, budget_s / len(cand))
+        calib[c] = n / dt
+        if best is None or calib[c] > calib[best[0]]:
+            best = (c, txt)
+    return best[0], calib[best[0]], best[1], calib
+
+
+def cpu_baseline(model, mocap, budget_s=12.0):
+    """Oracle DPEnv.step() on the host cores: one thread per core of this process's CPU share (each thread owns
+    its envs, as one SubprocVecEnv worker does), bounded sample of the same workload."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.oracle import OracleClip, bench_steps
+    clip = OracleClip(*mocap.tables())
+    limit, affinity, quota = cpu_share()
     t0 = time.perf_counter()
     bench_steps(model, clip, 4, 250, 1234)                      # single-thread rate, to size the sample
     rate1 = 1000 / (time.perf_counter() - t0)
-    # a container may grant fewer CPUs than its affinity mask shows without any quota file saying so (the one-GPU box: 256 in
-    # the mask, ~16 granted): measure the same bounded sample at the mask size and at 64 / 16 threads, report the best
-    cand = sorted({c for c in (16, 64, limit) if c <= limit} | {limit}, reverse=True)
-    per = budget_s / len(cand)
-    calib, best = {}, None
-    for c in cand:
-        nenv = max(2, min(64, int(rate1 * per / 1000)))         # envs per thread, 1000 steps each
+    def run(c, seconds):
+        nenv = max(2, min(64, int(rate1 * seconds / 1000)))     # envs per thread, 1000 steps each
         with ThreadPoolExecutor(c) as ex:                       # ctypes releases the GIL; each call owns its DmoData
             t0 = time.perf_counter()
             list(ex.map(lambda k: bench_steps(model, clip, nenv, 1000, 1234 + k), range(c)))
             dt = time.perf_counter() - t0
-        calib[c] = c * nenv * 1000 / dt
-        if best is None or calib[c] > calib[best[0]]:
-            best = (c, nenv, dt)
-    cores, nenv, dt = best
-    return {"value": cores * nenv * 1000 / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+        return c * nenv * 1000, dt, "%d threads x %d envs x 1000 random-torque steps, walk clip, fp64 oracle (oracle/dm_oracle.c)" % (c, nenv)
+    cores, rate, txt, calib = best_thread_count(run, limit, budget_s)
+    return {"value": rate, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "affinity_cores": affinity, "cgroup_cpu_quota": quota, "thread_calibration_env_steps_per_s": calib,
-            "single_thread_value": rate1,
-            "sample": "%d threads x %d envs x 1000 random-torque steps, walk clip, fp64 oracle (oracle/dm_oracle.c)"
-                      % (cores, nenv)}
+            "single_thread_value": rate1, "sample": txt}
+
+
+def _pci_bus_id(torch, idx):
+    try:
+        p = torch.cuda.get_device_properties(idx)
+        return "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", -1), getattr(p, "pci_device_id", 0))
+    except Exception:
+        return "?"
 
 
 def main():
@@ -317,7 +386,26 @@ def main():
     ap.add_argument("--no-ppo-loop", action="store_true", help="skip the auxiliary PPO-loop record (configs 3 / 4)")
     ap.add_argument("--no-g1", action="store_true", help="skip the auxiliary Unitree G1 record")
     ap.add_argument("--ppo-iters", type=int, default=2, help="timed PPO iterations per net in the ppo_loop record")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="rendezvous only: launch / join the ranks, all-reduce the rank ids, print {n_gpus, ranks_seen}; no GPU needed")
     args = ap.parse_args()
+
+    launched = "RANK" in os.environ
+    if args.gpus > 1 and not launched:
+        # `python bench.py --gpus N` (no launcher): become the launcher BEFORE anything touches the GPU — the N ranks are children of
+        # torch.distributed.run, rank 0's JSON line goes to the inherited stdout, the exit code is the children's
+        import socket
+        import subprocess
+        import torch
+        if args.dist_backend == "nccl" and not args.dry_launch and torch.cuda.device_count() < args.gpus:   # device_count() does not initialise HIP
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible; ranks are never folded onto one device"
+                             % (args.gpus, torch.cuda.device_count()))
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import torch
     import torch.distributed as dist
@@ -325,22 +413,52 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d: the two must agree" % (args.gpus, world))
+    import datetime
+    tmo = datetime.timedelta(minutes=5)        # a rank that dies must not leave the others waiting forever
+    if args.dry_launch:
+        ranks = [0]
+        if launched:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", timeout=tmo)
+            t = torch.zeros(world, dtype=torch.int64)
+            t[rank] = rank + 1
+            dist.all_reduce(t)
+            ranks = [int(x) - 1 for x in t]
+            assert dist.get_world_size() == args.gpus
+        if rank == 0:
+            print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks_seen": ranks, "self_launched": launched}))
+        if launched:
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    # one rank per GPU; --dist-backend gloo + several ranks on one GPU is only for rehearsing the N>1 path
-    local_dev = local_rank % torch.cuda.device_count()
-    launched = "RANK" in os.environ
+    # one rank per GPU.  Ranks are never folded onto one device under nccl; --dist-backend gloo + several ranks on one GPU is the
+    # explicit rehearsal mode of the N > 1 path on a one-GPU box (the line then says devices_distinct: false)
+    ndev = torch.cuda.device_count()
+    if launched and args.dist_backend == "nccl" and ndev < world:
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible; refusing to fold ranks onto one device" % (world, ndev))
+    local_dev = local_rank % ndev
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        import datetime
-        tmo = datetime.timedelta(minutes=5)        # a rank that dies must not leave the others waiting forever
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev), timeout=tmo)
         else:
             dist.init_process_group(args.dist_backend, timeout=tmo)
+        assert dist.get_world_size() == args.gpus
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     local_rank = local_dev
+    # which device every rank really sits on: (rank, local device index, PCI bus id) gathered on all ranks
+    ranks_seen = [[rank, local_dev, _pci_bus_id(torch, local_dev)]]
+    if launched:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, ranks_seen[0])
+        ranks_seen = gathered
+    devices_distinct = len({(r[1], r[2]) for r in ranks_seen}) == world
+    if launched and args.dist_backend == "nccl":
+        assert devices_distinct, "two ranks share a GPU: %r" % (ranks_seen,)
 
     def barrier():
         if launched:
@@ -387,6 +505,32 @@ def main():
         dt = float(t.item())
     done_frac = float(out["done"].float().mean().item())
 
+    # SURVEY 8(d) asks for physics-only throughput beside the full step(): for `nphys` consecutive steps the pre-step state is
+    # saved, dm_physics_step (the mj_step-equivalent alone: same kernel, task layer skipped, same launch order) is timed on it,
+    # the state is put back and the full dm_step is timed on the SAME state.  Kernel times from the library's HIP events.
+    physics_only = None
+    if args.actions == "random" and args.integrator != "Euler":
+        nphys, tp, tf = 24, 0.0, 0.0
+        eng.enable_timing(True, stride=1)
+        for i in range(nphys):
+            q, v, w, c = eng.get_state()
+            one_fill = args.warmup + args.steps + i
+            eng.fill_random_actions(actions, one_fill)
+            eng.physics_step(actions)
+            torch.cuda.synchronize()
+            tp += eng.last_step_ms()
+            eng.set_state(q, v, warm=w, ctrl=c, run_forward=False)
+            eng.step(actions, out)
+            torch.cuda.synchronize()
+            tf += eng.last_step_ms()
+        physics_only = {"kernel_ms_physics_only": tp / nphys, "kernel_ms_full_step_same_states": tf / nphys,
+                        "env_steps_per_s_physics_only": N / (tp / nphys * 1e-3), "env_steps_per_s_full_step": N / (tf / nphys * 1e-3),
+                        "task_layer_frac": 1.0 - tp / tf, "window": "steps %d..%d of the run, one launch of each kind per step" %
+                        (args.warmup + args.steps, args.warmup + args.steps + nphys - 1),
+                        "note": "kernel time only (one launch per batch step, no host gap); the full step also resets finished envs "
+                                "(a fifth forward evaluation for ~%.1f %% of them), which physics-only never does" % (100 * done_frac)}
+        eng.enable_timing(False)
+
     # Auxiliary figure (never `value`): the same 4096 envs stepped as two independent 2048-env sub-batches on two
     # streams with no barrier between them, as a double-buffered rollout does (policy on one half while the other
     # half simulates): the ramp-down of one launch overlaps the next launch of the other half.
@@ -415,7 +559,7 @@ def main():
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t1
         pipelined = {"sub_batches": K, "envs_per_sub_batch": n2, "value": args.steps * N / dt2, "unit": "env-steps/s",
-                     "ms_per_step": dt2 / args.steps * 1e3,
+                     "ms_per_step": dt2 / args.steps * 1e3, "window": "steps %d..%d after reset" % (args.warmup, args.warmup + args.steps - 1),
                      "note": "auxiliary: no barrier between the sub-batches (double-buffered rollout); not the headline value"}
         for e2, _, _, _ in subs:
             e2.close()
@@ -441,7 +585,8 @@ def main():
         traffic = measured_traffic_bytes() if (N == 4096 and args.actions == "random" and args.integrator != "Euler") else None
         line = {
             "metric": "env-steps/sec (whole node), 34-DoF humanoid, 4096 envs, at 1/2/4/8 MI355X",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "ranks_seen": ranks_seen, "devices_distinct": devices_distinct,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cfg2_random_torque: %d envs/GPU, humanoid3d, clip %s, %s h=0.0166 PGS<=50, "
@@ -464,6 +609,8 @@ def main():
             line["g1"] = g1
         if pipelined is not None:
             line["pipelined"] = pipelined
+        if physics_only is not None:
+            line["physics_only"] = physics_only
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, mocap)
         print(json.dumps(line))

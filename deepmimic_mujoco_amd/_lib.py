@@ -22,7 +22,7 @@ REASONS = {0: None, 1: "low_z", 2: "high_z", 3: "max_ep_len", 4: "acyclical_end"
 TASK_DPENV, TASK_COMBINED = 0, 1
 
 EXPORTS = ["dm_default_config", "dm_create", "dm_destroy", "dm_last_error", "dm_num_envs",
-           "dm_load_clip", "dm_set_env_clips", "dm_reset", "dm_step", "dm_step_forced",
+           "dm_load_clip", "dm_set_env_clips", "dm_reset", "dm_step", "dm_step_forced", "dm_physics_step",
            "dm_set_state", "dm_get_state", "dm_get_counters", "dm_set_counters", "dm_set_debug",
            "dm_fill_random_actions", "dm_last_step_ms", "dm_enable_timing", "dm_get_work",
            "dm_set_clip_flags", "dm_obs_dim", "dm_terms_dim", "dm_get_env_clips", "dm_mean_step_ms", "dm_ppo_loss", "dm_forward", "dm_linear_wgrad", "dm_ppo_gather", "dm_adam_clip_step", "dm_policy_sample",
@@ -88,6 +88,7 @@ def load_library():
     L.dm_reset.argtypes = [vp, vp, vp, vp, vp]
     L.dm_step.argtypes = [vp] * 9
     L.dm_step_forced.argtypes = [vp] * 9
+    L.dm_physics_step.argtypes = [vp] * 3
     L.dm_set_state.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp]
     L.dm_get_state.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
     L.dm_forward.argtypes = [vp, vp, i32, vp]
@@ -229,6 +230,10 @@ class HipEngine:
         self._chk(self.L.dm_step(self.h, _ptr(actions), _ptr(out["obs"]), _ptr(out["rew"]), _ptr(out["done"]),
                                  _ptr(out.get("terms")), _ptr(out.get("reason")), _ptr(out.get("terminal_obs")),
                                  self._stream()), "dm_step")
+
+    def physics_step(self, actions):
+        """sim.step() alone (src/deepmimic_env.py:362): the state advances, nothing is observed (dm_physics_step)."""
+        self._chk(self.L.dm_physics_step(self.h, _ptr(actions), self._stream()), "dm_physics_step")
 
     def step_forced(self, qpos, qvel, out):
         self._chk(self.L.dm_step_forced(self.h, _ptr(qpos), _ptr(qvel), _ptr(out["obs"]), _ptr(out["rew"]),

@@ -222,6 +222,9 @@ extern "C" int dm_create(const DmModel *model, const DmConfig *cfg, DmHandle *ou
     hipFree(e->dArScratch); hipFree(e->dState); hipFree(e->dT); delete e; return DM_ENOMEM;
   }
   hipMemset(e->dCost, 0, e->N * sizeof(int32_t));
+  { std::vector<int32_t> ident(e->N);
+    for (int i = 0; i < e->N; i++) ident[i] = i;
+    hipMemcpy(e->dOrder, ident.data(), e->N * sizeof(int32_t), hipMemcpyHostToDevice); }   // until the first dm_step schedules
   for (int i = 0; i < DmEngine::NEV; i++) { hipEventCreate(&e->ev0[i]); hipEventCreate(&e->ev1[i]); }
   *out = e;
   return DM_OK;
@@ -402,6 +405,20 @@ extern "C" int dm_step(DmHandle e, const float *actions, float *obs, float *rew,
   P.actions = actions; P.obs = obs; P.rew = rew; P.done = done; P.terms = terms; P.reason = reason; P.terminal_obs = terminal_obs;
   P.cost = e->dCost;
   if (e->cfg.lpt_schedule) {
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    hipLaunchKernelGGL(dm_schedule_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->dCost, e->dOrder, e->N);
+    P.env_ids = e->dOrder;
+  }
+  return launch(e, P, e->N, stream);
+}
+
+extern "C" int dm_physics_step(DmHandle e, const float *actions, void *stream) {
+  if (!e || !actions) return fail(e, DM_EINVAL, "dm_physics_step: null buffer");
+  DmLaunch P;
+  fill_launch(e, P, DMK_MODE_PHYSICS);
+  P.actions = actions;
+  P.auto_reset = 0;
+  if (e->cfg.lpt_schedule) {   // same launch order as a dm_step from this state: the work estimates of the last dm_step
     HIPCHK(e, hipSetDevice(e->cfg.device));
     hipLaunchKernelGGL(dm_schedule_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->dCost, e->dOrder, e->N);
     P.env_ids = e->dOrder;

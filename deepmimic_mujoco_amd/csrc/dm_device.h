@@ -144,7 +144,8 @@ struct DmClipDev {
   int32_t L, flags;     // flags: DM_CLIP_FLOOR | DM_CLIP_ACYCLIC
 };
 
-enum { DMK_MODE_STEP = 0, DMK_MODE_FORCED = 1, DMK_MODE_RESET = 2, DMK_MODE_SETSTATE = 3 };
+enum { DMK_MODE_STEP = 0, DMK_MODE_FORCED = 1, DMK_MODE_RESET = 2, DMK_MODE_SETSTATE = 3,
+       DMK_MODE_PHYSICS = 4 };   // PHYSICS: sim.step() alone (the mj_step-equivalent): no observation, reward, termination, counters
 
 struct DmLaunch {
   const DmDev *T;

@@ -1655,7 +1655,7 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
   if (lane < DMK_NV) { S.qvel[lane] = st[DMS_QVEL + lane]; S.warm[lane] = st[DMS_WARM + lane]; }
   if (lane < DMK_NU) S.ctrl[lane] = st[DMS_CTRL + lane];
   SYNC();
-  if (mode == DMK_MODE_STEP) {
+  if (mode == DMK_MODE_STEP || mode == DMK_MODE_PHYSICS) {
     if (lane < DMK_NU) S.ctrl[lane] = P.actions[(size_t)env * DMK_NU + lane];  // ctrl = action * 1.0 (:347)
   } else if (mode == DMK_MODE_FORCED || mode == DMK_MODE_SETSTATE) {
     if (P.in_qpos) {   // null in SETSTATE mode = dm_forward: keep the stored state, only re-run the forward evaluation
@@ -1693,7 +1693,7 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
   // RK4 bookkeeping, lane = dof (k<3 root translation, 3..5 root rotation, >=6 hinges): X0 (position, velocity), the
   // weighted sums of the stage derivatives and the current stage velocity live in LDS (S.rk / S.rkq), not in VGPRs —
   // they are touched once per stage and would otherwise occupy nine registers across every forward evaluation
-  int it = (mode == DMK_MODE_STEP) ? 0 : 4;
+  int it = (mode == DMK_MODE_STEP || mode == DMK_MODE_PHYSICS) ? 0 : 4;
   bool after_reset = false, done = false, sim_err = false;
   int reason = DM_REASON_NONE;
   float reward = 0;
@@ -1708,7 +1708,7 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
     if (lane < DMK_NU) st[DMS_CTRL + lane] = S.ctrl[lane];
     return;
   }
-  if (mode == DMK_MODE_STEP || mode == DMK_MODE_FORCED) {  // mj_checkPos / mj_checkVel
+  if (mode == DMK_MODE_STEP || mode == DMK_MODE_FORCED || mode == DMK_MODE_PHYSICS) {  // mj_checkPos / mj_checkVel
     float a = (lane < DMK_NQ) ? S.qpos[lane] : 0.f, b = (lane < DMK_NV) ? S.qvel[lk] : 0.f;
     sim_err = __any(!(fabsf(a) <= MAXVALF) || !(fabsf(b) <= MAXVALF));
   }
@@ -1757,7 +1757,7 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
     }
    }  // !sim_err
 
-    const bool euler = (P.integrator == DM_INT_EULER) && mode == DMK_MODE_STEP;
+    const bool euler = (P.integrator == DM_INT_EULER) && (mode == DMK_MODE_STEP || mode == DMK_MODE_PHYSICS);
     float x0q = 0, x0v = 0, accq = 0, accv = 0, curv = 0;
     float q0[4] = {1, 0, 0, 0};
     if (!sim_err && it < 4) {
@@ -1825,6 +1825,16 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
     }
 
     PROF(10);
+    if (mode == DMK_MODE_PHYSICS) {   // dm_physics_step: sim.step() alone; an instability resets the data as MuJoCo does
+      if (sim_err) {
+        SYNC();
+        if (lane < DMK_NQ) S.qpos[lane] = T.qpos0[lane];
+        if (lane < DMK_NV) { S.qvel[lane] = 0; S.warm[lane] = 0; }
+        if (lane < DMK_NU) S.ctrl[lane] = 0;
+        SYNC();
+      }
+      break;
+    }
     // ============================================================== task layer: obs, reward, done
     // (derived arrays are those of the LAST forward evaluation: SURVEY F6)
     const bool task_pass = !after_reset && (mode == DMK_MODE_STEP || mode == DMK_MODE_FORCED);

@@ -120,6 +120,12 @@ int dm_reset(DmHandle h, const uint8_t *mask, const int32_t *idx_init, float *ob
 int dm_step(DmHandle h, const float *actions, float *obs, float *rew, uint8_t *done, float *terms,
             int32_t *reason, float *terminal_obs, void *stream);
 
+/* Replaces: `self.sim.step()` alone (deepmimic_env.py:362, frame_skip 1): ctrl <- actions, one mj_step-equivalent, state and
+ * warm start advance; NO observation, reward, termination, counters or auto-reset.  The "physics-only" figure SURVEY 8(d)
+ * asks for beside the full step(), and the building block of a frame_skip > 1 loop.  Envs are launched longest-first
+ * by the work estimates of the last dm_step, like dm_step itself.  actions float[N*28]. */
+int dm_physics_step(DmHandle h, const float *actions, void *stream);
+
 /* Replaces: DPEnv.step(action, force_state=(qpos, qvel)) (deepmimic_env.py:355-357): set_state +
  * sim.forward, then obs/reward/done exactly as step().  qpos float[N*35], qvel float[N*34].
  * No auto-reset on this path. */

@@ -42,13 +42,15 @@ typedef struct CvxGeom {
 static int mesh_support_index(const double *vert, int nvert, const double *dl) {
   int best = 0;
   double bd = -1e300;
+  double sv[nvert > 0 ? nvert : 1]; /* the scan's values, kept for the tie pass (<= 5 365 vertices: 43 KB of stack) */
   for (int k = 0; k < nvert; k++) {
     double s = dot3(vert + 3 * k, dl);
+    sv[k] = s;
     if (s > bd) { bd = s; best = k; }
   }
   if (TW.support_tie > 0)
     for (int k = 0; k < best; k++)
-      if (dot3(vert + 3 * k, dl) >= bd - TW.support_tie) return k;
+      if (sv[k] >= bd - TW.support_tie) return k;
   return best;
 }
 

@@ -368,6 +368,50 @@ def test_dm_forward_recomputes_without_changing_the_state(model, clips, oracle_c
     eng.close()
 
 
+def test_physics_step_is_sim_step_alone(model, clips):
+    """dm_physics_step = `self.sim.step()` alone (src/deepmimic_env.py:362; the physics-only leg of SURVEY 8d): from the same
+    state and action it leaves exactly the qpos / qvel / warm start / ctrl the full dm_step leaves (same kernel, task layer
+    skipped), matches the oracle's dmo_step, and touches neither the counters nor any output buffer."""
+    import torch
+    from deepmimic_mujoco_amd._lib import HipEngine
+    from oracle.oracle import OracleSim
+    n = 64
+    eng = HipEngine(model, n, auto_reset=False)
+    eng.load_clip(0, clips["walk"])
+    out = eng.alloc_outputs()
+    eng.reset(out["obs"], idx_init=(torch.arange(n, device=eng.device) % 70).to(torch.int32))
+    act = torch.empty(n, 28, device=eng.device)
+    for t in range(3):
+        eng.fill_random_actions(act, t)
+        eng.step(act, out)
+    q, v, w, c = eng.get_state()
+    idx0, len0, rew0 = [x.clone() for x in eng.get_counters()]
+    obs0 = out["obs"].clone()
+    eng.fill_random_actions(act, 7)
+    eng.physics_step(act)
+    torch.cuda.synchronize()
+    qp, vp, wp, cp = eng.get_state()
+    idx1, len1, rew1 = eng.get_counters()
+    assert torch.equal(idx0, idx1) and torch.equal(len0, len1) and torch.equal(rew0, rew1) and torch.equal(obs0, out["obs"])
+    assert torch.equal(cp, act)
+    eng.set_state(q, v, warm=w, ctrl=c, run_forward=False)
+    eng.step(act, out)
+    torch.cuda.synchronize()
+    qf, vf, wf, cf = eng.get_state()
+    assert torch.equal(qp, qf) and torch.equal(vp, vf) and torch.equal(wp, wf) and torch.equal(cp, cf)
+    assert int(eng.get_counters()[1][0]) == int(len0[0]) + 1
+    worst = 0.0
+    for i in range(0, n, 8):
+        o = OracleSim(model)
+        o.set_caps(32, 128)
+        o.set("qpos", q[i].double().cpu().numpy()); o.set("qvel", v[i].double().cpu().numpy())
+        o.set("qacc_warmstart", w[i].double().cpu().numpy()); o.set("ctrl", act[i].double().cpu().numpy())
+        assert o.step() == 0
+        worst = max(worst, float(np.abs(qp[i].cpu().numpy() - o.get("qpos")).max()))
+    assert worst < 1e-4, worst
+    eng.close()
+
+
 def test_hip_linear_wgrad_matches_torch():
     """dm_linear_wgrad (MFMA split-K) against torch's weight / bias gradients for every layer shape of both nets."""
     import torch
