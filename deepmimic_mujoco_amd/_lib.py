@@ -25,8 +25,8 @@ EXPORTS = ["dm_default_config", "dm_create", "dm_destroy", "dm_last_error", "dm_
            "dm_load_clip", "dm_set_env_clips", "dm_reset", "dm_step", "dm_step_forced", "dm_physics_step",
            "dm_set_state", "dm_get_state", "dm_get_counters", "dm_set_counters", "dm_set_debug",
            "dm_fill_random_actions", "dm_last_step_ms", "dm_enable_timing", "dm_get_work",
-           "dm_set_clip_flags", "dm_obs_dim", "dm_terms_dim", "dm_get_env_clips", "dm_mean_step_ms", "dm_ppo_loss", "dm_forward", "dm_linear_wgrad", "dm_ppo_gather", "dm_adam_clip_step", "dm_policy_sample",
-           "dm_rollout_store", "dm_policy_pack", "dm_policy_forward", "dm_policy_packed_floats", "dm_ppo_mlp_grad", "dm_ppo_mlp_workspace_floats", "dm_adam_clip_update", "dm_colsum", "dm_set_seed",
+           "dm_set_clip_flags", "dm_obs_dim", "dm_terms_dim", "dm_get_env_clips", "dm_mean_step_ms", "dm_ppo_loss", "dm_forward", "dm_linear_wgrad", "dm_ppo_gather", "dm_flat_adam_step", "dm_policy_sample",
+           "dm_rollout_store", "dm_policy_pack", "dm_policy_forward", "dm_policy_packed_floats", "dm_ppo_mlp_grad", "dm_ppo_mlp_workspace_floats", "dm_flat_adam_update", "dm_colsum", "dm_set_seed",
            "dm_linear_tanh", "dm_tanh_linear_wgrad", "dm_tanh_bwd_colsum"]
 
 
@@ -100,12 +100,12 @@ def load_library():
     L.dm_ppo_mlp_grad.argtypes = [C.POINTER(DmPpoMlpStep), vp]
     L.dm_policy_pack.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
     L.dm_policy_forward.argtypes = [vp] + [i32] * 5 + [vp] * 9 + [C.c_uint64, vp, C.c_uint32, i32] + [vp] * 9
-    L.dm_adam_clip_step.argtypes = [vp, vp, vp, vp, i32] + [C.c_float] * 5 + [vp, vp]
+    L.dm_flat_adam_step.argtypes = [vp, vp, vp, vp, i32] + [C.c_float] * 6 + [vp, i32, vp]
     L.dm_colsum.argtypes = [vp, i32, i32, vp, vp]
     L.dm_linear_tanh.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     L.dm_tanh_linear_wgrad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
     L.dm_tanh_bwd_colsum.argtypes = [vp, vp, vp, vp, i32, i32, vp]
-    L.dm_adam_clip_update.argtypes = [vp, vp, vp, vp, i32] + [C.c_float] * 5 + [vp, vp]
+    L.dm_flat_adam_update.argtypes = [vp, vp, vp, vp, i32] + [C.c_float] * 6 + [vp, i32, vp]
     L.dm_ppo_gather.argtypes = [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.dm_get_counters.argtypes = [vp, vp, vp, vp, vp]
     L.dm_set_counters.argtypes = [vp, vp, vp, vp]

@@ -273,7 +273,15 @@ class DPCombinedEnv:
                             t.tensor(np.asarray(qvel)[None], dtype=t.float32, device=self._eng.device), run_forward=True)
 
     def render(self, mode=None):
-        raise NotImplementedError("rendering needs a MuJoCo viewer; out of scope (SURVEY §8f-4)")
+        """Software stick figure (render.py) of the current body poses; the warm start is put back (rendering is not physics)."""
+        from .render import stick_figure
+        if self._eng._debug is None:
+            self._eng.enable_debug()
+        q, v, w, c = self._eng.get_state()
+        self._eng.forward()
+        self._eng.set_state(q, v, warm=w, ctrl=c, run_forward=False)
+        xpos = self._eng._debug[0, :42].double().cpu().numpy().reshape(14, 3)
+        return stick_figure(xpos, self.model.body_parent)
 
     def seed(self, seed=None):
         random.seed(seed)
@@ -296,7 +304,7 @@ class HipCombinedVecEnv(_SB3VecEnv):
     def __new__(cls, num_envs, robot="unitree_g1", getup_motion="getup_facedown", device=0, seed=1234, auto_reset=True, **kw):
         if robot == "unitree_g1" and cls is HipCombinedVecEnv:
             from .g1 import HipG1CombinedVecEnv
-            return HipG1CombinedVecEnv(num_envs, device=device, seed=seed, auto_reset=auto_reset)
+            return HipG1CombinedVecEnv(num_envs, device=device, seed=seed, auto_reset=auto_reset, sub_batches=kw.get("sub_batches", 1))
         return super().__new__(cls)
 
     def __init__(self, num_envs, robot="unitree_g1", getup_motion="getup_facedown", device=0, seed=1234,
@@ -392,7 +400,16 @@ class HipCombinedVecEnv(_SB3VecEnv):
         return self
 
     def get_images(self):
-        return [None] * self.num_envs
+        return [self.render(mode="rgb_array")]
 
     def render(self, mode=None):
-        return None
+        """Software stick figure of env 0 of the batch (render.py); the warm start is put back (rendering is not physics)."""
+        from .render import stick_figure
+        e = self.engine
+        if e._debug is None:
+            e.enable_debug()
+        q, v, w, c = e.get_state()
+        e.forward()
+        e.set_state(q, v, warm=w, ctrl=c, run_forward=False)
+        xpos = e._debug[0, :42].double().cpu().numpy().reshape(14, 3)
+        return stick_figure(xpos, self.model.body_parent)

@@ -134,7 +134,7 @@ struct Launch {
   float *sepc;               // per-env separating-direction cache of the MPR pairs: [SEPC + 1][4]
   const int32_t *order;      // STEP: workgroup -> env, heaviest envs first (g1_schedule_kernel), or null
   int32_t *cost;             // STEP: per-env work estimate of this step, or null
-  ClipDev clips[3];          // DPEnv: clips[0]; DPCombinedEnv: walk, run, getup
+  ClipDev clips[DMG1_MAX_CLIPS];   // DPEnv: the env's clip id picks one (multi-clip batches); DPCombinedEnv: 0..2 = walk, run, getup
   int32_t task, amnesty_steps, to_getup_len, pad2;
   int32_t N, mode, auto_reset, max_ep_length, run_forward, pad;
   float vel_obs_scale, high_z, obs_bound;
@@ -2081,6 +2081,9 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
   const bool TASK = P.task != 0;
   int motion = TASK ? sti[S_MOTION] : 0;
   motion = (motion < 0 || motion > 3) ? 0 : motion;
+  // DPEnv task: the same slot holds the env's clip id (dmg1_set_env_clips; one DPEnv(motion=...) per worker in the reference)
+  int clip_id = TASK ? 0 : sti[S_MOTION];
+  clip_id = (clip_id < 0 || clip_id >= DMG1_MAX_CLIPS) ? 0 : clip_id;
   const int NOBS_T = TASK ? NOBS_C : NOBS, NTERMS = TASK ? 8 : 5;
   if (TASK && (P.clips[0].L < 1 || P.clips[1].L < 1 || P.clips[2].L < 2)) return;   // walk, run, getup all needed
   if (TASK) idx_curr = idx_curr < 0 ? 0 : idx_curr;
@@ -2088,7 +2091,8 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
   if (lane < NV) { S.qvel[lane] = st[S_QVEL + lane]; S.warm[lane] = st[S_WARM + lane]; }
   if (lane < NU) S.ctrl[lane] = st[S_CTRL + lane];
   SYNC();
-  ClipDev clip = P.clips[TASK ? (motion == 3 ? 2 : motion) : 0];
+  ClipDev clip = P.clips[TASK ? (motion == 3 ? 2 : motion) : clip_id];
+  if (clip.L < 1) return;   // no clip loaded under this env's clip id
   if (mode == MODE_STEP) {
     if (lane < NU) S.ctrl[lane] = (lane < NACT) ? P.actions[(size_t)env * NACT + lane] * T.action_scale : 0.f;   // :348-351
   } else if (mode == MODE_FORCED || mode == MODE_SETSTATE) {
@@ -2434,8 +2438,8 @@ struct DmG1Engine {
   int32_t *dOidx = nullptr;
   float *dState = nullptr, *dJT = nullptr, *dBT = nullptr, *dAR = nullptr, *dRowsE = nullptr, *dSepc = nullptr;
   int32_t *dOrder = nullptr, *dCost = nullptr;
-  float *dRows[3] = {nullptr, nullptr, nullptr}, *dReset[3] = {nullptr, nullptr, nullptr}, *dCom[3] = {nullptr, nullptr, nullptr}, *dDebug = nullptr;
-  int L[3] = {0, 0, 0}, flags[3] = {0, 0, 0};
+  float *dRows[DMG1_MAX_CLIPS] = {}, *dReset[DMG1_MAX_CLIPS] = {}, *dCom[DMG1_MAX_CLIPS] = {}, *dDebug = nullptr;
+  int L[DMG1_MAX_CLIPS] = {}, flags[DMG1_MAX_CLIPS] = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
 };
@@ -2727,7 +2731,7 @@ extern "C" int dmg1_create(const void *model, size_t model_bytes, const DmG1Conf
 extern "C" int dmg1_destroy(DmG1Handle e) {
   if (!e) return DM_EINVAL;
   hipFree(e->dT); hipFree(e->dMesh); hipFree(e->dOidx); hipFree(e->dClus); hipFree(e->dState); hipFree(e->dJT); hipFree(e->dBT); hipFree(e->dAR); hipFree(e->dRowsE); hipFree(e->dSepc); hipFree(e->dOrder); hipFree(e->dCost);
-  for (int c = 0; c < 3; c++) { hipFree(e->dRows[c]); hipFree(e->dReset[c]); hipFree(e->dCom[c]); }
+  for (int c = 0; c < DMG1_MAX_CLIPS; c++) { hipFree(e->dRows[c]); hipFree(e->dReset[c]); hipFree(e->dCom[c]); }
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   delete e;
@@ -2737,7 +2741,7 @@ extern "C" const char *dmg1_last_error(DmG1Handle e) { return e ? e->err.c_str()
 
 extern "C" int dmg1_load_clip(DmG1Handle e, int clip_id, int L, const double *q, const double *v, const double *bx, const double *gx, int flags) {
   using namespace g1;
-  if (!e || L < 1 || !q || !v || !bx || !gx || clip_id < 0 || clip_id > 2) return DM_EINVAL;
+  if (!e || L < 1 || !q || !v || !bx || !gx || clip_id < 0 || clip_id >= DMG1_MAX_CLIPS) return DM_EINVAL;
   g1::Dev *T = new g1::Dev();
   hipMemcpy(T, e->dT, sizeof(g1::Dev), hipMemcpyDeviceToHost);
   std::vector<float> rows((size_t)L * CLIP_ROW, 0.f), reset((size_t)L * 88, 0.f), com((size_t)L * 4, 0.f);
@@ -2760,6 +2764,7 @@ extern "C" int dmg1_load_clip(DmG1Handle e, int clip_id, int L, const double *q,
   }
   delete T;
   const int c = clip_id;
+  if (hipSetDevice(e->cfg.device) != hipSuccess) return g1_fail(e, DM_EHIP, "hipSetDevice failed");
   hipFree(e->dRows[c]); hipFree(e->dReset[c]); hipFree(e->dCom[c]);
   e->dRows[c] = e->dReset[c] = e->dCom[c] = nullptr;
   if (hipMalloc(&e->dRows[c], rows.size() * 4) != hipSuccess || hipMalloc(&e->dReset[c], reset.size() * 4) != hipSuccess ||
@@ -2774,15 +2779,22 @@ extern "C" int dmg1_load_clip(DmG1Handle e, int clip_id, int L, const double *q,
 
 static int g1_launch(DmG1Engine *e, g1::Launch &P, void *stream, bool time_it) {
   P.T = e->dT; P.mesh_vert = e->dMesh; P.mesh_oidx = e->dOidx; P.mesh_clus = e->dClus; P.state = e->dState; P.jt = e->dJT; P.bt = e->dBT; P.ar = e->dAR; P.rows = e->dRowsE; P.sepc = e->dSepc;
-  for (int c = 0; c < 3; c++) { P.clips[c].rows = e->dRows[c]; P.clips[c].reset = e->dReset[c]; P.clips[c].com = e->dCom[c]; P.clips[c].L = e->L[c]; P.clips[c].flags = e->flags[c]; }
+  for (int c = 0; c < DMG1_MAX_CLIPS; c++) { P.clips[c].rows = e->dRows[c]; P.clips[c].reset = e->dReset[c]; P.clips[c].com = e->dCom[c]; P.clips[c].L = e->L[c]; P.clips[c].flags = e->flags[c]; }
   P.task = e->cfg.task; P.amnesty_steps = e->cfg.amnesty_steps; P.to_getup_len = e->cfg.to_getup_len;
   P.N = e->N; P.auto_reset = e->cfg.auto_reset; P.max_ep_length = e->cfg.max_ep_length;
   P.vel_obs_scale = e->cfg.vel_obs_scale; P.high_z = e->cfg.high_z; P.obs_bound = e->cfg.obs_bound; P.seed = e->cfg.seed;
   P.debug = e->dDebug;
-  if (const char *sk = getenv("DMG1_SKIP")) P.pad = atoi(sk);   // profiling aid: bit 0 no PGS sweeps, 1 no collision, 2 no A matrix, 3 no rows, 4 no constraint solve
+  if (!e->L[0]) return g1_fail(e, DM_EINVAL, "no clip loaded (dmg1_load_clip clip 0 first)");
+  if (e->cfg.task && (e->L[1] < 1 || e->L[2] < 2)) return g1_fail(e, DM_EINVAL, "combined task needs clips 0, 1, 2 = walk, run, getup");
+  if (hipSetDevice(e->cfg.device) != hipSuccess) return g1_fail(e, DM_EHIP, "hipSetDevice failed");
+  bool lpt = true;
+#ifdef G1_PROFILE   // phase switches of the diagnostic build only: the shipped library never reads the environment on a launch
+  if (const char *sk = getenv("DMG1_SKIP")) P.pad = atoi(sk);   // bit 0 no PGS sweeps, 1 no collision, 2 no A matrix, 3 no rows, 4 no constraint solve
+  lpt = !getenv("DMG1_NO_LPT");
+#endif
   hipStream_t s = (hipStream_t)stream;
   if (time_it) hipEventRecord(e->ev0, s);
-  if (P.mode == g1::MODE_STEP && e->N >= 512 && !getenv("DMG1_NO_LPT")) {   // longest-first order from the previous step's costs
+  if (P.mode == g1::MODE_STEP && e->N >= 512 && lpt) {   // longest-first order from the previous step's costs
     hipLaunchKernelGGL(g1::g1_schedule_kernel, dim3(1), dim3(1024), 0, s, e->dCost, e->dOrder, e->N);
     P.order = e->dOrder;
   }
@@ -2850,6 +2862,11 @@ extern "C" int dmg1_set_counters(DmG1Handle e, const int32_t *idx, const int32_t
   if (eplen) hipLaunchKernelGGL(g1::g1_scatter_int_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, e->dState, e->N, g1::S_EPLEN, g1::STATE, eplen);
   return DM_OK;
 }
+extern "C" int dmg1_set_seed(DmG1Handle e, uint64_t seed) {
+  if (!e) return DM_EINVAL;
+  e->cfg.seed = seed;
+  return DM_OK;
+}
 extern "C" int dmg1_obs_dim(DmG1Handle e) { return e ? (e->cfg.task ? DMG1_NOBS_COMBINED : DMG1_NOBS) : DM_EINVAL; }
 extern "C" int dmg1_get_motion(DmG1Handle e, int32_t *motion, void *stream) {
   if (!e || !motion) return DM_EINVAL;
@@ -2861,6 +2878,8 @@ extern "C" int dmg1_set_motion(DmG1Handle e, const int32_t *motion, void *stream
   hipLaunchKernelGGL(g1::g1_scatter_int_kernel, dim3((e->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->dState, e->N, g1::S_MOTION, g1::STATE, motion);
   return DM_OK;
 }
+extern "C" int dmg1_set_env_clips(DmG1Handle e, const int32_t *clip_ids, void *stream) { return dmg1_set_motion(e, clip_ids, stream); }
+extern "C" int dmg1_get_env_clips(DmG1Handle e, int32_t *clip_ids, void *stream) { return dmg1_get_motion(e, clip_ids, stream); }
 extern "C" int dmg1_set_debug(DmG1Handle e, float *debug) {
   if (!e) return DM_EINVAL;
   e->dDebug = debug;

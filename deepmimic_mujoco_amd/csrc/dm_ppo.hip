@@ -636,11 +636,13 @@ __global__ void adam_sumsq_kernel(const float *g, int n, float *state, int bump_
   if (threadIdx.x == 0) state[2 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 __global__ void adam_update_kernel(float *p, const float *g, float *m, float *v, int n, float lr, float b1, float b2, float eps,
-                                   float max_norm, const float *state) {
+                                   float max_norm, float grad_scale, const float *state) {
   float part = 0;
   for (int i = threadIdx.x & 63; i < (int)gridDim.x; i += 64) part += state[2 + i];   // same partials, same order in every block
-  const float total = sqrtf(ppo_wave_sum(part));
-  const float coef = fminf(1.f, max_norm / (total + 1e-6f));          // clip_grad_norm_
+  // grad_scale: the gradient buffer holds grad_scale^-1 x the gradient (the SUM over ranks of an all-reduce: 1 / world); the
+  // norm and every element are scaled here instead of by an extra elementwise launch after the collective
+  const float total = grad_scale * sqrtf(ppo_wave_sum(part));
+  const float coef = grad_scale * fminf(1.f, max_norm / (total + 1e-6f));          // clip_grad_norm_
   const float t = state[1];
   const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
   const float step_size = lr / bc1;
@@ -667,26 +669,24 @@ __global__ void adam_update_kernel(float *p, const float *g, float *m, float *v,
 }
 }  // namespace
 
-extern "C" int dm_adam_clip_step(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
-                                 float max_norm, float *state2, void *stream) {
-  if (!p || !g || !m || !v || !state2 || n < 1) return -22;
+static int flat_adam_launch(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
+                            float max_norm, float grad_scale, float *state2, int state2_floats, void *stream, int begin) {
+  if (!p || !g || !m || !v || !state2 || n < 1 || !(grad_scale > 0.f)) return -22;
+  if (state2_floats < 2 + DM_ADAM_PARTIALS) return -22;   // the partial sums live behind the two scalars: a shorter buffer would be overrun
   hipStream_t s = (hipStream_t)stream;
   int blocks = (n + 256 * 8 - 1) / (256 * 8);
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(adam_sumsq_kernel, dim3(blocks), dim3(256), 0, s, g, n, state2, 1);      // step count folded in: two launches
-  hipLaunchKernelGGL(adam_update_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, max_norm, state2);
+  if (blocks > DM_ADAM_PARTIALS) blocks = DM_ADAM_PARTIALS;
+  hipLaunchKernelGGL(adam_sumsq_kernel, dim3(blocks), dim3(256), 0, s, g, n, state2, begin);      // step count folded in: two launches
+  hipLaunchKernelGGL(adam_update_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, max_norm, grad_scale, state2);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
-
-extern "C" int dm_adam_clip_update(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
-                                   float max_norm, float *state2, void *stream) {
-  if (!p || !g || !m || !v || !state2 || n < 1) return -22;
-  hipStream_t s = (hipStream_t)stream;
-  int blocks = (n + 256 * 8 - 1) / (256 * 8);
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(adam_sumsq_kernel, dim3(blocks), dim3(256), 0, s, g, n, state2, 0);
-  hipLaunchKernelGGL(adam_update_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, max_norm, state2);
-  return hipGetLastError() == hipSuccess ? 0 : -5;
+extern "C" int dm_flat_adam_step(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
+                                 float max_norm, float grad_scale, float *state2, int state2_floats, void *stream) {
+  return flat_adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, max_norm, grad_scale, state2, state2_floats, stream, 1);
+}
+extern "C" int dm_flat_adam_update(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
+                                   float max_norm, float grad_scale, float *state2, int state2_floats, void *stream) {
+  return flat_adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, max_norm, grad_scale, state2, state2_floats, stream, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -309,6 +309,35 @@ class LazyInfos(list):
     def __eq__(self, other):
         return self._all() == list(other)
 
+    __hash__ = None
+
+    # every list operation that would read the raw (unmaterialised) slots goes through _all()
+    def __add__(self, other):
+        return self._all() + list(other)
+
+    def __radd__(self, other):
+        return list(other) + self._all()
+
+    def __mul__(self, k):
+        return self._all() * k
+
+    __rmul__ = __mul__
+
+    def __reversed__(self):
+        return reversed(self._all())
+
+    def __contains__(self, item):
+        return item in self._all()
+
+    def count(self, item):
+        return self._all().count(item)
+
+    def index(self, item, *a):
+        return self._all().index(item, *a)
+
+    def __repr__(self):
+        return repr(self._all())
+
     def __reduce__(self):          # pickles / deep-copies as the plain list it stands for
         return (list, (self._all(),))
 
@@ -326,7 +355,7 @@ class HipDeepMimicVecEnv(_SB3VecEnv):
     def __new__(cls, num_envs, motion=None, robot="humanoid3d", device=0, seed=1234, auto_reset=True, sub_batches=1):
         if robot == "unitree_g1" and cls is HipDeepMimicVecEnv:
             from .g1 import HipG1VecEnv
-            return HipG1VecEnv(num_envs, motion=motion, device=device, seed=seed, auto_reset=auto_reset)
+            return HipG1VecEnv(num_envs, motion=motion, device=device, seed=seed, auto_reset=auto_reset, sub_batches=sub_batches)
         return super().__new__(cls)
 
     def __init__(self, num_envs, motion=None, robot="humanoid3d", device=0, seed=1234, auto_reset=True, sub_batches=1):
@@ -467,7 +496,18 @@ class HipDeepMimicVecEnv(_SB3VecEnv):
         return [False] * n
 
     def get_images(self):
-        raise NotImplementedError("rendering is out of scope (SURVEY §8f-4)")
+        """One frame per env in SB3; a 4 096-tile mosaic is of no use: the frame of env 0 stands for the batch."""
+        return [self.render(mode="rgb_array")]
 
     def render(self, mode=None):
-        raise NotImplementedError("rendering is out of scope (SURVEY §8f-4)")
+        """Software stick figure (render.py) of env 0 of the batch, 240 x 320 x 3 uint8 (what VecVideoRecorder-style callers get).
+        The derived arrays are refreshed by a forward evaluation and the warm start is put back: rendering is not physics."""
+        from .render import stick_figure
+        e = self.engine
+        if e._debug is None:
+            e.enable_debug()
+        q, v, w, c = e.get_state()
+        e.forward()
+        e.set_state(q, v, warm=w, ctrl=c, run_forward=False)
+        xpos = e._debug[0, :42].double().cpu().numpy().reshape(14, 3)
+        return stick_figure(xpos, self.model.body_parent)

@@ -28,7 +28,8 @@ REASONS = {0: None, 1: "low_z", 2: "high_z", 3: "max_ep_len", 4: "acyclical_end"
            7: "fallen without amnesty", 8: "run roll/pitch limit"}
 EXPORTS = ["dmg1_default_config", "dmg1_model_sizeof", "dmg1_create", "dmg1_destroy", "dmg1_last_error", "dmg1_load_clip",
            "dmg1_reset", "dmg1_step", "dmg1_step_forced", "dmg1_set_state", "dmg1_get_state", "dmg1_get_counters",
-           "dmg1_set_counters", "dmg1_set_debug", "dmg1_last_kernel_ms", "dmg1_obs_dim", "dmg1_get_motion", "dmg1_set_motion"]
+           "dmg1_set_counters", "dmg1_set_debug", "dmg1_last_kernel_ms", "dmg1_obs_dim", "dmg1_get_motion", "dmg1_set_motion",
+           "dmg1_set_seed", "dmg1_set_env_clips", "dmg1_get_env_clips"]
 
 _i32, _f64 = C.c_int32, C.c_double
 
@@ -166,6 +167,9 @@ def _lib():
         L.dmg1_get_counters.argtypes = [vp] * 5
         L.dmg1_set_counters.argtypes = [vp] * 4
         L.dmg1_set_debug.argtypes = [vp, vp]
+        L.dmg1_set_seed.argtypes = [vp, C.c_uint64]
+        L.dmg1_set_env_clips.argtypes = [vp, vp, vp]
+        L.dmg1_get_env_clips.argtypes = [vp, vp, vp]
         L.dmg1_last_kernel_ms.argtypes = [vp]
         L.dmg1_last_kernel_ms.restype = C.c_float
         if L.dmg1_model_sizeof() != C.sizeof(DmModelG1):
@@ -278,6 +282,20 @@ class G1HipEngine:
     def set_motion(self, motion):
         self._check(self.L.dmg1_set_motion(self.h, _ptr(motion), self._stream()), "dmg1_set_motion")
 
+    def set_seed(self, seed):
+        """gym.Env.seed(): re-keys the RSI reset generator (dmg1_set_seed)."""
+        self._check(self.L.dmg1_set_seed(self.h, int(seed) & 0xFFFFFFFFFFFFFFFF), "dmg1_set_seed")
+
+    def set_env_clips(self, clip_ids):
+        """DPEnv task: per-env clip id (int32 device tensor [N]) among the loaded clip slots."""
+        assert clip_ids.dtype == self.torch.int32 and clip_ids.numel() == self.N and clip_ids.is_contiguous()
+        self._check(self.L.dmg1_set_env_clips(self.h, _ptr(clip_ids), self._stream()), "dmg1_set_env_clips")
+
+    def get_env_clips(self):
+        m = self.torch.zeros(self.N, dtype=self.torch.int32, device=self.device)
+        self._check(self.L.dmg1_get_env_clips(self.h, _ptr(m), self._stream()), "dmg1_get_env_clips")
+        return m
+
     def enable_debug(self):
         self._debug = self.torch.zeros(self.N, DEBUG_STRIDE, device=self.device)
         self.L.dmg1_set_debug(self.h, _ptr(self._debug))
@@ -288,6 +306,12 @@ class G1HipEngine:
 
 
 # ------------------------------------------------------------------------------------------ Gym / VecEnv surfaces
+try:  # pragma: no cover - SB3 is not installed in the build image; with it the batch classes ARE VecEnvs (isinstance checks of wrappers)
+    from stable_baselines3.common.vec_env.base_vec_env import VecEnv as _SB3VecEnv
+except Exception:  # noqa: BLE001
+    _SB3VecEnv = object
+
+
 def _g1_mocap(motion):
     from .config import MotionConfig
     from .mocap import MocapDM
@@ -302,44 +326,80 @@ def _load(engine, mcfg, mc):
                      run_rule=mcfg.motion == "run")                                  # src/deepmimic_env.py:426
 
 
-class HipG1VecEnv:
+class HipG1VecEnv(_SB3VecEnv):
     """N ``DPEnv(robot="unitree_g1")`` instances as one HIP batch with SubprocVecEnv semantics (auto-reset,
     ``terminal_observation``): the G1 counterpart of :class:`deepmimic_env.HipDeepMimicVecEnv`, which constructs this class
-    when asked for ``robot="unitree_g1"``.  Actions are the policy's 23 values (src/deepmimic_env.py:303-307)."""
+    when asked for ``robot="unitree_g1"``.  Actions are the policy's 23 values (src/deepmimic_env.py:303-307).
+    ``motion`` may be a list (per-env clip id = env index mod len(list), as BASELINE config 5 mixes clips); ``sub_batches`` > 1
+    splits the batch into independent engines over contiguous env ranges (double-buffered rollouts, see HipDeepMimicVecEnv)."""
 
-    def __init__(self, num_envs, motion=None, device=0, seed=1234, auto_reset=True):
+    OBS_DIM, TERMS_DIM = NOBS, 5
+
+    def __init__(self, num_envs, motion=None, device=0, seed=1234, auto_reset=True, sub_batches=1):
+        from .deepmimic_env import DPEnvConfig
+        motions = [motion] if (motion is None or isinstance(motion, str)) else list(motion)
+        assert 1 <= len(motions) <= 8, "an engine holds up to 8 clips (DMG1_MAX_CLIPS)"
+        pairs = [_g1_mocap(m) for m in motions]
+        self.motion_config, self.mocap = pairs[0]
+        self.motions = [mcfg.motion for mcfg, _ in pairs]
+        self.mocaps = [mc for _, mc in pairs]
+
+        def make(nk, k):
+            e = G1HipEngine(nk, device=device, seed=seed + 104729 * k, auto_reset=auto_reset, max_ep_length=DPEnvConfig().MAX_EP_LENGTH)
+            for cid, (mcfg, mc) in enumerate(pairs):
+                e.load_clip(mc, floor=mcfg.motion in mcfg.floor_motions, acyclic=mcfg.motion in mcfg.acyclical_motions,
+                            run_rule=mcfg.motion == "run", clip_id=cid)                 # src/deepmimic_env.py:426
+            if len(pairs) > 1:
+                ids = (e.torch.arange(nk, device=e.device) + k * nk) % len(pairs)
+                e.set_env_clips(ids.to(e.torch.int32).contiguous())
+            return e
+        self._build(num_envs, sub_batches, make, scale=1.0)
+
+    def _build(self, num_envs, sub_batches, make_engine, scale):
+        """Common construction: engines over contiguous env ranges, one set of [N, ...] output tensors, spaces."""
         import torch
-        from .deepmimic_env import Box, DPEnvConfig
+        from .deepmimic_env import Box
         self._torch = torch
-        self.num_envs = int(num_envs)
+        self.num_envs, self.sub_batches = int(num_envs), int(sub_batches)
+        assert self.sub_batches >= 1 and self.num_envs % self.sub_batches == 0
+        nk = self.num_envs // self.sub_batches
         self.robot_config = RobotConfig("unitree_g1")
-        self.motion_config, self.mocap = _g1_mocap(motion)
-        self.engine = G1HipEngine(self.num_envs, device=device, seed=seed, auto_reset=auto_reset,
-                                  max_ep_length=DPEnvConfig().MAX_EP_LENGTH)
-        _load(self.engine, self.motion_config, self.mocap)
+        self.engines = [make_engine(nk, k) for k in range(self.sub_batches)]
+        self.engine = self.engines[0]
         self.model = self.engine.gmodel
         self.device = self.engine.device
-        self.out = self.engine.alloc_outputs()
-        lo, hi = self.model.act_ctrlrange[:NACT, 0].astype(np.float32), self.model.act_ctrlrange[:NACT, 1].astype(np.float32)
+        if self.sub_batches == 1:
+            self.out = self.engine.alloc_outputs()
+        else:   # every engine writes its contiguous block of rows
+            z = lambda *shape, dt=torch.float32: torch.zeros(*shape, device=self.device, dtype=dt)
+            N, D, K = self.num_envs, self.OBS_DIM, self.TERMS_DIM
+            self.out = dict(obs=z(N, D), rew=z(N), done=z(N, dt=torch.uint8), terms=z(N, K), reason=z(N, dt=torch.int32), terminal_obs=z(N, D))
+        self.sub_slices = [slice(k * nk, (k + 1) * nk) for k in range(self.sub_batches)]
+        self.sub_out = [self.out] if self.sub_batches == 1 else [{k_: v[sl] for k_, v in self.out.items()} for sl in self.sub_slices]
+        lo = self.model.act_ctrlrange[:NACT, 0].astype(np.float32) * scale
+        hi = self.model.act_ctrlrange[:NACT, 1].astype(np.float32) * scale
         self.action_space = Box(lo, hi, dtype=np.float32)            # the first N - 14 actuators (src/deepmimic_env.py:305-307)
-        self.observation_space = Box(-np.inf, np.inf, (NOBS,), np.float32)
+        self.observation_space = Box(-np.inf, np.inf, (self.OBS_DIM,), np.float32)
         self._actions = torch.zeros(self.num_envs, NACT, device=self.device)
         self.render_mode = None
         self.reset_infos = [{} for _ in range(self.num_envs)]
-        self._ppo_attrs()
-
-    def _ppo_attrs(self):   # what deepmimic_mujoco_amd.ppo reads of a batch env
-        self.engines, self.sub_batches, self.sub_slices, self.sub_out = [self.engine], 1, [slice(0, self.num_envs)], [self.out]
+        if _SB3VecEnv is not object:  # pragma: no cover
+            _SB3VecEnv.__init__(self, self.num_envs, self.observation_space, self.action_space)
 
     def step_sub(self, k, actions_k):
-        return self.step_tensor(actions_k)
+        """Step sub-batch k only (on the current stream): actions_k [N / sub_batches, 23] -> its slice of the outputs."""
+        self.engines[k].step(actions_k.contiguous(), self.sub_out[k])
+        return self.sub_out[k]
 
     def reset_tensor(self, idx_init=None):
-        self.engine.reset(self.out["obs"], idx_init=idx_init)
+        for e, o, sl in zip(self.engines, self.sub_out, self.sub_slices):
+            e.reset(o["obs"], idx_init=None if idx_init is None else idx_init[sl].contiguous())
         return self.out["obs"]
 
     def step_tensor(self, actions):
-        self.engine.step(actions.contiguous(), self.out)
+        actions = actions.contiguous()
+        for e, o, sl in zip(self.engines, self.sub_out, self.sub_slices):
+            e.step(actions[sl], o)
         return self.out
 
     def reset(self):
@@ -349,29 +409,39 @@ class HipG1VecEnv:
         t = self._torch
         self._actions.copy_(t.as_tensor(np.ascontiguousarray(actions, dtype=np.float32)).reshape(self._actions.shape))
 
-    def step_wait(self):
+    def _infos(self, terms, reason, done, tobs):
         from .deepmimic_env import LazyInfos
+        return LazyInfos(terms, reason, done, tobs)
+
+    def step_wait(self):
         t = self._torch
         out = self.step_tensor(self._actions)
         packed = t.cat([out["obs"], out["terminal_obs"], out["terms"], out["rew"][:, None], out["done"][:, None].float(),
                         out["reason"][:, None].float()], dim=1).cpu().numpy()
-        d, k = NOBS, 5
+        d, k = self.OBS_DIM, self.TERMS_DIM
         obs, tobs, terms = (np.ascontiguousarray(packed[:, 0:d]), np.ascontiguousarray(packed[:, d:2 * d]),
                             np.ascontiguousarray(packed[:, 2 * d:2 * d + k]))
         rew = packed[:, 2 * d + k].copy()
         done = packed[:, 2 * d + k + 1] != 0
         reason = packed[:, 2 * d + k + 2].astype(np.int32)
-        return obs, rew, done, LazyInfos(terms, reason, done, tobs)
+        return obs, rew, done, self._infos(terms, reason, done, tobs)
 
     def step(self, actions):
         self.step_async(actions)
         return self.step_wait()
 
     def close(self):
-        self.engine.close()
+        for e in getattr(self, "engines", []):
+            e.close()
 
     def seed(self, seed=None):
-        return [None if seed is None else int(seed) + i for i in range(self.num_envs)]
+        """SB3 VecEnv.seed: env i gets seed + i.  Here: re-keys the engines' counter-based RSI generator (dmg1_set_seed; env index
+        and reset count are part of the key already) and returns the per-env seeds SB3 expects."""
+        if seed is None:
+            return [None] * self.num_envs
+        for k, e in enumerate(self.engines):
+            e.set_seed(int(seed) + 104729 * k)
+        return [int(seed) + i for i in range(self.num_envs)]
 
     # ---- the rest of SB3's VecEnv surface (same conventions as HipDeepMimicVecEnv: one batch object stands for all envs)
     def _n_indices(self, indices):
@@ -397,10 +467,21 @@ class HipG1VecEnv:
         return self
 
     def get_images(self):
-        return [None] * self.num_envs
+        """One frame per env in SB3; a 4 096-tile mosaic is of no use: the frame of env 0 stands for the batch."""
+        return [self.render(mode="rgb_array")]
 
     def render(self, mode=None):
-        return None
+        """Software stick figure (render.py) of env 0 of the batch, 240 x 320 x 3 uint8 — what VecVideoRecorder-style callers get.
+        The forward evaluation that refreshes the body poses puts the warm start back: rendering never changes the physics."""
+        from .render import stick_figure
+        e = self.engine
+        if e._debug is None:
+            e.enable_debug()
+        q, v, w = e.get_state()
+        e.set_state(q, v, warm=w, run_forward=True)
+        e.set_state(q, v, warm=w, run_forward=False)
+        xpos = e._debug[0, :117].double().cpu().numpy().reshape(39, 3)
+        return stick_figure(xpos, self.model.body_parent)
 
 
 class G1DPEnv:
@@ -526,37 +607,21 @@ class HipG1CombinedVecEnv(HipG1VecEnv):
     """N ``DPCombinedEnv()`` instances — the reference's training environment (src/sb3_ppo.py:277-278): Unitree G1, walk / run /
     getup / to_getup motion state machine, obs 98, 23 actions — as one HIP batch with SubprocVecEnv semantics."""
 
-    def __init__(self, num_envs, device=0, seed=1234, auto_reset=True):
-        import torch
-        from .deepmimic_env import Box
-        self._torch = torch
-        self.num_envs = int(num_envs)
-        self.robot_config = RobotConfig("unitree_g1")
-        self.engine, self.mocaps = _combined_engine(self.num_envs, device, seed, auto_reset)
-        self.model = self.engine.gmodel
-        self.device = self.engine.device
-        self.out = self.engine.alloc_outputs()
-        lo, hi = self.model.act_ctrlrange[:NACT, 0].astype(np.float32) / 20.0, self.model.act_ctrlrange[:NACT, 1].astype(np.float32) / 20.0
-        self.action_space = Box(lo, hi, dtype=np.float32)            # ctrlrange / ACT_SCALE (src/combined_env.py:196-200)
-        self.observation_space = Box(-np.inf, np.inf, (NOBS_COMBINED,), np.float32)
-        self._actions = torch.zeros(self.num_envs, NACT, device=self.device)
-        self.render_mode = None
-        self.reset_infos = [{} for _ in range(self.num_envs)]
-        self._ppo_attrs()
+    OBS_DIM, TERMS_DIM = NOBS_COMBINED, 8
 
-    def step_wait(self):
+    def __init__(self, num_envs, device=0, seed=1234, auto_reset=True, sub_batches=1):
+        self.mocaps = None
+
+        def make(nk, k):
+            e, mocaps = _combined_engine(nk, device, seed + 104729 * k, auto_reset)
+            self.mocaps = self.mocaps or mocaps
+            return e
+        self._build(num_envs, sub_batches, make, scale=1.0 / 20.0)      # action space = ctrlrange / ACT_SCALE (src/combined_env.py:196-200)
+        self.mocap = self.mocaps[0]
+
+    def _infos(self, terms, reason, done, tobs):
         from .combined_env import _LazyCombinedInfos
-        t = self._torch
-        out = self.step_tensor(self._actions)
-        packed = t.cat([out["obs"], out["terminal_obs"], out["terms"], out["rew"][:, None], out["done"][:, None].float(),
-                        out["reason"][:, None].float()], dim=1).cpu().numpy()
-        d, k = NOBS_COMBINED, 8
-        obs, tobs, terms = (np.ascontiguousarray(packed[:, 0:d]), np.ascontiguousarray(packed[:, d:2 * d]),
-                            np.ascontiguousarray(packed[:, 2 * d:2 * d + k]))
-        rew = packed[:, 2 * d + k].copy()
-        done = packed[:, 2 * d + k + 1] != 0
-        reason = packed[:, 2 * d + k + 2].astype(np.int32)
-        return obs, rew, done, _LazyCombinedInfos(terms, reason, done, tobs)
+        return _LazyCombinedInfos(terms, reason, done, tobs)
 
 
 class G1CombinedEnv:

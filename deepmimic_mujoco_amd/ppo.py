@@ -477,7 +477,7 @@ class FlatGradAllReduce:
 
 
 class FlatAdam:
-    """clip_grad_norm_ + Adam on one flat buffer (`dm_adam_clip_step`, csrc/dm_ppo.hip): every parameter of the policy
+    """clip_grad_norm_ + Adam on one flat buffer (`dm_flat_adam_step`, csrc/dm_ppo.hip): every parameter of the policy
     becomes a view of `flat_p`, every gradient is gathered in `flat_g` (the HipLinear layers write theirs there
     directly), and the whole update is two launches.  With several ranks `flat_g` is also what is all-reduced: the
     one collective of the data-parallel learner, without staging copies.  GPU only; `state` mimics torch.optim's layout
@@ -535,10 +535,15 @@ class FlatAdam:
                 g.copy_(p.grad)
 
     def all_reduce(self):
+        """The ONE collective of the data-parallel learner: sum of the flat gradient over the ranks, in place.  The division by
+        the world size is not a launch of its own: `step()` hands 1 / world to the update kernel as `grad_scale`."""
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
-            self.flat_g.div_(dist.get_world_size())
             self.calls += 1
+
+    @property
+    def grad_scale(self):
+        return 1.0 / dist.get_world_size() if (dist.is_initialized() and dist.get_world_size() > 1) else 1.0
 
     def step(self, begin=True):
         """begin=False: state2 was prepared by dm_ppo_mlp_grad (adam_state2 fold) — two launches instead of three."""
@@ -546,11 +551,12 @@ class FlatAdam:
         from . import _lib
         p = lambda t: C.c_void_p(t.data_ptr())
         L = _lib.load_library()
-        rc = (L.dm_adam_clip_step if begin else L.dm_adam_clip_update)(p(self.flat_p), p(self.flat_g), p(self.m), p(self.v), self.n, self.lr,
-                                                   self.betas[0], self.betas[1], self.eps, self.max_grad_norm, p(self.state2),
+        rc = (L.dm_flat_adam_step if begin else L.dm_flat_adam_update)(p(self.flat_p), p(self.flat_g), p(self.m), p(self.v), self.n, self.lr,
+                                                   self.betas[0], self.betas[1], self.eps, self.max_grad_norm, self.grad_scale,
+                                                   p(self.state2), int(self.state2.numel()),
                                                    C.c_void_p(torch.cuda.current_stream(self.flat_p.device).cuda_stream))
         if rc != 0:
-            raise RuntimeError("dm_adam_clip_step failed (%d)" % rc)
+            raise RuntimeError("dm_flat_adam_step failed (%d)" % rc)
         if self.flat_pb is not None:
             self.flat_pb.copy_(self.flat_p)
 
@@ -559,7 +565,13 @@ class FlatAdam:
                 "lr": self.lr, "betas": self.betas, "eps": self.eps, "max_grad_norm": self.max_grad_norm}
 
     def load_state_dict(self, sd):
-        self.m.copy_(sd["exp_avg"]); self.v.copy_(sd["exp_avg_sq"]); self.state2.copy_(sd["state2"])
+        self.m.copy_(sd["exp_avg"]); self.v.copy_(sd["exp_avg_sq"])
+        # state2 = [scratch, step count, per-block partial sums]: only the step count is state.  Checkpoints written before the
+        # fixed-order norm (r1 / early r2, incl. the eval dashboard's "_best" models) carry two floats: take those, zero the rest.
+        st2 = sd["state2"].to(self.state2.device).reshape(-1)
+        k = min(int(st2.numel()), int(self.state2.numel()))
+        self.state2.zero_()
+        self.state2[:k].copy_(st2[:k])
         self.lr, self.betas, self.eps = sd["lr"], tuple(sd["betas"]), sd["eps"]
 
 
@@ -642,7 +654,7 @@ class PPO:
             # draw counters, advanced on the device: ONE PER SUB-BATCH — sub-batch chains run on their own streams (or as
             # independent branches of a captured graph), so a shared counter bumped by one chain would be read by the
             # others at unordered times (same noise at consecutive steps, non-reproducible rollouts)
-            self._rctrs = torch.zeros(16, dtype=torch.int32, device=self.device)
+            self._rctrs = torch.zeros(max(16, int(getattr(self.env, "sub_batches", 1))), dtype=torch.int32, device=self.device)
             self._rctr = self._rctrs[0:1]
         return sc[key]
 
@@ -921,13 +933,15 @@ class PPO:
             acc = self._loss_acc if on_dev else torch.stack([eg["loss"], torch.full((), float(nsteps), device=self.device)])
             self.stats["loss"] = float(acc[0] / torch.clamp(acc[1], min=1.0))
             return self.stats["loss"]
-        if self._dist_graph_ok(flat, n, on_dev):
-            # several ranks: a minibatch is [graph A: gather + dm_ppo_mlp_grad] -> all-reduce of the flat gradient (the ONE
-            # collective, eager, on the same stream) -> [graph B: dm_adam_clip_update]: three host calls and no eager
-            # kernel launches, instead of falling back to the un-captured step
+        if self._dist_graph_ok(flat, n):
+            # several ranks: a minibatch is [graph A: gather + minibatch gradient (dm_ppo_mlp_grad, or for nets beyond its class
+            # the library-GEMM forward / loss / backward incl. dm_linear_tanh, dm_tanh_linear_wgrad, dm_ppo_loss)] -> all-reduce of
+            # the flat gradient (the ONE collective, eager, on the same stream) -> [graph B: dm_flat_adam_step / _update with
+            # grad_scale = 1 / world]: three host calls and no eager kernel launches, instead of the un-captured step
             dg = self._dist_graphs(flat, n)
             for k in dg["flat"]:
                 dg["flat"][k].copy_(flat[k])
+            dg["loss"].zero_()
             B = self.batch_size
             for _ in range(self.n_epochs):
                 torch.randperm(n, device=self.device, generator=generator, out=dg["perm"])
@@ -937,7 +951,8 @@ class PPO:
                     self.optimizer.all_reduce()
                     dg["adam"].replay()
                     nsteps += 1
-            self.stats["loss"] = float(self._loss_acc[0] / torch.clamp(self._loss_acc[1], min=1.0))
+            acc = self._loss_acc if on_dev else torch.stack([dg["loss"], torch.full((), float(nsteps), device=self.device)])
+            self.stats["loss"] = float(acc[0] / torch.clamp(acc[1], min=1.0))
             return self.stats["loss"]
         for _ in range(self.n_epochs):
             perm = torch.randperm(n, device=self.device, generator=generator)
@@ -992,9 +1007,11 @@ class PPO:
         return FusedPPOLoss.apply(mean, self.policy.log_std, value, act, old_logp, adv, ret, self.clip_range, self.vf_coef,
                                   self.ent_coef, self.normalize_advantage and obs.shape[0] > 1)
 
-    def _minibatch_step(self, obs, act, adv, ret, old_logp):
-        if (self.flat_adam and self.fused_mlp and self.fused_loss and obs.is_cuda
-                and FusedMlpGrad.supported(self.policy, obs.shape[0])):
+    def _minibatch_grad(self, obs, act, adv, ret, old_logp):
+        """Gradient half of an optimizer step on the flat-Adam paths: leaves the minibatch gradient in ``optimizer.flat_g``
+        (the operand of the ONE collective of the data-parallel learner).  Returns (loss, begin): begin is False when Adam's
+        begin launch was folded into the gradient launches (dm_ppo_mlp_grad)."""
+        if (self.fused_mlp and self.fused_loss and obs.is_cuda and FusedMlpGrad.supported(self.policy, obs.shape[0])):
             # the whole minibatch gradient in three launches, written into the flat arena
             # (that launch sequence also clears the arena, performs Adam's begin and adds the loss to a device-side sum)
             mg = self._mlp_grads.get(obs.shape[0])
@@ -1002,36 +1019,33 @@ class PPO:
                 mg = self._mlp_grads[obs.shape[0]] = FusedMlpGrad(self.policy, self.optimizer, obs.shape[0], loss_acc=self._loss_acc)
             loss = mg(obs.contiguous(), act.contiguous(), adv.contiguous(), ret.contiguous(), old_logp.contiguous(), self.clip_range,
                       self.vf_coef, self.ent_coef, self.normalize_advantage and obs.shape[0] > 1)
-            self.optimizer.all_reduce()
-            self.optimizer.step(begin=False)
-            return loss
-        if self.flat_adam:
-            # every gradient lands in one flat buffer (one memset), clipping + Adam are one fused update on it, and
-            # with several ranks that buffer is the operand of the ONE collective of the data-parallel learner
-            self.optimizer.zero_grad()
-            if self.fused_loss and obs.is_cuda:
-                mean, value = self._trunks(obs)
-                gls = self.optimizer.slices[[id(q) for q in self.optimizer.params].index(id(self.policy.log_std))]
-                loss, gm, gv = FusedPPOLoss.raw(mean.contiguous(), self.policy.log_std, value.contiguous(), act, old_logp, adv, ret,
-                                                self.clip_range, self.vf_coef, self.ent_coef,
-                                                self.normalize_advantage and obs.shape[0] > 1, grad_log_std=gls)
-                torch.autograd.backward([mean, value], [gm, gv])
-                if getattr(self, "_vf_stream", None) is not None:
-                    torch.cuda.current_stream(obs.device).wait_stream(self._vf_stream)
-                self.optimizer.gather_grads()
-                self.optimizer.all_reduce()
-                self.optimizer.step()
-                return loss.detach()
+            return loss, False
+        # library-GEMM learner (nets beyond the [256,128] class): every gradient lands in one flat buffer (one memset)
+        self.optimizer.zero_grad()
+        if self.fused_loss and obs.is_cuda:
+            mean, value = self._trunks(obs)
+            gls = self.optimizer.slices[[id(q) for q in self.optimizer.params].index(id(self.policy.log_std))]
+            loss, gm, gv = FusedPPOLoss.raw(mean.contiguous(), self.policy.log_std, value.contiguous(), act, old_logp, adv, ret,
+                                            self.clip_range, self.vf_coef, self.ent_coef,
+                                            self.normalize_advantage and obs.shape[0] > 1, grad_log_std=gls)
+            torch.autograd.backward([mean, value], [gm, gv])
+        else:
             loss = (self._loss_fused if self.fused_loss else self._loss_torch)(obs, act, adv, ret, old_logp)
             loss.backward()
-            if getattr(self, "_vf_stream", None) is not None:
-                # the layer kernels of the value trunk hand no gradient tensor to autograd (they write flat_g), so the
-                # engine has no leaf to synchronise on: join the second stream explicitly before the update
-                torch.cuda.current_stream(obs.device).wait_stream(self._vf_stream)
-            self.optimizer.gather_grads()
+        if getattr(self, "_vf_stream", None) is not None:
+            # the layer kernels of the value trunk hand no gradient tensor to autograd (they write flat_g), so the
+            # engine has no leaf to synchronise on: join the second stream explicitly before the update
+            torch.cuda.current_stream(obs.device).wait_stream(self._vf_stream)
+        self.optimizer.gather_grads()
+        return loss.detach(), True
+
+    def _minibatch_step(self, obs, act, adv, ret, old_logp):
+        if self.flat_adam:
+            # clipping + Adam are one fused update on the flat buffer; with several ranks that buffer is all-reduced in between
+            loss, begin = self._minibatch_grad(obs, act, adv, ret, old_logp)
             self.optimizer.all_reduce()
-            self.optimizer.step()
-            return loss.detach()
+            self.optimizer.step(begin=begin)
+            return loss
         loss = (self._loss_fused if (self.fused_loss and obs.is_cuda) else self._loss_torch)(obs, act, adv, ret, old_logp)
         # grads are re-created by backward (no zero-fill, no accumulate-add per parameter); inside a captured
         # hipGraph they live in the graph's private pool, so their addresses are the same at every replay
@@ -1103,8 +1117,9 @@ class PPO:
         return (self.use_hip_graph and self.device.type == "cuda" and n % self.batch_size == 0 and self.epoch_graph
                 and all(flat[k].dtype == torch.float32 for k in ("obs", "act", "adv", "ret", "logp")))
 
-    def _dist_graph_ok(self, flat, n, on_dev):
-        return (self.dist_graph and on_dev and dist.is_initialized() and dist.get_world_size() > 1
+    def _dist_graph_ok(self, flat, n):
+        return (self.dist_graph and self.flat_adam and self.device.type == "cuda" and n % self.batch_size == 0
+                and dist.is_initialized() and dist.get_world_size() > 1
                 and all(flat[k].dtype == torch.float32 for k in ("obs", "act", "adv", "ret", "logp")))
 
     def _dist_graphs(self, flat, n):
@@ -1113,20 +1128,19 @@ class PPO:
         if dg is not None and dg["n"] == n:
             return dg
         dev, B = self.device, self.batch_size
-        dg = dict(n=n, perm=torch.arange(n, device=dev), idx=torch.arange(B, device=dev),
+        dg = dict(n=n, perm=torch.arange(n, device=dev), idx=torch.arange(B, device=dev), loss=torch.zeros((), device=dev), begin=True,
                   flat={k: torch.zeros_like(flat[k]) for k in ("obs", "act", "adv", "ret", "logp")})
         gin = self._static_minibatch()
-        mg = self._mlp_grads.get(B)
-        if mg is None:
-            mg = self._mlp_grads[B] = FusedMlpGrad(self.policy, self.optimizer, B, loss_acc=self._loss_acc)
-        norm = self.normalize_advantage and B > 1
+        kw = {("old_logp" if k == "logp" else k): v for k, v in gin.items()}
 
         def grad():
             self._gather_minibatch(dg["flat"], dg["idx"], gin)
-            return mg(gin["obs"], gin["act"], gin["adv"], gin["ret"], gin["logp"], self.clip_range, self.vf_coef, self.ent_coef, norm)
+            loss, dg["begin"] = self._minibatch_grad(**kw)
+            if not self._on_dev:
+                dg["loss"].add_(loss)
 
         def adam():
-            self.optimizer.step(begin=False)
+            self.optimizer.step(begin=dg["begin"])
 
         def warm():              # local only: no collective during warm-up / capture, every rank does the same
             grad()

@@ -32,6 +32,7 @@ typedef struct DmG1Engine *DmG1Handle;
 #define DMG1_MAXCON 48  /* contact slots per forward evaluation (MuJoCo: nconmax 200, xml :10) */
 #define DMG1_MAXROW 256 /* constraint rows per forward evaluation: 37 friction-loss + limits + 4 per contact */
 #define DMG1_DEBUG_STRIDE 1024
+#define DMG1_MAX_CLIPS 8   /* clip slots per engine (as DM_MAX_CLIPS of deepmimic_hip.h) */
 
 typedef struct DmG1Config {
   int32_t num_envs;
@@ -60,7 +61,8 @@ const char *dmg1_last_error(DmG1Handle h);
 
 /* Replaces DPEnv.load_mocap (src/deepmimic_env.py:321-324): HOST float64 tables of MocapDM(robot="unitree_g1"):
  * qpos[L*44], qvel[L*43], body_xpos[L*39*3], geom_xpos[L*94*3].  flags: 1 floor motion, 2 acyclical motion
- * (src/config.py:36-37), 4 the "run" roll / pitch rule (src/deepmimic_env.py:426-433).  clip_id 0 (DPEnv) or 0..2. */
+ * (src/config.py:36-37), 4 the "run" roll / pitch rule (src/deepmimic_env.py:426-433).  clip_id 0..DMG1_MAX_CLIPS-1; the
+ * DPCombinedEnv task reads slots 0, 1, 2 = walk, run, getup. */
 int dmg1_load_clip(DmG1Handle h, int clip_id, int L, const double *host_qpos, const double *host_qvel, const double *host_body_xpos,
                    const double *host_geom_xpos, int flags);
 
@@ -88,8 +90,15 @@ int dmg1_set_counters(DmG1Handle h, const int32_t *idx_curr, const int32_t *epis
 
 /* Row width of the obs buffers for the configured task (85 / 98); per-env motion id of the DPCombinedEnv task
  * (env.current_motion_mocap, combined_env.py:190; under that task dmg1_get/set_counters' idx_curr is current_motion_n_steps). */
+/* Replaces: gym.Env.seed() / VecEnv.seed() (random.seed for reference_state_init, src/deepmimic_env.py:313): re-keys the
+ * counter-based generator of the random-frame (RSI) resets.  Takes effect from the next launch. */
+int dmg1_set_seed(DmG1Handle h, uint64_t seed);
 int dmg1_obs_dim(DmG1Handle h);
 int dmg1_get_motion(DmG1Handle h, int32_t *motion, void *stream);
+/* DPEnv task: per-env clip id (one `DPEnv(motion=...)` per SubprocVecEnv worker in the reference; multi-clip batches as in
+ * BASELINE config 5) — the same state slot as the motion id of the combined task.  clip_ids device int32[N]. */
+int dmg1_set_env_clips(DmG1Handle h, const int32_t *clip_ids, void *stream);
+int dmg1_get_env_clips(DmG1Handle h, int32_t *clip_ids, void *stream);
 int dmg1_set_motion(DmG1Handle h, const int32_t *motion, void *stream);
 
 /* Parity-test hook: per-env dump of the last forward evaluation, float[N*DMG1_DEBUG_STRIDE] (NULL switches it off):

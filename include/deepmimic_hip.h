@@ -207,14 +207,17 @@ int dm_ppo_gather(const long long *idx, int B, const float *obs, int D, const fl
 
 /* torch.nn.utils.clip_grad_norm_(max_norm) + torch.optim.Adam.step() [EXT, as used by SB3's PPO.train] on one flat
  * parameter / gradient / moment buffer of n floats.  state2 = {scratch, step count, DM_ADAM_PARTIALS partial sums} on the
- * device: 2 + DM_ADAM_PARTIALS floats, zero-initialised by the caller once; no weight decay, no amsgrad.  The gradient
- * norm is reduced in a fixed order, so replicas holding the same (all-reduced) gradient stay bit-identical. */
+ * device, zero-initialised by the caller once; its length is passed (state2_floats >= 2 + DM_ADAM_PARTIALS, else -22: r2's
+ * two-float buffer would be overrun, hence also the new names).  grad_scale > 0 multiplies the gradient on the fly: 1 on one
+ * GPU, 1 / world after the sum all-reduce of the data-parallel learner (no separate division launch).  No weight decay, no
+ * amsgrad.  The gradient norm is reduced in a fixed order, so replicas holding the same (all-reduced) gradient stay
+ * bit-identical. */
 #define DM_ADAM_PARTIALS 1024
-int dm_adam_clip_step(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
-                      float max_norm, float *state2, void *stream);
+int dm_flat_adam_step(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
+                      float max_norm, float grad_scale, float *state2, int state2_floats, void *stream);
 /* the same without the begin launch (state2 prepared by dm_ppo_mlp_grad's adam_state2 fold): two launches */
-int dm_adam_clip_update(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
-                        float max_norm, float *state2, void *stream);
+int dm_flat_adam_update(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
+                        float max_norm, float grad_scale, float *state2, int state2_floats, void *stream);
 
 /* out[o] += sum_b Y[b][o] for a row-major [B x O] matrix (out zeroed by the caller, stream-ordered): the bias gradient of the
  * nn.Linear layers of PPO.train [EXT] whose weight gradient stays on the library GEMM (layers beyond 256 units). */
@@ -281,7 +284,7 @@ typedef struct DmPpoMlpStep {
   /* optional folds (NULL / 0 to skip), each saving one launch of the optimizer step: */
   float *zero_ptr;              /* zero_floats floats cleared by the first launch (the flat gradient arena that holds gW / gb / g_log_std) */
   long long zero_floats;
-  float *adam_state2;           /* dm_adam_clip_step's begin (state2[0] = 0, state2[1] += 1): follow with dm_adam_clip_update */
+  float *adam_state2;           /* dm_flat_adam_step's begin (state2[0] = 0, state2[1] += 1): follow with dm_flat_adam_update */
   float *loss_acc;              /* loss_acc[0] += loss, loss_acc[1] += 1 (running mean of the loss without a host-side add) */
 } DmPpoMlpStep;
 long long dm_ppo_mlp_workspace_floats(int B, int D, int H1, int H2, int A);

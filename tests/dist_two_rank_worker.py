@@ -15,7 +15,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
+    ap.add_argument("--arch", default="256,128", help="hidden sizes: 256,128 (dm_ppo_mlp_grad) or 1024,512 (library-GEMM learner, BASELINE cfg3-5)")
     args = ap.parse_args()
+    arch = tuple(int(x) for x in args.arch.split(","))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo")
     rank = dist.get_rank()
@@ -25,7 +27,7 @@ def main():
     res = {}
     for tag, dg in (("graph", True), ("eager", False)):
         env = HipDeepMimicVecEnv(64, motion="spinkick", device=0, seed=1234 + 7919 * rank)
-        ppo = PPO(env, net_arch=(256, 128), n_steps=6, batch_size=128, n_epochs=1, seed=3, dist_graph=dg)
+        ppo = PPO(env, net_arch=arch, n_steps=6, batch_size=128, n_epochs=1, seed=3, dist_graph=dg)
         buf = ppo.collect_rollouts()
         with torch.no_grad():
             mean = ppo.policy.action_net(ppo.policy.pi(buf["obs"].reshape(-1, 67)))

@@ -1,7 +1,7 @@
 """The multi-GPU learner path as it runs on GPUs, rehearsed with two ranks on the one GPU of the test box (gloo).
 
 Covers what the CPU gloo test (tests/test_ppo_cpu.py) cannot: `FlatAdam.all_reduce` on the device-resident flat gradient
-(deepmimic_mujoco_amd/ppo.py), the [gather + dm_ppo_mlp_grad] / [dm_adam_clip_update] graphs captured around it, and the
+(deepmimic_mujoco_amd/ppo.py), the [gather + dm_ppo_mlp_grad] / [dm_flat_adam_update] graphs captured around it, and the
 per-rank exploration noise of the fused samplers."""
 import os
 import subprocess
@@ -13,11 +13,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_two_ranks_one_gpu_flat_adam_allreduce(tmp_path):
+@pytest.mark.parametrize("arch", ["256,128", "1024,512"])
+def test_two_ranks_one_gpu_flat_adam_allreduce(tmp_path, arch):
+    """arch 256,128: graph A = gather + dm_ppo_mlp_grad; 1024,512 (the net BASELINE configs 3-5 name): graph A = gather + the
+    library-GEMM forward / dm_ppo_loss / backward (dm_linear_tanh, dm_tanh_linear_wgrad, ...) — VERDICT r2 item 3."""
     import torch
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "tests", "dist_two_rank_worker.py"), "--out", str(tmp_path)]
+           "--master-port", "29533" if arch == "256,128" else "29534", os.path.join(ROOT, "tests", "dist_two_rank_worker.py"),
+           "--out", str(tmp_path), "--arch", arch]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     a, b = (torch.load(os.path.join(tmp_path, "rank%d.pt" % k)) for k in (0, 1))

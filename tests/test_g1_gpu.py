@@ -330,6 +330,75 @@ def test_g1_combined_surfaces():
     venv.close()
 
 
+def test_g1_multi_clip_batches_and_sub_batches_replay_bit_equal():
+    """`HipDeepMimicVecEnv(robot="unitree_g1", motion=[...], sub_batches=2)` — per-env clip ids
+    (dmg1_set_env_clips, env i follows clip i mod 3) and two engines over contiguous halves.  Twin-env replay: the same actions
+    through a one-engine batch and a two-engine batch, and through per-clip single-clip batches, give bit-equal trajectories."""
+    import torch
+    from deepmimic_mujoco_amd.deepmimic_env import HipDeepMimicVecEnv
+    from deepmimic_mujoco_amd import g1
+    motions = ["walk", "run", "getup_facedown"]
+    n = 24
+    a = HipDeepMimicVecEnv(n, motion=motions, robot="unitree_g1", seed=5, auto_reset=False)
+    b = HipDeepMimicVecEnv(n, motion=motions, robot="unitree_g1", seed=5, auto_reset=False, sub_batches=2)
+    assert isinstance(b, g1.HipG1VecEnv) and len(b.engines) == 2 and b.sub_slices == [slice(0, 12), slice(12, 24)]
+    assert a.engine.get_env_clips().tolist() == [i % 3 for i in range(n)]
+    assert b.engines[1].get_env_clips().tolist() == [(12 + i) % 3 for i in range(12)]
+    idx = (torch.arange(n, device=a.device, dtype=torch.int32) * 2) % 40
+    oa, ob = a.reset_tensor(idx).clone(), b.reset_tensor(idx).clone()
+    assert torch.equal(oa, ob)
+    singles = []
+    for cid, m in enumerate(motions):           # the envs of clip cid as their own single-clip batch
+        env = HipDeepMimicVecEnv(n // 3, motion=m, robot="unitree_g1", seed=5, auto_reset=False)
+        o = env.reset_tensor(idx[cid::3].contiguous())
+        assert torch.equal(o, oa[cid::3])
+        singles.append(env)
+    g = torch.Generator(device=a.device).manual_seed(3)
+    for t in range(6):
+        act = (torch.rand(n, 23, device=a.device, generator=g) * 2 - 1) * 0.3
+        ra = {k: v.clone() for k, v in a.step_tensor(act).items()}
+        rb = b.step_tensor(act)
+        for k in ("obs", "rew", "done", "terms", "reason"):
+            assert torch.equal(ra[k], rb[k]), (t, k)
+        for cid, env in enumerate(singles):
+            rs = env.step_tensor(act[cid::3].contiguous())
+            assert torch.equal(rs["obs"], ra["obs"][cid::3]) and torch.equal(rs["rew"], ra["rew"][cid::3]), (t, cid)
+    # getup_facedown is a floor motion: no low_z termination for its envs, while walk / run envs pressed to the floor would end
+    assert int(ra["reason"][2::3].max()) in (0, 3, 4)
+    sub = b.step_sub(1, act[12:].contiguous())
+    assert sub["obs"].shape == (12, 85)
+    for e in (a, b, *singles):
+        e.close()
+
+
+def test_g1_vecenv_seed_rekeys_rsi_and_batch_render_returns_a_frame():
+    """`seed()` on the G1 batch envs re-keys the RSI generator (dmg1_set_seed); `render()` / `get_images()` of a batch
+    return the frame of env 0 instead of raising or returning None, without disturbing the physics."""
+    import torch
+    from deepmimic_mujoco_amd.combined_env import HipCombinedVecEnv
+    from deepmimic_mujoco_amd.deepmimic_env import HipDeepMimicVecEnv
+
+    def frames(env, seed):
+        assert env.seed(seed) == [seed + i for i in range(env.num_envs)]
+        env.reset_tensor()
+        return env.engine.get_counters()[0].clone()
+    for make in (lambda: HipDeepMimicVecEnv(32, motion="walk", robot="unitree_g1", seed=1),
+                 lambda: HipCombinedVecEnv(32, seed=1, sub_batches=2),
+                 lambda: HipDeepMimicVecEnv(32, motion="walk", seed=1),
+                 lambda: HipCombinedVecEnv(32, robot="humanoid3d", seed=1)):
+        env, other, twin = make(), make(), make()      # (the RSI key is (seed, env, reset count): compare first resets of fresh batches)
+        f1, f2, f1t = frames(env, 11), frames(other, 12), frames(twin, 11)
+        assert torch.equal(f1, f1t) and not torch.equal(f1, f2), type(env).__name__
+        other.close()
+        img = env.render(mode="rgb_array")
+        assert img.shape == (240, 320, 3) and img.dtype == np.uint8 and len(np.unique(img.reshape(-1, 3), axis=0)) >= 4
+        assert len(env.get_images()) == 1
+        act = torch.zeros(32, env.action_space.shape[0], device=env.device)
+        o1, o2 = env.step_tensor(act)["obs"].clone(), twin.step_tensor(act)["obs"].clone()
+        assert torch.equal(o1, o2), "render changed the physics"
+        env.close(); twin.close()
+
+
 def test_ppo_iteration_on_the_g1_combined_env():
     """The reference's training setup (src/sb3_ppo.py:249-313: PPO on DPCombinedEnv(), Unitree G1, MLP [256,128]) on the device-
     resident loop: one-launch policy forward (D = 98, A = 23), dmg1_step, fused learner; one iteration changes the weights,

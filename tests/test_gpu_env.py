@@ -494,7 +494,7 @@ def test_big_net_learner_step_matches_plain_autograd():
 
 
 def test_flat_adam_matches_clip_grad_norm_plus_torch_adam():
-    """dm_adam_clip_step on the flat buffers against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam (fused) over
+    """dm_flat_adam_step on the flat buffers against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam (fused) over
     several optimizer steps of the same minibatches, with every custom piece on (fused loss, HipLinear) on one side
     and plain PyTorch on the other."""
     import torch
@@ -521,6 +521,40 @@ def test_flat_adam_matches_clip_grad_norm_plus_torch_adam():
     for n in results[0]:
         a, b = results[0][n], results[1][n]
         assert float((a - b).abs().max()) < 2e-4 * (float(a.abs().max()) + 1e-3), n
+
+
+def test_flat_adam_abi_checks_state2_and_loads_r2_checkpoints(tmp_path):
+    """the partial sums of the gradient norm live behind the two scalars of state2 — the entry points take the buffer
+    length and refuse a short one (r2's 2-float buffer would be overrun); checkpoints written with the 2-float state2 load."""
+    import ctypes as C
+    import torch
+    from deepmimic_mujoco_amd import _lib
+    from deepmimic_mujoco_amd.deepmimic_env import HipDeepMimicVecEnv
+    from deepmimic_mujoco_amd.ppo import PPO
+    L = _lib.load_library()
+    dev = torch.device("cuda", 0)
+    n = 1000
+    p_, g_, m_, v_ = (torch.zeros(n, device=dev) for _ in range(4))
+    st = torch.zeros(2, device=dev)
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    s0 = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    assert L.dm_flat_adam_step(vp(p_), vp(g_), vp(m_), vp(v_), n, 1e-3, 0.9, 0.999, 1e-5, 0.5, 1.0, vp(st), 2, s0) == -22
+    assert L.dm_flat_adam_step(vp(p_), vp(g_), vp(m_), vp(v_), n, 1e-3, 0.9, 0.999, 1e-5, 0.5, 0.0, vp(st), 2 + 1024, s0) == -22
+    env = HipDeepMimicVecEnv(32, motion="walk", seed=1)
+    ppo = PPO(env, n_steps=4, batch_size=64, n_epochs=1, seed=0)
+    ppo.learn(32 * 4, log_interval=0)
+    sd = ppo.optimizer.state_dict()
+    steps = float(sd["state2"][1])
+    assert steps >= 1 and sd["state2"].numel() == 2 + 1024
+    old = dict(sd, state2=sd["state2"][:2].clone())                   # what r1 / early r2 wrote
+    path = str(tmp_path / "old.pt")
+    torch.save({"policy": ppo.policy.state_dict(), "optimizer": old, "num_timesteps": ppo.num_timesteps}, path)
+    ppo2 = PPO(env, n_steps=4, batch_size=64, n_epochs=1, seed=1).load(path)
+    assert float(ppo2.optimizer.state2[1]) == steps and float(ppo2.optimizer.state2[2:].abs().max()) == 0.0
+    assert torch.equal(ppo2.optimizer.m, ppo.optimizer.m)
+    ppo2.learn(2 * 32 * 4, log_interval=0)                           # and keeps training from there (num_timesteps was restored)
+    assert float(ppo2.optimizer.state2[1]) > steps
+    env.close()
 
 
 def test_sub_batched_vecenv_and_captured_rollout(model):

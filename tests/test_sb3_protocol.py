@@ -85,6 +85,22 @@ def test_lazyinfos_is_a_list_with_lazy_dicts():
     assert isinstance(copy.deepcopy(infos), list)
 
 
+def test_lazyinfos_never_leaks_its_unmaterialised_slots():
+    """`infos + [...]`, reversed(), `in`, count() and index() read list storage directly in CPython; every one of them
+    must see dicts, never the internal None."""
+    infos, terms, reason, done, tobs = _fake_infos()
+    extra = [{"x": 1}]
+    both = infos + extra
+    assert type(both) is list and len(both) == 7 and all(isinstance(d, dict) for d in both)
+    assert all(isinstance(d, dict) for d in (extra + infos))
+    infos2, *_ = _fake_infos()
+    assert all(isinstance(d, dict) for d in reversed(infos2)) and list(reversed(infos2))[0] is infos2[5]
+    infos3, *_ = _fake_infos()
+    assert None not in infos3 and infos3.count(None) == 0
+    assert infos3[0] in infos3 and infos3.index(infos3[5]) == 5      # (dicts that both hold an array compare ambiguously, as in a plain list)
+    assert all(isinstance(d, dict) for d in infos3 * 2) and "None" not in repr(infos3)
+
+
 class _VecMonitorLike:
     """Call pattern of SB3 VecMonitor.step_wait [EXT]."""
 
