@@ -38,7 +38,7 @@ class DmConfig(C.Structure):
                 ("seed", C.c_uint64), ("auto_reset", C.c_int32), ("device", C.c_int32),
                 ("lpt_schedule", C.c_int32), ("task", C.c_int32),
                 ("amnesty_steps", C.c_int32), ("to_getup_len", C.c_int32),
-                ("integrator", C.c_int32), ("reserved0", C.c_int32)]
+                ("integrator", C.c_int32), ("stale_contact_slots", C.c_int32)]
 
 
 INTEGRATORS = {None: 0, "model": 0, "Euler": 1, "euler": 1, "RK4": 2, "rk4": 2}   # DM_CFG_INT_*

@@ -354,6 +354,7 @@ static void fill_launch(DmEngine *e, DmLaunch &P, int mode) {
   P.seed = e->cfg.seed;
   P.amnesty_steps = e->cfg.amnesty_steps; P.to_getup_len = e->cfg.to_getup_len;
   P.integrator = e->cfg.integrator == DM_CFG_INT_EULER ? DM_INT_EULER : e->cfg.integrator == DM_CFG_INT_RK4 ? DM_INT_RK4 : e->model.integrator;
+  P.f8 = e->cfg.stale_contact_slots ? 1 : 0;
   P.debug = e->debug;
 }
 

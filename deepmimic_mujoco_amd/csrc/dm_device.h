@@ -132,6 +132,8 @@ struct EnvLds {
 #define DMS_EPREW 133
 #define DMS_CLIP 134
 #define DMS_RCNT 135
+#define DMS_F8R 136   // F8 option: bit k = contact slot k last held a (right foot, floor) pair; DMS_F8L: left foot
+#define DMS_F8L 137
 
 // clip row layout (DMK_CLIP_ROW floats): [0:28) qpos[7:] | [28:56) qvel[6:] | [56:60) root quat wxyz |
 //  [60:72) end-effector geom xpos 4x3 | [72:75) mass-weighted body_xpos COM | [75:78) root pos | pad
@@ -154,7 +156,7 @@ struct DmLaunch {
   DmClipDev clips[8];
   int32_t N, nslots, mode, auto_reset, max_ep_length;
   int32_t amnesty_steps, to_getup_len;   // DPCombinedEnv task only
-  int32_t integrator, pad_i;             // DM_INT_RK4 (xml :9) or DM_INT_EULER
+  int32_t integrator, f8;                // DM_INT_RK4 (xml :9) or DM_INT_EULER; f8: DmConfig.stale_contact_slots
   float vel_obs_scale, low_z, high_z, obs_bound;
   float w_pose, w_vel, w_ee, w_com, w_jl;
   uint64_t seed;

@@ -36,6 +36,7 @@ namespace g1 {
 
 constexpr int NQ = 44, NV = 43, NU = 37, NB = 39, NG = 94, NJ = 38, NM = 434, NACT = 23, NOBS = 85, NREW = 23;
 constexpr int MAXCON = DMG1_MAXCON, MAXROW = DMG1_MAXROW, MAXANC = 16, MAXSURV = 384, NCG = 48;   // NCG: geoms that collide (47)
+constexpr int PAIRCAP = 128;    // split pipeline: surviving pairs per env and evaluation that the pair queue holds (monolithic: MAXSURV)
 constexpr int STATE = 176;   // floats per env in the HBM state row
 constexpr int S_QPOS = 0, S_QVEL = 44, S_WARM = 87, S_CTRL = 130, S_IDX = 167, S_EPLEN = 168, S_EPREW = 169, S_RCNT = 170, S_MOTION = 171;
 constexpr int NOBS_C = DMG1_NOBS_COMBINED;   // DPCombinedEnv: 82 + extra contacts 8 + phase + player-action obs 7
@@ -145,6 +146,17 @@ struct Launch {
   float *obs, *rew, *terms, *terminal_obs, *debug;
   uint8_t *done;
   int32_t *reason;
+  // ---- split pipeline (g1_env_kernel / g1_pair_kernel): per-env slot of the LDS working set + step context between launches, and
+  // the pair queue of the collision stage
+  char *ws;                  // N x WS_BYTES
+  double *pq_geo;            // [N][PAIRCAP][36]: the two staged geoms of a surviving pair (fp64)
+  int32_t *pq_pair;          // [N][PAIRCAP]: pair id of the env's s-th survivor (canonical order)
+  int32_t *pq_cnt;           // [N][PAIRCAP]: contacts the pair kernel found
+  float *pq_con;             // [N][PAIRCAP][8][16]: dist | pos 3 | frame 9 of each
+  int32_t *tick;             // [2][N * PAIRCAP]: tickets (env << 8 | s): list 0 = support-query pairs (MPR, plane-mesh), 1 = analytic
+  int32_t *qctr;             // per round: tickets in list 0, in list 1, queue head, pad
+  float *sepc2;              // [N][1024][4]: separating-direction cache, one entry per (env, pair)
+  int32_t round, pad3;
 };
 
 // ------------------------------------------------------------------------------------------ small math (fp32)
@@ -793,9 +805,11 @@ __device__ __forceinline__ void mesh_support_pair(const Geo &A, const double *dl
   if (meshA) wave_pick(pa);
   if (meshB) wave_pick(pb);
 }
-__device__ __forceinline__ int mesh_support_index(const Geo &g, const double *dl, const int lane) {
+// slot of the support vertex in the clustered array, and the vertex itself
+__device__ __forceinline__ int mesh_support_index(const Geo &g, const double *dl, double *v, const int lane) {
   MeshPick i, j;
   mesh_support_pair(g, dl, true, i, g, dl, false, j, lane);
+  v[0] = i.x; v[1] = i.y; v[2] = i.z;
   return i.bk;
 }
 
@@ -826,12 +840,20 @@ __device__ __forceinline__ bool ccd_eq(double a, double b) {
   a = fabs(a); b = fabs(b);
   return b > a ? ab < CCD_EPS * b : ab < CCD_EPS * a;
 }
+#ifdef G1_PAIRSTATS
+__device__ unsigned long long g_pairstats[8];   // 0 support evaluations, 1 tickets, 2 hint-separated, 3 contacts, 4 MPR misses
+#define PSTAT(k) do { if (lane == 0) atomicAdd(&g_pairstats[k], 1ull); } while (0)
+#else
+#define PSTAT(k) do {} while (0)
+#endif
 // support point of A - B in direction dir: both supports together, so the two hull scans share their memory round trips
 __device__ __forceinline__ void mpr_support(const Geo &a, const Geo &b, const double *dir, Sup &s, const int lane) {
   double nd[3] = {-dir[0], -dir[1], -dir[2]}, dla[3], dlb[3], pa[3], pb[3];
   drot_t(dla, a.mat, dir);
   drot_t(dlb, b.mat, nd);
   const bool ma = a.type == DM_GEOM_MESH, mb = b.type == DM_GEOM_MESH;
+  PSTAT(0);
+
   support_local(a, dla, pa);
   support_local(b, dlb, pb);
   if (ma || mb) {
@@ -910,11 +932,11 @@ __device__ __forceinline__ double tri_closest_origin(const double *a, const doub
 // returns -2 if it still separates them (disjoint shapes: MPR would find no contact either, so the shortcut is result-neutral).
 // On a `no intersection` verdict reached through a strictly negative support projection, `sep` receives that direction.
 __device__ __forceinline__ int mpr_penetration(const Geo &a, const Geo &b, double *depth, double *dir, double *pos, const double *hint,
-                                               double *sep, bool &sep_valid, const int lane) {
+                                               double *sep, bool &sep_valid, Sup *ps, const int lane) {
   enum { V1, V2, DISCOVER, REFINE, PENETR, HINT };
   constexpr double SEP_EPS = 1e-9;
   sep_valid = false;
-  Sup *ps = reinterpret_cast<Sup *>(&S.u.co.mpr_ps[0][0]);   // (every lane writes the same values)
+  // ps: the portal (v0..v3: v, v1, v2), wave-uniform state in LDS (every lane writes the same values; 72 VGPRs if kept per lane)
   Sup sv;
   double d[3], va[3], vb[3], dot;
   for (int i = 0; i < 3; i++) { ps[0].v1[i] = a.center[i]; ps[0].v2[i] = b.center[i]; ps[0].v[i] = a.center[i] - b.center[i]; }
@@ -1027,12 +1049,15 @@ __device__ __forceinline__ int mpr_penetration(const Geo &a, const Geo &b, doubl
 // typically — keep the direction that proved it, stored in geom 1's frame; the next evaluation re-tests it with ONE support
 // evaluation instead of running the portal search (4..5 on average).  Entries: pair id, direction xyz; slot SEPC = next victim.
 constexpr int SEPC = 16;
-__device__ __forceinline__ int np_convex(Con *c, const Geo &a, const Geo &b, float *cache, const int pair, const int lane) {
+// `direct`: cache points at the ONE entry of this (env, pair) — the pair kernel's waves own a pair each, a shared 16-entry set would race.
+__device__ __forceinline__ int np_convex(Con *c, const Geo &a, const Geo &b, float *cache, const bool direct, const int pair, Sup *ps,
+                                         const int lane) {
   double depth, dir[3], pos[3], hint[3], sep[3];
   bool sep_valid;
   int slot = -1;
   if (cache) {
-    const unsigned long long hit = __ballot(lane < SEPC && __float_as_int(cache[4 * (lane < SEPC ? lane : 0)]) == pair);
+    const unsigned long long hit = direct ? (__float_as_int(cache[0]) == pair ? 1ull : 0ull)
+                                          : __ballot(lane < SEPC && __float_as_int(cache[4 * (lane < SEPC ? lane : 0)]) == pair);
     if (hit) {
       slot = __ffsll((long long)hit) - 1;
       const double hl[3] = {cache[4 * slot + 1], cache[4 * slot + 2], cache[4 * slot + 3]};
@@ -1040,9 +1065,13 @@ __device__ __forceinline__ int np_convex(Con *c, const Geo &a, const Geo &b, flo
       dnormalize(hint);
     }
   }
-  const int res = mpr_penetration(a, b, &depth, dir, pos, slot >= 0 ? hint : nullptr, sep, sep_valid, lane);
+  const int res = mpr_penetration(a, b, &depth, dir, pos, slot >= 0 ? hint : nullptr, sep, sep_valid, ps, lane);
+  PSTAT(1); if (res == -2) PSTAT(2); else if (res == 0) PSTAT(3); else PSTAT(4);
   if (cache && res == -1 && sep_valid) {   // remember what separated them (geom 1's frame)
-    if (slot < 0) { slot = __float_as_int(cache[4 * SEPC]) & (SEPC - 1); if (lane == 0) cache[4 * SEPC] = __int_as_float(slot + 1); }
+    if (slot < 0) {
+      if (direct) slot = 0;
+      else { slot = __float_as_int(cache[4 * SEPC]) & (SEPC - 1); if (lane == 0) cache[4 * SEPC] = __int_as_float(slot + 1); }
+    }
     double sl[3];
     drot_t(sl, a.mat, sep);
     if (lane == 0) { cache[4 * slot] = __int_as_float(pair); cache[4 * slot + 1] = (float)sl[0]; cache[4 * slot + 2] = (float)sl[1]; cache[4 * slot + 3] = (float)sl[2]; }
@@ -1138,11 +1167,12 @@ __device__ __noinline__ int np_plane_mesh(Con *c, const Geo &p, const Geo &g, co
       for (int i = 0; i < 3; i++) dw[i] = -normal[i] + ca * t1[i] + sa * t2[i];
     }
     drot_t(dl, g.mat, dw);
-    const int vi = mesh_support_index(g, dl, lane);
+    double vl[3];
+    const int vi = mesh_support_index(g, dl, vl, lane);
     bool dup = false;
     for (int j = 0; j < n; j++) dup |= used[j] == vi;
     if (dup) continue;
-    double v[3], dif[3], vl[3] = {g.vert[3 * vi], g.vert[3 * vi + 1], g.vert[3 * vi + 2]};
+    double v[3], dif[3];
     drot(v, g.mat, vl);
     for (int i = 0; i < 3; i++) v[i] += g.pos[i];
     dsub(dif, v, p.pos);
@@ -1329,43 +1359,62 @@ __device__ __noinline__ int np_box_box(Con *c, const Geo &A, const Geo &Bx, doub
   return cnt;
 }
 
-// stage geom g of the current pair in LDS slot `slot` (lanes 0..17 write one double each): the geom's pose in fp64 from the
-// fp64 pose of its body (kinematics) and the fp64 model tables
-__device__ __forceinline__ void stage_geo(const Dev &T, int g, int slot, const int lane) {
+// Staging of the pair being processed (fp64, wave-uniform): the two geoms (pos 3 | mat 9 | size 3 | centre 3 each), its contacts,
+// the box-box polygons and the MPR portal.  The monolithic kernel keeps it in LDS slack of the contact stage (S.u.co), the pair
+// kernel of the split pipeline in a small LDS block of its own.
+struct NpStage {
+  double (*geo)[18];
+  int32_t (*geoi)[6];     // type, nvert, nclus, vertex start, cluster start, pad
+  Con *rc;
+  double (*poly0)[3], (*poly1)[3];
+  Sup *ps;
+};
+// entry l (0..17) of geom g's staged record: its pose in fp64 from the fp64 pose of its body (kinematics) and the fp64 tables
+__device__ __forceinline__ double geo_entry(const Dev &T, const int g, const int l) {
   const int type = T.g_type[g], me = T.g_mesh[g], b = T.g_body[g];
-  double v = 0;
-  if (lane < 18) {
-    double bq[4], R[9];
-    for (int i = 0; i < 4; i++) bq[i] = (double)S.xquat[b][i] + (double)S.xquat_lo[b][i];
-    dquat2mat(R, bq);
-    if (lane >= 12 && lane < 15) v = T.g_size_d[g][lane - 12];
-    else if (lane >= 3 && lane < 12) {
-      const int i = (lane - 3) / 3, j = (lane - 3) % 3;
-      v = R[3 * i] * T.g_mat_d[g][j] + R[3 * i + 1] * T.g_mat_d[g][3 + j] + R[3 * i + 2] * T.g_mat_d[g][6 + j];
-    } else {
-      const int i = lane < 3 ? lane : lane - 15;
-      v = ((double)S.xpos[b][i] + (double)S.xpos_lo[b][i]) +
-          (R[3 * i] * T.g_pos_d[g][0] + R[3 * i + 1] * T.g_pos_d[g][1] + R[3 * i + 2] * T.g_pos_d[g][2]);
-      if (lane >= 15 && type == DM_GEOM_MESH) {
-        double gm[3];
-        for (int j = 0; j < 3; j++) gm[j] = R[3 * i] * T.g_mat_d[g][j] + R[3 * i + 1] * T.g_mat_d[g][3 + j] + R[3 * i + 2] * T.g_mat_d[g][6 + j];
-        v += gm[0] * T.m_center[me][0] + gm[1] * T.m_center[me][1] + gm[2] * T.m_center[me][2];
-      }
+  double bq[4], R[9], v;
+  for (int i = 0; i < 4; i++) bq[i] = (double)S.xquat[b][i] + (double)S.xquat_lo[b][i];
+  dquat2mat(R, bq);
+  if (l >= 12 && l < 15) v = T.g_size_d[g][l - 12];
+  else if (l >= 3 && l < 12) {
+    const int i = (l - 3) / 3, j = (l - 3) % 3;
+    v = R[3 * i] * T.g_mat_d[g][j] + R[3 * i + 1] * T.g_mat_d[g][3 + j] + R[3 * i + 2] * T.g_mat_d[g][6 + j];
+  } else {
+    const int i = l < 3 ? l : l - 15;
+    v = ((double)S.xpos[b][i] + (double)S.xpos_lo[b][i]) +
+        (R[3 * i] * T.g_pos_d[g][0] + R[3 * i + 1] * T.g_pos_d[g][1] + R[3 * i + 2] * T.g_pos_d[g][2]);
+    if (l >= 15 && type == DM_GEOM_MESH) {
+      double gm[3];
+      for (int j = 0; j < 3; j++) gm[j] = R[3 * i] * T.g_mat_d[g][j] + R[3 * i + 1] * T.g_mat_d[g][3 + j] + R[3 * i + 2] * T.g_mat_d[g][6 + j];
+      v += gm[0] * T.m_center[me][0] + gm[1] * T.m_center[me][1] + gm[2] * T.m_center[me][2];
     }
-    S.u.co.geo[slot][lane] = v;
   }
-  if (lane == 0) {
-    const bool mesh = type == DM_GEOM_MESH;
-    S.u.co.geoi[slot][0] = type; S.u.co.geoi[slot][1] = mesh ? T.m_vnum[me] : 0; S.u.co.geoi[slot][2] = mesh ? T.m_cnum[me] : 0;
-    S.u.co.geoi[slot][3] = mesh ? T.m_vadr[me] : 0; S.u.co.geoi[slot][4] = mesh ? T.m_cadr[me] : 0;
-  }
+  return v;
 }
-__device__ __forceinline__ void view_geo(const Launch &P, int slot, Geo &o) {
-  o.type = S.u.co.geoi[slot][0]; o.nvert = S.u.co.geoi[slot][1]; o.nclus = S.u.co.geoi[slot][2];
-  o.pos = &S.u.co.geo[slot][0]; o.mat = &S.u.co.geo[slot][3]; o.size = &S.u.co.geo[slot][12]; o.center = &S.u.co.geo[slot][15];
-  o.vert = P.mesh_vert + 3 * (size_t)S.u.co.geoi[slot][3];
-  o.oidx = P.mesh_oidx + S.u.co.geoi[slot][3];
-  o.clus = P.mesh_clus + 8 * (size_t)S.u.co.geoi[slot][4];
+__device__ __forceinline__ void stage_geoi(const Dev &T, const NpStage &W, int g, int slot) {
+  const int type = T.g_type[g], me = T.g_mesh[g];
+  const bool mesh = type == DM_GEOM_MESH;
+  W.geoi[slot][0] = type; W.geoi[slot][1] = mesh ? T.m_vnum[me] : 0; W.geoi[slot][2] = mesh ? T.m_cnum[me] : 0;
+  W.geoi[slot][3] = mesh ? T.m_vadr[me] : 0; W.geoi[slot][4] = mesh ? T.m_cadr[me] : 0;
+}
+// stage geom g of the current pair in slot `slot` (lanes 0..17 write one double each)
+__device__ __forceinline__ void stage_geo(const Dev &T, const NpStage &W, int g, int slot, const int lane) {
+  if (lane < 18) W.geo[slot][lane] = geo_entry(T, g, lane);
+  if (lane == 0) stage_geoi(T, W, g, slot);
+}
+struct MeshPtrs { const double *vert; const int32_t *oidx; const double *clus; };
+__device__ __forceinline__ void view_geo(const MeshPtrs &M, const NpStage &W, int slot, Geo &o) {
+  o.type = W.geoi[slot][0]; o.nvert = W.geoi[slot][1]; o.nclus = W.geoi[slot][2];
+  o.pos = &W.geo[slot][0]; o.mat = &W.geo[slot][3]; o.size = &W.geo[slot][12]; o.center = &W.geo[slot][15];
+  o.vert = M.vert + 3 * (size_t)W.geoi[slot][3];
+  o.oidx = M.oidx + W.geoi[slot][3];
+  o.clus = M.clus + 8 * (size_t)W.geoi[slot][4];
+}
+// pair classes (cost): 0 analytic, 1 plane - mesh (support queries), 2 MPR
+__device__ __forceinline__ int pair_class(const int t1, const int t2) {
+  if (t1 == DM_GEOM_PLANE && t2 == DM_GEOM_MESH) return 1;
+  if (t1 == DM_GEOM_PLANE || (t1 == DM_GEOM_SPHERE && (t2 == DM_GEOM_SPHERE || t2 == DM_GEOM_BOX)) || (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX)) return 0;
+  return 2;
 }
 
 __device__ __forceinline__ void make_frame(float *f) {   // [EXT] mju_makeFrame
@@ -1407,9 +1456,10 @@ __device__ __forceinline__ bool obb_separated(const float *c1, const float *R1, 
   return false;
 }
 
-// [EXT] mj_collision: candidate pairs in canonical order, bounding-sphere + bounding-box filters, narrowphase
-__device__ __noinline__ int collide(const Dev &T, const Launch &P, const int env, const int lane) {
-  int nsurv = 0, overflow = 0;
+// [EXT] mj_collision, part 1: candidate pairs in canonical order through the bounding-sphere + bounding-box filters; the survivors'
+// pair ids go to S.u.co.surv in order.  Returns their number (capped; `overflow` set when the cap cut the list).
+__device__ __forceinline__ int broadphase(const Dev &T, const int cap, int &overflow, const int lane) {
+  int nsurv = 0;
   for (int base = 0; base < T.npair; base += 64) {
     const int p = base + lane;
     bool keep = false;
@@ -1440,48 +1490,69 @@ __device__ __noinline__ int collide(const Dev &T, const Launch &P, const int env
     }
     const unsigned long long m = __ballot(keep);
     const int slot = nsurv + __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-    if (keep) { if (slot < MAXSURV) S.u.co.surv[slot] = (int16_t)p; }
+    if (keep) { if (slot < cap) S.u.co.surv[slot] = (int16_t)p; }
     nsurv += __popcll(m);
   }
-  if (nsurv > MAXSURV) { overflow = 1; nsurv = MAXSURV; }
+  if (nsurv > cap) { overflow = 1; nsurv = cap; }
+  return nsurv;
+}
+
+// [EXT] mj_collision, part 2: the narrowphase of ONE staged pair (geoms in W.geo / W.geoi): analytic routines for the pairs MuJoCo
+// has them for, MPR for everything with a cylinder or a mesh.  Returns the number of contacts left in W.rc.
+__device__ __forceinline__ int narrow_pair(const MeshPtrs &M, const NpStage &W, float *cache, const bool direct, const int pair,
+                                           const int skip, const int lane) {
+  Geo A, B;
+  view_geo(M, W, 0, A);
+  view_geo(M, W, 1, B);
+  Con *rc = W.rc;
+  int n = 0;
+  const int t1 = A.type, t2 = B.type;
+  if (t1 == DM_GEOM_PLANE) {
+    if (t2 == DM_GEOM_SPHERE) n = np_plane_sphere(rc, A, B.pos, B.size[0]);
+    else if (t2 == DM_GEOM_CYLINDER) n = np_plane_cylinder(rc, A, B);
+    else if (t2 == DM_GEOM_BOX) n = np_plane_box(rc, A, B);
+    else if (t2 == DM_GEOM_MESH && !(skip & 128)) n = np_plane_mesh(rc, A, B, lane);
+  } else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_SPHERE) n = np_sphere_sphere(rc, A.pos, A.size[0], B.pos, B.size[0]);
+  else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_BOX) n = np_sphere_box(rc, A, B);
+  else if (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX) n = np_box_box(rc, A, B, W.poly0, W.poly1);
+  else if (!(skip & 64)) n = np_convex(rc, A, B, (skip & 256) ? nullptr : cache, direct, pair, W.ps, lane);
+  return n;
+}
+// contact k of the staged pair -> the fp32 record the constraint stage reads: dist | pos 3 | frame 9 ([EXT] mju_makeFrame of the normal)
+__device__ __forceinline__ void contact_record(const Con &c, float &dist, float *pos, float *fr) {
+  dist = (float)c.dist;
+  fr[0] = (float)c.n[0]; fr[1] = (float)c.n[1]; fr[2] = (float)c.n[2];
+  for (int i = 3; i < 9; i++) fr[i] = 0;
+  make_frame(fr);
+  for (int i = 0; i < 3; i++) pos[i] = (float)c.pos[i];
+}
+
+// [EXT] mj_collision of the monolithic kernel: the survivors one after the other on this wave
+__device__ __noinline__ int collide(const Dev &T, const Launch &P, const int env, const int lane) {
+  int overflow = 0;
+  int nsurv = broadphase(T, MAXSURV, overflow, lane);
   if (P.pad & 32) nsurv = 0;
   SYNC();
   PROF(3);
   int ncon = 0, n_pm = 0, n_an = 0, n_mpr = 0;
-  Con *rc = reinterpret_cast<Con *>(&S.u.co.rc[0][0]);
+  const NpStage W = {S.u.co.geo, S.u.co.geoi, reinterpret_cast<Con *>(&S.u.co.rc[0][0]), S.u.co.poly[0], S.u.co.poly[1],
+                     reinterpret_cast<Sup *>(&S.u.co.mpr_ps[0][0])};
+  const MeshPtrs M = {P.mesh_vert, P.mesh_oidx, P.mesh_clus};
   for (int s = 0; s < nsurv; s++) {
     const int p = S.u.co.surv[s];
     const int g1 = T.p_g1[p], g2 = T.p_g2[p];
-    stage_geo(T, g1, 0, lane);
-    stage_geo(T, g2, 1, lane);
+    stage_geo(T, W, g1, 0, lane);
+    stage_geo(T, W, g2, 1, lane);
     SYNC();
-    Geo A, B;
-    view_geo(P, 0, A);
-    view_geo(P, 1, B);
-    int n = 0;
-    const int t1 = A.type, t2 = B.type;
-    if (t1 == DM_GEOM_PLANE && t2 == DM_GEOM_MESH) n_pm++;
-    else if (t1 == DM_GEOM_PLANE || (t1 == DM_GEOM_SPHERE && (t2 == DM_GEOM_SPHERE || t2 == DM_GEOM_BOX)) || (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX)) n_an++;
-    else n_mpr++;
-    if (t1 == DM_GEOM_PLANE) {
-      if (t2 == DM_GEOM_SPHERE) n = np_plane_sphere(rc, A, B.pos, B.size[0]);
-      else if (t2 == DM_GEOM_CYLINDER) n = np_plane_cylinder(rc, A, B);
-      else if (t2 == DM_GEOM_BOX) n = np_plane_box(rc, A, B);
-      else if (t2 == DM_GEOM_MESH && !(P.pad & 128)) n = np_plane_mesh(rc, A, B, lane);
-    } else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_SPHERE) n = np_sphere_sphere(rc, A.pos, A.size[0], B.pos, B.size[0]);
-    else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_BOX) n = np_sphere_box(rc, A, B);
-    else if (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX) n = np_box_box(rc, A, B, S.u.co.poly[0], S.u.co.poly[1]);
-    else if (!(P.pad & 64)) n = np_convex(rc, A, B, (P.pad & 256) ? nullptr : P.sepc + (size_t)env * (4 * SEPC + 4), p, lane);
+    const int cls = pair_class(W.geoi[0][0], W.geoi[1][0]);
+    n_an += cls == 0; n_pm += cls == 1; n_mpr += cls == 2;
+    const int n = narrow_pair(M, W, P.sepc + (size_t)env * (4 * SEPC + 4), false, p, P.pad, lane);
     SYNC();
-    PROF((t1 == DM_GEOM_PLANE && t2 == DM_GEOM_MESH) ? 5 : ((t1 == DM_GEOM_PLANE || (t1 == DM_GEOM_SPHERE && (t2 == DM_GEOM_SPHERE || t2 == DM_GEOM_BOX)) || (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX)) ? 4 : 6));
+    PROF(cls == 1 ? 5 : (cls == 0 ? 4 : 6));
     for (int k = 0; k < n; k++) {
       if (ncon >= MAXCON) { overflow = 1; continue; }
       if (lane == 0) {
-        S.u.co.c_dist[ncon] = (float)rc[k].dist;
-        float fr[9] = {(float)rc[k].n[0], (float)rc[k].n[1], (float)rc[k].n[2], 0, 0, 0, 0, 0, 0};
-        make_frame(fr);
-        for (int i = 0; i < 3; i++) S.u.co.c_pos[ncon][i] = (float)rc[k].pos[i];
-        for (int i = 0; i < 9; i++) S.u.co.c_frame[ncon][i] = fr[i];
+        contact_record(W.rc[k], S.u.co.c_dist[ncon], S.u.co.c_pos[ncon], S.u.co.c_frame[ncon]);
         S.u.co.c_g1[ncon] = g1; S.u.co.c_g2[ncon] = g2;
         S.u.co.c_mu[ncon] = fmaxf(T.g_mu[g1], T.g_mu[g2]);
       }
@@ -1998,9 +2069,10 @@ __device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const
   SYNC();
 }
 
-__device__ __noinline__ void forward(const Launch &P, const Dev &T, const int env, const int lane, const bool qlo) {
-  float *JT = P.jt + (size_t)env * 44 * MAXROW, *BT = P.bt + (size_t)env * 44 * MAXROW, *AR = P.ar + (size_t)env * MAXROW * MAXROW;
-  float *RW = P.rows + (size_t)env * 5 * MAXROW;
+// One forward evaluation = a per-env first half (poses, inertia, factorisation, smooth dynamics), the collision stage, and a
+// per-env second half (constraint rows, A, PGS).  The monolithic kernel runs all three on the env's wave; the split pipeline runs
+// the halves in g1_env_kernel and the narrowphase of ALL envs' pairs in g1_pair_kernel (one wave per pair).
+__device__ __forceinline__ void forward_pre(const Dev &T, const int lane, const bool qlo) {
   PROF(15);
   kinematics(T, lane, qlo);
   com_pos(T, lane);
@@ -2009,9 +2081,10 @@ __device__ __noinline__ void forward(const Launch &P, const Dev &T, const int en
   PROF(1);
   fwd_smooth(T, lane);   // before the collision stage: its scratch shares LDS with the contact arrays
   PROF(2);
-  int ncon = 0;
-  if (!(P.pad & 2)) ncon = collide(T, P, env, lane);
-  else { if (lane == 0) { S.info[0] = 0; S.info[4] = 0; } SYNC(); }
+}
+__device__ __forceinline__ void forward_post(const Launch &P, const Dev &T, const int env, const int lane, const int ncon) {
+  float *JT = P.jt + (size_t)env * 44 * MAXROW, *BT = P.bt + (size_t)env * 44 * MAXROW, *AR = P.ar + (size_t)env * MAXROW * MAXROW;
+  float *RW = P.rows + (size_t)env * 5 * MAXROW;
   int nefc = 0;
   PROF(7);
   if (!(P.pad & 8)) nefc = make_constraint(T, JT, RW, ncon, lane);
@@ -2022,6 +2095,13 @@ __device__ __noinline__ void forward(const Launch &P, const Dev &T, const int en
   if (P.pad & 16) nefc = 0;
   fwd_constraint(T, JT, BT, AR, RW, nefc, lane, (P.pad & 1) ? 0 : T.iterations);
   PROF(10);
+}
+__device__ __noinline__ void forward(const Launch &P, const Dev &T, const int env, const int lane, const bool qlo) {
+  forward_pre(T, lane, qlo);
+  int ncon = 0;
+  if (!(P.pad & 2)) ncon = collide(T, P, env, lane);
+  else { if (lane == 0) { S.info[0] = 0; S.info[4] = 0; } SYNC(); }
+  forward_post(P, T, env, lane, ncon);
 }
 
 // [EXT] mj_integratePos from the step's start state x0q (+ the low words of its normalised root quaternion), in fp64.  `lo`: keep
@@ -2061,38 +2141,42 @@ __device__ void integrate_pos(const Dev &T, const float *vel, const double a, co
   }
 }
 
-extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
-  const int lane = threadIdx.x;
-  if ((int)blockIdx.x >= P.N) return;
-  const int env = (P.order && P.mode == MODE_STEP) ? P.order[blockIdx.x] : (int)blockIdx.x;
-  const Dev &T = *P.T;
+// What a step carries from one evaluation to the next besides the LDS working set (registers in the monolithic kernel, a few
+// words of the env's HBM slot between the launches of the split pipeline)
+struct StepCtx {
+  int idx_curr, ep_len, rcnt, motion, clip_id, reason, work, stage;   // stage: RK4 stage of the evaluation about to run / in flight
+  unsigned stage_ncon, stage_nefc_lo;                                  // byte i = count at RK stage i (debug)
+  float ep_rew, reward;
+  bool sim_err, done, after_reset;
+  ClipDev clip;
+};
+
+// Loads the env's state row, applies the launch mode (action / forced state / reset state) and runs mj_checkPos / mj_checkVel.
+// false: this env has nothing (more) to do in this launch.
+__device__ __forceinline__ bool step_enter(const Launch &P, const Dev &T, const int env, const int lane, StepCtx &X) {
   const int mode = P.mode;
-  if (mode == MODE_RESET && P.mask && !P.mask[env]) return;
-#ifdef G1_PROFILE
-  if (lane == 0) for (int i = 0; i < 16; i++) S.prof[i] = 0;
-  S.prof_t = clock64();
-#endif
+  if (mode == MODE_RESET && P.mask && !P.mask[env]) return false;
   float *st = P.state + (size_t)env * STATE;
   int *sti = (int *)st;
-  int idx_curr = sti[S_IDX], ep_len = sti[S_EPLEN], rcnt = sti[S_RCNT];
-  float ep_rew = st[S_EPREW];
+  X.idx_curr = sti[S_IDX]; X.ep_len = sti[S_EPLEN]; X.rcnt = sti[S_RCNT];
+  X.ep_rew = st[S_EPREW];
   // TASK (DPCombinedEnv, src/combined_env.py): per-env motion 0 walk, 1 run, 2 getup, 3 to_getup; idx_curr is then the
   // unwrapped current_motion_n_steps
   const bool TASK = P.task != 0;
-  int motion = TASK ? sti[S_MOTION] : 0;
-  motion = (motion < 0 || motion > 3) ? 0 : motion;
+  X.motion = TASK ? sti[S_MOTION] : 0;
+  X.motion = (X.motion < 0 || X.motion > 3) ? 0 : X.motion;
   // DPEnv task: the same slot holds the env's clip id (dmg1_set_env_clips; one DPEnv(motion=...) per worker in the reference)
-  int clip_id = TASK ? 0 : sti[S_MOTION];
-  clip_id = (clip_id < 0 || clip_id >= DMG1_MAX_CLIPS) ? 0 : clip_id;
+  X.clip_id = TASK ? 0 : sti[S_MOTION];
+  X.clip_id = (X.clip_id < 0 || X.clip_id >= DMG1_MAX_CLIPS) ? 0 : X.clip_id;
   const int NOBS_T = TASK ? NOBS_C : NOBS, NTERMS = TASK ? 8 : 5;
-  if (TASK && (P.clips[0].L < 1 || P.clips[1].L < 1 || P.clips[2].L < 2)) return;   // walk, run, getup all needed
-  if (TASK) idx_curr = idx_curr < 0 ? 0 : idx_curr;
+  if (TASK && (P.clips[0].L < 1 || P.clips[1].L < 1 || P.clips[2].L < 2)) return false;   // walk, run, getup all needed
+  if (TASK) X.idx_curr = X.idx_curr < 0 ? 0 : X.idx_curr;
   if (lane < NQ) S.qpos[lane] = st[S_QPOS + lane];
   if (lane < NV) { S.qvel[lane] = st[S_QVEL + lane]; S.warm[lane] = st[S_WARM + lane]; }
   if (lane < NU) S.ctrl[lane] = st[S_CTRL + lane];
   SYNC();
-  ClipDev clip = P.clips[TASK ? (motion == 3 ? 2 : motion) : clip_id];
-  if (clip.L < 1) return;   // no clip loaded under this env's clip id
+  X.clip = P.clips[TASK ? (X.motion == 3 ? 2 : X.motion) : X.clip_id];
+  if (X.clip.L < 1) return false;   // no clip loaded under this env's clip id
   if (mode == MODE_STEP) {
     if (lane < NU) S.ctrl[lane] = (lane < NACT) ? P.actions[(size_t)env * NACT + lane] * T.action_scale : 0.f;   // :348-351
   } else if (mode == MODE_FORCED || mode == MODE_SETSTATE) {
@@ -2104,93 +2188,95 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
   } else if (mode == MODE_RESET) {
     int fi;
     if (TASK) {   // DPCombinedEnv.reset(rsi=True) (:219-227): walk with amnesty or getup, random frame; idx_init keeps the motion
-      if (P.idx_init) idx_curr = P.idx_init[env] < 0 ? 0 : P.idx_init[env];
+      if (P.idx_init) X.idx_curr = P.idx_init[env] < 0 ? 0 : P.idx_init[env];
       else {
-        motion = (hash32(P.seed, env, rcnt, 0x5EED) & 1) ? 2 : 0;
-        clip = P.clips[motion];
-        idx_curr = (int)(hash32(P.seed, env, rcnt, 0x5EEE) % (uint32_t)clip.L) + (motion == 0 ? P.amnesty_steps + 10 : 0);
+        X.motion = (hash32(P.seed, env, X.rcnt, 0x5EED) & 1) ? 2 : 0;
+        X.clip = P.clips[X.motion];
+        X.idx_curr = (int)(hash32(P.seed, env, X.rcnt, 0x5EEE) % (uint32_t)X.clip.L) + (X.motion == 0 ? P.amnesty_steps + 10 : 0);
       }
-      fi = (motion == 3) ? 1 : idx_curr % clip.L;
+      fi = (X.motion == 3) ? 1 : X.idx_curr % X.clip.L;
     } else {
-      fi = P.idx_init ? P.idx_init[env] : (int)(hash32(P.seed, env, rcnt, 0x5EED) % (uint32_t)clip.L);
-      fi = fi < 0 ? 0 : (fi >= clip.L ? clip.L - 1 : fi);
-      idx_curr = fi;
+      fi = P.idx_init ? P.idx_init[env] : (int)(hash32(P.seed, env, X.rcnt, 0x5EED) % (uint32_t)X.clip.L);
+      fi = fi < 0 ? 0 : (fi >= X.clip.L ? X.clip.L - 1 : fi);
+      X.idx_curr = fi;
     }
-    const float *rr = clip.reset + (size_t)fi * 88;
+    const float *rr = X.clip.reset + (size_t)fi * 88;
     if (lane < NQ) S.qpos[lane] = rr[lane];
     if (lane < NV) S.qvel[lane] = rr[44 + lane];
-    ep_len = 0; ep_rew = 0; rcnt++;
+    X.ep_len = 0; X.ep_rew = 0; X.rcnt++;
   }
   SYNC();
   if (mode == MODE_SETSTATE && !P.run_forward) {
     if (lane < NQ) st[S_QPOS + lane] = S.qpos[lane];
     if (lane < NV) { st[S_QVEL + lane] = S.qvel[lane]; st[S_WARM + lane] = S.warm[lane]; }
-    return;
+    return false;
   }
 
-  bool sim_err = false, done = false, after_reset = false;
-  int reason = 0;
-  unsigned stage_ncon = 0, stage_nefc_lo = 0;   // byte i = count at RK stage i (debug)
-  int work = 0;                                 // work estimate of this step (longest-first scheduling of the next one)
-  float reward = 0;
-  const float h = T.timestep;
+  X.sim_err = false; X.done = false; X.after_reset = false;
+  X.reason = 0; X.stage_ncon = 0; X.stage_nefc_lo = 0; X.work = 0; X.reward = 0; X.stage = 0;
   if (mode == MODE_STEP || mode == MODE_FORCED) {   // mj_checkPos / mj_checkVel
     const float a = (lane < NQ) ? S.qpos[lane] : 0.f, b = (lane < NV) ? S.qvel[lane] : 0.f;
-    sim_err = __any(!(fabsf(a) <= MAXVALF) || !(fabsf(b) <= MAXVALF));
+    X.sim_err = __any(!(fabsf(a) <= MAXVALF) || !(fabsf(b) <= MAXVALF));
   }
-  int stage = 0;   // RK4 stage of the evaluation about to run (MODE_STEP); every other mode runs one evaluation
-  for (;;) {
-    if (!sim_err) {
-      forward(P, T, env, lane, mode == MODE_STEP && !after_reset && stage > 0);   // the only call site: the evaluation is ~20 k instructions
-      work += 4000 + S.info[1] * (8 + 6 * S.info[3]) + 3000 * ((S.info[6] >> 16) & 0xFF);   // fixed part, rows x sweeps, MPR pairs
-      if (mode == MODE_STEP && !after_reset) {   // [EXT] mj_step with mj_RungeKutta(4): A = (1/2, 1/2, 1), B = (1/6, 1/3, 1/3, 1/6)
-        const float Bw = (stage == 0 || stage == 3) ? 1.f / 6 : 1.f / 3;
-        stage_ncon |= ((unsigned)S.info[0] & 0xFF) << (8 * stage); stage_nefc_lo |= ((unsigned)S.info[1] & 0xFF) << (8 * stage);
+  return true;
+}
+
+// MODE_STEP, after the evaluation of RK stage stage ([EXT] mj_step with mj_RungeKutta(4): A = (1/2, 1/2, 1), B = (1/6, 1/3, 1/3,
+// 1/6)): accumulates, then leaves either the next stage's state in LDS (true: evaluate again) or the step's final state (false).
+__device__ __forceinline__ bool rk_advance(const Launch &P, const Dev &T, const int env, const int lane, StepCtx &X) {
+  const float h = T.timestep;
+        const float Bw = (X.stage == 0 || X.stage == 3) ? 1.f / 6 : 1.f / 3;
+        X.stage_ncon |= ((unsigned)S.info[0] & 0xFF) << (8 * X.stage); X.stage_nefc_lo |= ((unsigned)S.info[1] & 0xFF) << (8 * X.stage);
         if (P.debug) {   // 24-bit hash of the stage's contact list (geom pairs in order): the parity tests hold the index SETS bit-exact
           unsigned hsh = 0;
           for (int c = 0; c < S.info[0]; c++) hsh = (hsh * 131u + (unsigned)S.u.co.c_g1[c] * 97u + (unsigned)S.u.co.c_g2[c] + 1u) & 0xFFFFFFu;
-          if (lane == 0) P.debug[(size_t)env * DMG1_DEBUG_STRIDE + 1012 + stage] = (float)hsh;
+          if (lane == 0) P.debug[(size_t)env * DMG1_DEBUG_STRIDE + 1012 + X.stage] = (float)hsh;
         }
-        if (stage == 0) {
+        if (X.stage == 0) {
           const bool badv = (lane < NV) && !(fabsf(S.qacc[lane]) <= MAXVALF);   // mj_checkAcc
-          sim_err = __any(badv);
-          if (!sim_err) {
+          X.sim_err = __any(badv);
+          if (!X.sim_err) {
             if (lane < NQ) S.x0q[lane] = S.qpos[lane];
             if (lane < NV) { S.x0v[lane] = S.qvel[lane]; S.accq[lane] = 0.f; S.accv[lane] = 0.f; }
           }
         }
-        if (!sim_err) {
+        if (!X.sim_err) {
           float dq = 0, dv = 0;
           if (lane < NV) {
             S.accq[lane] += Bw * S.qvel[lane]; S.accv[lane] += Bw * S.qacc[lane];
-            const float a = (stage == 2) ? 1.f : 0.5f;
+            const float a = (X.stage == 2) ? 1.f : 0.5f;
             dq = a * S.qvel[lane]; dv = a * S.qacc[lane];
           }
           SYNC();
-          if (stage < 3) {
+          if (X.stage < 3) {
             if (lane < NV) S.tmp[lane] = dq;
             SYNC();
             integrate_pos(T, S.tmp, 1.0, true, lane);
             if (lane < NV) S.qvel[lane] = S.x0v[lane] + h * dv;
             SYNC();
-            stage++;
-            continue;
+            X.stage++;
+            return true;
           }
           if (lane < NV) S.qvel[lane] = S.x0v[lane] + h * S.accv[lane];
           integrate_pos(T, S.accq, 1.0, false, lane);
           SYNC();
         }
-      } else if (mode == MODE_FORCED && !after_reset) {
-        const bool badv = (lane < NV) && !(fabsf(S.qacc[lane]) <= MAXVALF);
-        sim_err = __any(badv);
-      }
-    }
+  return false;
+}
+
+// Task layer of the last evaluation (observation, reward, termination, counters, outputs; SURVEY F6: the derived arrays are those
+// of the LAST forward evaluation).  true: the env was reset inside the step (VecEnv auto-reset) and needs one more forward
+// evaluation at the reset state (set_state -> sim.forward) before its observation can be written.
+__device__ __forceinline__ bool task_and_finish(const Launch &P, const Dev &T, const int env, const int lane, StepCtx &X) {
+  const int mode = P.mode;
+  const bool TASK = P.task != 0;
+  const int NOBS_T = TASK ? NOBS_C : NOBS, NTERMS = TASK ? 8 : 5;
     // ---- task layer (derived arrays are those of the LAST forward evaluation)
-    const bool task_pass = !after_reset && (mode == MODE_STEP || mode == MODE_FORCED);
+    const bool task_pass = !X.after_reset && (mode == MODE_STEP || mode == MODE_FORCED);
     float obs_a = 0, obs_b = 0;   // obs[lane], obs[64 + lane]
     float terms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (sim_err) {
-      reward = 0; done = true; reason = 5;
+    if (X.sim_err) {
+      X.reward = 0; X.done = true; X.reason = 5;
       SYNC();
       if (lane < NQ) S.qpos[lane] = T.qpos0[lane];
       if (lane < NV) { S.qvel[lane] = 0; S.warm[lane] = 0; }
@@ -2216,9 +2302,9 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
         if (fl) for (int k = 0; k < 8; k++) if (g1 == T.extra_geom[k] || g2 == T.extra_geom[k]) xc |= 1u << k;
       }
       // motion length / frame: to_getup is a 180-step pseudo clip whose target is frame 1 of getup (combined_env.py:67-99)
-      const int Lm = (TASK && motion == 3) ? P.to_getup_len : clip.L;
-      const int frame = TASK ? ((motion == 3) ? 1 : idx_curr % clip.L) : idx_curr;
-      float ph = TASK ? (float)(idx_curr % Lm) / (float)Lm : (float)idx_curr / (float)clip.L;
+      const int Lm = (TASK && X.motion == 3) ? P.to_getup_len : X.clip.L;
+      const int frame = TASK ? ((X.motion == 3) ? 1 : X.idx_curr % X.clip.L) : X.idx_curr;
+      float ph = TASK ? (float)(X.idx_curr % Lm) / (float)Lm : (float)X.idx_curr / (float)X.clip.L;
       ph = fminf(fmaxf(ph, 0.f), 1.f);
       auto obs_at = [&](int i) -> float {
         if (i < 37) return S.qpos[7 + i];
@@ -2232,15 +2318,15 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
         if (i == 91) return cy;
         if (i == 92) return sy;
         if (i == 93) return 1.f;
-        if (i == 96) return (motion == 3) ? 1.f : 0.f;
-        if (i == 97) return (motion == 2) ? 1.f : 0.f;
+        if (i == 96) return (X.motion == 3) ? 1.f : 0.f;
+        if (i == 97) return (X.motion == 2) ? 1.f : 0.f;
         return 0.f;
       };
       obs_a = obs_at(lane);
       if (lane < NOBS_T - 64) obs_b = obs_at(64 + lane);
       if (task_pass) {
         // ---- calc_imitation_reward, unitree_g1 branch (:193-256)
-        const float *cr = clip.rows + (size_t)frame * CLIP_ROW;
+        const float *cr = X.clip.rows + (size_t)frame * CLIP_ROW;
         float e_cfg = 0, e_vel = 0, adiff = 0;
         int viol = 0;
         if (lane < NREW) {
@@ -2266,74 +2352,74 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
         }
         float cc[3];
         for (int i = 0; i < 3; i++) cc[i] = wsum((lane < NB) ? T.b_mass[lane] * S.xpos[lane][i] : 0.f) * T.total_mass_inv;
-        const float *tc = clip.com + (size_t)frame * 4;
+        const float *tc = X.clip.com + (size_t)frame * 4;
         float ce = 0;
         for (int i = 0; i < 3; i++) { const float df = tc[i] - cc[i]; ce += df * df; }
         terms[0] = expf(-e_cfg); terms[1] = expf(-0.1f * e_vel); terms[2] = expf(-40.f * ee); terms[3] = expf(-10.f * ce);
         terms[4] = nviol / (float)NREW;
-        reward = 0.75f * terms[0] + 0.1f * terms[1] + 0.15f * terms[2] + 0.0f * terms[3] - 0.1f * terms[4];
+        X.reward = 0.75f * terms[0] + 0.1f * terms[1] + 0.15f * terms[2] + 0.0f * terms[3] - 0.1f * terms[4];
         // ---- termination (:418-442)
         const float zc = wsum((lane < NB) ? T.b_mass[lane] * S.xipos[lane][2] : 0.f) * T.total_mass_inv;
         if (TASK) {
           // ---- DPCombinedEnv: task reward (combined_env.py:338-354), motion state machine + termination (:393-445)
           const float ALIM = 0.2617993877991494f, MAX_ANGLE = 1.0471975511965976f;   // deg2rad(15), deg2rad(60)
           const float droll = fabsf(rc[0] - rt[0]), dpitch = fabsf(rc[1] - rt[1]);
-          float imitation = reward, task_r = 0.f;
-          if (motion == 0 || motion == 1) {   // heading + velocity error against the clip's root velocity
+          float imitation = X.reward, task_r = 0.f;
+          if (X.motion == 0 || X.motion == 1) {   // heading + velocity error against the clip's root velocity
             const float ex = cr[62] - S.qvel[0], ey = cr[63] - S.qvel[1];
             task_r = expf(-sqrtf(ex * ex + ey * ey) * 10.f);
           }
-          if (motion == 3) { imitation = 0.f; task_r = expf(-(dsum + dpitch + droll) / 5.f) / 3.f; }
-          reward = imitation * 0.7f + task_r * 0.3f;
+          if (X.motion == 3) { imitation = 0.f; task_r = expf(-(dsum + dpitch + droll) / 5.f) / 3.f; }
+          X.reward = imitation * 0.7f + task_r * 0.3f;
           const unsigned long long badm = __ballot(adiff > ALIM);
           const bool all_close = !__any(!(adiff < ALIM));   // lanes >= 23 carry 0
           terms[5] = imitation; terms[6] = task_r;
           terms[7] = (float)(__popcll(badm) + (dpitch > ALIM ? 1 : 0) + (droll > ALIM ? 1 : 0));   // debug_n_bad_angles
-          done = false; reason = 0;
-          if (idx_curr >= Lm - 1) {   // out of time; :396 compares PlayerAction objects by identity: getup always hands over to run
-            if (motion == 2) { motion = 1; idx_curr = 0; }
-            if (motion == 3) { motion = 2; idx_curr = 0; }
+          X.done = false; X.reason = 0;
+          if (X.idx_curr >= Lm - 1) {   // out of time; :396 compares PlayerAction objects by identity: getup always hands over to run
+            if (X.motion == 2) { X.motion = 1; X.idx_curr = 0; }
+            if (X.motion == 3) { X.motion = 2; X.idx_curr = 0; }
           }
-          if (dpitch < ALIM && droll < ALIM && all_close && motion == 3) { motion = 2; idx_curr = 0; }
-          if (motion == 0 || motion == 1) {
+          if (dpitch < ALIM && droll < ALIM && all_close && X.motion == 3) { X.motion = 2; X.idx_curr = 0; }
+          if (X.motion == 0 || X.motion == 1) {
             const bool fallen = (zc < T.low_z) || (zc > P.high_z) || (droll > MAX_ANGLE) || (dpitch > MAX_ANGLE);
             if (fallen) {
-              if (!(idx_curr > P.amnesty_steps)) { done = true; reason = 7; }
-              motion = 3; idx_curr = 0;
+              if (!(X.idx_curr > P.amnesty_steps)) { X.done = true; X.reason = 7; }
+              X.motion = 3; X.idx_curr = 0;
             }
           }
-          if (P.max_ep_length != 0 && ep_len >= P.max_ep_length) { done = true; reason = 3; }
-          clip = P.clips[motion == 3 ? 2 : motion];
-          idx_curr += 1;   // :454 (not wrapped)
+          if (P.max_ep_length != 0 && X.ep_len >= P.max_ep_length) { X.done = true; X.reason = 3; }
+          X.clip = P.clips[X.motion == 3 ? 2 : X.motion];
+          X.idx_curr += 1;   // :454 (not wrapped)
         } else {
-        if (!(clip.flags & 1)) {
-          done = (zc < T.low_z) || (zc > P.high_z);
-          reason = (zc < T.low_z) ? 1 : 2;
+        if (!(X.clip.flags & 1)) {
+          X.done = (zc < T.low_z) || (zc > P.high_z);
+          X.reason = (zc < T.low_z) ? 1 : 2;
         }
-        if (clip.flags & 4) {
+        if (X.clip.flags & 4) {
           const float mx = 60.f * 3.14159265358979f / 180.f;
-          if (fabsf(rc[0] - rt[0]) > mx || fabsf(rc[1] - rt[1]) > mx) { done = true; reason = 8; }
+          if (fabsf(rc[0] - rt[0]) > mx || fabsf(rc[1] - rt[1]) > mx) { X.done = true; X.reason = 8; }
         }
-        if (P.max_ep_length != 0 && ep_len >= P.max_ep_length) { done = true; reason = 3; }
-        if ((clip.flags & 2) && idx_curr + 1 == clip.L) { done = true; reason = 4; }
-        idx_curr = (idx_curr + 1) % clip.L;
+        if (P.max_ep_length != 0 && X.ep_len >= P.max_ep_length) { X.done = true; X.reason = 3; }
+        if ((X.clip.flags & 2) && X.idx_curr + 1 == X.clip.L) { X.done = true; X.reason = 4; }
+        X.idx_curr = (X.idx_curr + 1) % X.clip.L;
         }
-        ep_rew += reward;
-        ep_len += 1;
+        X.ep_rew += X.reward;
+        X.ep_len += 1;
         const bool ob = !(fabsf(obs_a) <= P.obs_bound) || !(fabsf(obs_b) <= P.obs_bound);
         if (__any(ob)) {
-          obs_a = 0; obs_b = 0; reward = 0; done = true; reason = 6;
+          obs_a = 0; obs_b = 0; X.reward = 0; X.done = true; X.reason = 6;
           for (int i = 0; i < 8; i++) terms[i] = 0;
         }
       }
     }
-    if (P.debug && !after_reset) {
+    if (P.debug && !X.after_reset) {
       float *dbg = P.debug + (size_t)env * DMG1_DEBUG_STRIDE;
       for (int i = lane; i < NB * 3; i += 64) dbg[i] = (&S.xpos[0][0])[i];
       if (lane < NV) { dbg[117 + lane] = S.qas[lane]; dbg[160 + lane] = S.qacc[lane]; }
       if (lane == 0) { dbg[1008] = (float)S.info[5]; dbg[1009] = (float)(S.info[6] & 0xFF); dbg[1010] = (float)((S.info[6] >> 8) & 0xFF); dbg[1011] = (float)((S.info[6] >> 16) & 0xFF);
                        dbg[203] = S.info[0]; dbg[204] = S.info[1]; dbg[205] = S.info[3]; dbg[206] = S.info[2]; dbg[207] = S.info[4];
-                       for (int i = 0; i < 4; i++) { dbg[1000 + i] = (float)((stage_ncon >> (8 * i)) & 0xFF); dbg[1004 + i] = (float)((stage_nefc_lo >> (8 * i)) & 0xFF); } }
+                       for (int i = 0; i < 4; i++) { dbg[1000 + i] = (float)((X.stage_ncon >> (8 * i)) & 0xFF); dbg[1004 + i] = (float)((X.stage_nefc_lo >> (8 * i)) & 0xFF); } }
       if (lane < MAXCON) {
         float *o = dbg + 208 + 9 * lane;
         const bool on = lane < S.info[0];
@@ -2343,42 +2429,82 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
       for (int r = lane; r < MAXROW; r += 64) dbg[640 + r] = (r < S.info[1]) ? P.rows[(size_t)env * 5 * MAXROW + 2 * MAXROW + r] : 0.f;
     }
     if (task_pass) {
-      if (P.rew && lane == 0) P.rew[env] = reward;
-      if (P.done && lane == 0) P.done[env] = done ? 1 : 0;
-      if (P.reason && lane == 0) P.reason[env] = reason;
+      if (P.rew && lane == 0) P.rew[env] = X.reward;
+      if (P.done && lane == 0) P.done[env] = X.done ? 1 : 0;
+      if (P.reason && lane == 0) P.reason[env] = X.reason;
       if (P.terms && lane < NTERMS) P.terms[(size_t)env * NTERMS + lane] = (lane == 0) ? terms[0] : (lane == 1) ? terms[1] : (lane == 2) ? terms[2]
                                                               : (lane == 3) ? terms[3] : (lane == 4) ? terms[4] : (lane == 5) ? terms[5] : (lane == 6) ? terms[6] : terms[7];
-      if (done && P.auto_reset && mode == MODE_STEP) {
+      if (X.done && P.auto_reset && mode == MODE_STEP) {
         if (P.terminal_obs) {
           P.terminal_obs[(size_t)env * NOBS_T + lane] = obs_a;
           if (lane < NOBS_T - 64) P.terminal_obs[(size_t)env * NOBS_T + 64 + lane] = obs_b;
         }
         int fi;
         if (TASK) {   // DPCombinedEnv.reset(rsi=True) (:219-227)
-          motion = (hash32(P.seed, env, rcnt, 0x5EED) & 1) ? 2 : 0;
-          clip = P.clips[motion];
-          idx_curr = (int)(hash32(P.seed, env, rcnt, 0x5EEE) % (uint32_t)clip.L) + (motion == 0 ? P.amnesty_steps + 10 : 0);
-          fi = idx_curr % clip.L;
+          X.motion = (hash32(P.seed, env, X.rcnt, 0x5EED) & 1) ? 2 : 0;
+          X.clip = P.clips[X.motion];
+          X.idx_curr = (int)(hash32(P.seed, env, X.rcnt, 0x5EEE) % (uint32_t)X.clip.L) + (X.motion == 0 ? P.amnesty_steps + 10 : 0);
+          fi = X.idx_curr % X.clip.L;
         } else {
-          fi = (int)(hash32(P.seed, env, rcnt, 0x5EED) % (uint32_t)clip.L);
-          idx_curr = fi;
+          fi = (int)(hash32(P.seed, env, X.rcnt, 0x5EED) % (uint32_t)X.clip.L);
+          X.idx_curr = fi;
         }
-        rcnt++;
-        const float *rr = clip.reset + (size_t)fi * 88;
+        X.rcnt++;
+        const float *rr = X.clip.reset + (size_t)fi * 88;
         SYNC();
         if (lane < NQ) S.qpos[lane] = rr[lane];
         if (lane < NV) S.qvel[lane] = rr[44 + lane];
-        ep_len = 0; ep_rew = 0;
+        X.ep_len = 0; X.ep_rew = 0;
         SYNC();
-        after_reset = true;
-        sim_err = false;
-        continue;   // one more forward evaluation at the reset state (set_state -> sim.forward)
+        X.after_reset = true;
+        X.sim_err = false;
+        return true;   // one more forward evaluation at the reset state (set_state -> sim.forward)
       }
     }
     if (P.obs) {
       P.obs[(size_t)env * NOBS_T + lane] = obs_a;
       if (lane < NOBS_T - 64) P.obs[(size_t)env * NOBS_T + 64 + lane] = obs_b;
     }
+  return false;
+}
+
+__device__ __forceinline__ void step_write_back(const Launch &P, const int env, const int lane, const StepCtx &X) {
+  const int mode = P.mode;
+  const bool TASK = P.task != 0;
+  float *st = P.state + (size_t)env * STATE;
+  int *sti = (int *)st;
+  if (lane < NQ) st[S_QPOS + lane] = S.qpos[lane];
+  if (lane < NV) { st[S_QVEL + lane] = S.qvel[lane]; st[S_WARM + lane] = S.warm[lane]; }
+  if (lane < NU) st[S_CTRL + lane] = S.ctrl[lane];
+  if (lane == 0) { sti[S_IDX] = X.idx_curr; sti[S_EPLEN] = X.ep_len; st[S_EPREW] = X.ep_rew; sti[S_RCNT] = X.rcnt; if (TASK) sti[S_MOTION] = X.motion; }
+  if (P.cost && mode == MODE_STEP && lane == 0) P.cost[env] = X.work;
+}
+
+// The monolithic kernel: one wave runs the whole step (or the single evaluation of the other modes) of its env.
+extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= P.N) return;
+  const int env = (P.order && P.mode == MODE_STEP) ? P.order[blockIdx.x] : (int)blockIdx.x;
+  const Dev &T = *P.T;
+  const int mode = P.mode;
+#ifdef G1_PROFILE
+  if (lane == 0) for (int i = 0; i < 16; i++) S.prof[i] = 0;
+  S.prof_t = clock64();
+#endif
+  StepCtx X;
+  if (!step_enter(P, T, env, lane, X)) return;
+  for (;;) {
+    if (!X.sim_err) {
+      forward(P, T, env, lane, mode == MODE_STEP && !X.after_reset && X.stage > 0);   // the only call site: the evaluation is ~20 k instructions
+      X.work += 4000 + S.info[1] * (8 + 6 * S.info[3]) + 3000 * ((S.info[6] >> 16) & 0xFF);   // fixed part, rows x sweeps, MPR pairs
+      if (mode == MODE_STEP && !X.after_reset) {
+        if (rk_advance(P, T, env, lane, X)) continue;
+      } else if (mode == MODE_FORCED && !X.after_reset) {
+        const bool badv = (lane < NV) && !(fabsf(S.qacc[lane]) <= MAXVALF);
+        X.sim_err = __any(badv);
+      }
+    }
+    if (task_and_finish(P, T, env, lane, X)) continue;
     break;
   }
 #ifdef G1_PROFILE
@@ -2386,11 +2512,207 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_step_kernel(Launch P) {
   SYNC();
   if (P.debug && lane < 16) P.debug[(size_t)env * DMG1_DEBUG_STRIDE + 900 + lane] = (float)S.prof[lane];
 #endif
-  if (lane < NQ) st[S_QPOS + lane] = S.qpos[lane];
-  if (lane < NV) { st[S_QVEL + lane] = S.qvel[lane]; st[S_WARM + lane] = S.warm[lane]; }
-  if (lane < NU) st[S_CTRL + lane] = S.ctrl[lane];
-  if (lane == 0) { sti[S_IDX] = idx_curr; sti[S_EPLEN] = ep_len; st[S_EPREW] = ep_rew; sti[S_RCNT] = rcnt; if (TASK) sti[S_MOTION] = motion; }
-  if (P.cost && mode == MODE_STEP && lane == 0) P.cost[env] = work;
+  step_write_back(P, env, lane, X);
+}
+
+// ------------------------------------------------------------------------------------------ split pipeline (MODE_STEP)
+// At 4 096 envs the monolithic launch lasts as long as its heaviest env (18 M cycles against a 4.1 M mean, 70 % of it MPR pairs run
+// one after the other on that env's wave).  The split pipeline balances the collision stage across the BATCH: per evaluation
+//   g1_env_kernel   (one wave per env, longest-first): [second half of the previous evaluation: contacts of the pair kernel ->
+//                   constraint rows, A, PGS; RK4 bookkeeping / task layer] then [first half of the next one: poses, inertia,
+//                   factorisation, smooth dynamics, broadphase]; the survivors' staged geoms go to the pair queue
+//   g1_pair_kernel  (persistent waves pulling tickets, support-query pairs first): narrowphase of ONE pair per ticket, four waves
+//                   per SIMD (its own register budget and 1.8 KB of LDS) instead of two
+// so a step is 6 env launches + 5 pair launches (4 RK stages + the evaluation at the reset state of envs that ended).  Between
+// launches an env keeps the non-union head of its LDS working set and its StepCtx in an HBM slot (14.3 KB each way: ~0.12 ms per
+// step at 4 096 envs).  Arithmetic and order of operations are those of the monolithic kernel: trajectories are bit-identical
+// (tests/test_g1_gpu.py); only the separating-direction cache differs (one entry per (env, pair); result-neutral either way).
+constexpr int WS_HEAD = (int)offsetof(Lds, u);
+static_assert(WS_HEAD % 16 == 0, "the head of the working set is copied in 16-byte words");
+constexpr int WS_CTX_OFF = WS_HEAD, WS_BYTES = ((WS_HEAD + 128 + 255) / 256) * 256;
+enum { WC_IDX = 0, WC_EPLEN, WC_RCNT, WC_MOTION, WC_CLIPID, WC_REASON, WC_WORK, WC_STAGE, WC_SNCON, WC_SNEFC, WC_EPREW, WC_REWARD, WC_FLAGS,
+       WC_FINISHED = 15 };
+
+__device__ __forceinline__ void ws_save(char *ws, const StepCtx &X, const int lane) {
+  SYNC();
+  uint4 *dst = reinterpret_cast<uint4 *>(ws);
+  const uint4 *src = reinterpret_cast<const uint4 *>(&S);
+  for (int i = lane; i < WS_HEAD / 16; i += 64) dst[i] = src[i];
+  if (lane == 0) {
+    int *w = reinterpret_cast<int *>(ws + WS_CTX_OFF);
+    w[WC_IDX] = X.idx_curr; w[WC_EPLEN] = X.ep_len; w[WC_RCNT] = X.rcnt; w[WC_MOTION] = X.motion; w[WC_CLIPID] = X.clip_id;
+    w[WC_REASON] = X.reason; w[WC_WORK] = X.work; w[WC_STAGE] = X.stage; w[WC_SNCON] = (int)X.stage_ncon; w[WC_SNEFC] = (int)X.stage_nefc_lo;
+    w[WC_EPREW] = __float_as_int(X.ep_rew); w[WC_REWARD] = __float_as_int(X.reward);
+    w[WC_FLAGS] = (X.sim_err ? 1 : 0) | (X.done ? 2 : 0) | (X.after_reset ? 4 : 0);
+    w[WC_FINISHED] = 0;
+  }
+}
+__device__ __forceinline__ void ws_load(const Launch &P, const char *ws, StepCtx &X, const int lane) {
+  const uint4 *src = reinterpret_cast<const uint4 *>(ws);
+  uint4 *dst = reinterpret_cast<uint4 *>(&S);
+  for (int i = lane; i < WS_HEAD / 16; i += 64) dst[i] = src[i];
+  const int *w = reinterpret_cast<const int *>(ws + WS_CTX_OFF);
+  X.idx_curr = w[WC_IDX]; X.ep_len = w[WC_EPLEN]; X.rcnt = w[WC_RCNT]; X.motion = w[WC_MOTION]; X.clip_id = w[WC_CLIPID];
+  X.reason = w[WC_REASON]; X.work = w[WC_WORK]; X.stage = w[WC_STAGE]; X.stage_ncon = (unsigned)w[WC_SNCON]; X.stage_nefc_lo = (unsigned)w[WC_SNEFC];
+  X.ep_rew = __int_as_float(w[WC_EPREW]); X.reward = __int_as_float(w[WC_REWARD]);
+  const int fl = w[WC_FLAGS];
+  X.sim_err = fl & 1; X.done = (fl >> 1) & 1; X.after_reset = (fl >> 2) & 1;
+  X.clip = P.clips[P.task ? (X.motion == 3 ? 2 : X.motion) : X.clip_id];
+  SYNC();
+}
+
+// broadphase of the evaluation; the survivors (canonical order) go to the env's block of the pair queue: pair ids, staged geoms, and
+// one ticket each in the list of their cost class
+__device__ __forceinline__ void emit_pairs(const Dev &T, const Launch &P, const int env, const int lane) {
+  int overflow = 0;
+  const int nsurv = broadphase(T, PAIRCAP, overflow, lane);
+  SYNC();
+  const size_t base = (size_t)env * PAIRCAP;
+  int32_t *ctr = P.qctr + 4 * P.round, *tickA = P.tick, *tickB = P.tick + (size_t)P.N * PAIRCAP;
+  int n_an = 0, n_pm = 0, n_mpr = 0;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int b = 0; b < nsurv; b += 64) {
+    const int s = b + lane;
+    const bool on = s < nsurv;
+    int cls = 0;
+    if (on) {
+      const int p = S.u.co.surv[s];
+      cls = pair_class(T.g_type[T.p_g1[p]], T.g_type[T.p_g2[p]]);
+      P.pq_pair[base + s] = p;
+    }
+    const unsigned long long mh = __ballot(on && cls != 0), ml = __ballot(on && cls == 0);
+    n_mpr += __popcll(__ballot(on && cls == 2)); n_pm += __popcll(__ballot(on && cls == 1)); n_an += __popcll(ml);
+    int bh = 0, bl = 0;
+    if (lane == 0) {
+      if (mh) bh = atomicAdd(&ctr[0], __popcll(mh));
+      if (ml) bl = atomicAdd(&ctr[1], __popcll(ml));
+    }
+    bh = __builtin_amdgcn_readfirstlane(bh); bl = __builtin_amdgcn_readfirstlane(bl);
+    if (on) {
+      if (cls != 0) tickA[bh + __popcll(mh & lt)] = (env << 8) | s;
+      else tickB[bl + __popcll(ml & lt)] = (env << 8) | s;
+    }
+  }
+  for (int s = 0; s < nsurv; s++) {
+    const int p = S.u.co.surv[s];
+    const int g = lane < 18 ? T.p_g1[p] : T.p_g2[p];
+    if (lane < 36) P.pq_geo[(base + s) * 36 + lane] = geo_entry(T, g, lane < 18 ? lane : lane - 18);
+  }
+  if (lane == 0) { S.info[4] = overflow; S.info[5] = nsurv; S.info[6] = n_an | (n_pm << 8) | (n_mpr << 16); }
+}
+
+// the contacts the pair kernel found, in canonical order (survivor order, then the routine's order), into the contact arrays
+__device__ __forceinline__ int gather_contacts(const Dev &T, const Launch &P, const int env, const int lane) {
+  const int nsurv = S.info[5];
+  int overflow = S.info[4], ncon = 0;
+  const size_t base = (size_t)env * PAIRCAP;
+  for (int b = 0; b < nsurv; b += 64) {
+    const int s = b + lane;
+    const bool on = s < nsurv;
+    const int n = on ? P.pq_cnt[base + s] : 0;
+    int incl = n;
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+    const int off = ncon + incl - n;
+    if (n > 0) {
+      const int p = P.pq_pair[base + s];
+      const int g1 = T.p_g1[p], g2 = T.p_g2[p];
+      const float mu = fmaxf(T.g_mu[g1], T.g_mu[g2]);
+      for (int k = 0; k < n; k++) {
+        const int c = off + k;
+        if (c >= MAXCON) break;
+        const float4 *r = reinterpret_cast<const float4 *>(P.pq_con + ((base + s) * 8 + k) * 16);
+        const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+        S.u.co.c_dist[c] = r0.x;
+        S.u.co.c_pos[c][0] = r0.y; S.u.co.c_pos[c][1] = r0.z; S.u.co.c_pos[c][2] = r0.w;
+        float *fr = S.u.co.c_frame[c];
+        fr[0] = r1.x; fr[1] = r1.y; fr[2] = r1.z; fr[3] = r1.w; fr[4] = r2.x; fr[5] = r2.y; fr[6] = r2.z; fr[7] = r2.w; fr[8] = r3.x;
+        S.u.co.c_g1[c] = g1; S.u.co.c_g2[c] = g2; S.u.co.c_mu[c] = mu;
+      }
+    }
+    ncon += __shfl(incl, 63);
+  }
+  if (ncon > MAXCON) { overflow = 1; ncon = MAXCON; }
+  SYNC();
+  if (lane == 0) { S.info[0] = ncon; S.info[4] = overflow; }
+  SYNC();
+  return ncon;
+}
+
+extern "C" __global__ void __launch_bounds__(64, 2) g1_env_kernel(Launch P) {
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= P.N) return;
+  const int env = P.order ? P.order[blockIdx.x] : (int)blockIdx.x;
+  const Dev &T = *P.T;
+  char *ws = P.ws + (size_t)env * WS_BYTES;
+  int *wctx = reinterpret_cast<int *>(ws + WS_CTX_OFF);
+  StepCtx X;
+  if (P.round == 0) {
+    if (!step_enter(P, T, env, lane, X)) { if (lane == 0) wctx[WC_FINISHED] = 1; return; }
+    if (X.sim_err) {   // mj_checkPos / mj_checkVel failed: no evaluation, the task layer reports the error (and may reset the env)
+      if (!task_and_finish(P, T, env, lane, X)) { step_write_back(P, env, lane, X); if (lane == 0) wctx[WC_FINISHED] = 1; return; }
+    }
+  } else {
+    if (wctx[WC_FINISHED]) return;
+    ws_load(P, ws, X, lane);
+    const int ncon = gather_contacts(T, P, env, lane);            // second half of the evaluation in flight
+    forward_post(P, T, env, lane, ncon);
+    X.work += 4000 + S.info[1] * (8 + 6 * S.info[3]) + 3000 * ((S.info[6] >> 16) & 0xFF);
+    bool again = false;
+    if (!X.after_reset) again = rk_advance(P, T, env, lane, X);
+    if (!again && !task_and_finish(P, T, env, lane, X)) { step_write_back(P, env, lane, X); if (lane == 0) wctx[WC_FINISHED] = 1; return; }
+  }
+  forward_pre(T, lane, !X.after_reset && X.stage > 0);              // first half of the next evaluation
+  emit_pairs(T, P, env, lane);
+  ws_save(ws, X, lane);
+}
+
+struct PairLaunch {
+  const Dev *T;
+  const double *mesh_vert; const int32_t *mesh_oidx; const double *mesh_clus;
+  const double *pq_geo; const int32_t *pq_pair; int32_t *pq_cnt; float *pq_con;
+  const int32_t *tick; int32_t *qctr; float *sepc2;
+  int32_t N, pad;
+};
+struct NpLds { double geo[2][18]; int32_t geoi[2][6]; double rc[8][7]; double poly[2][16][3]; double mpr_ps[4][9]; };
+
+// Narrowphase of the split pipeline: persistent one-wave workgroups pull tickets (support-query pairs first: they cost ~10 x an
+// analytic pair) until the queue is empty; one ticket = one (env, pair): its staged geoms in, its contacts out.
+#ifndef G1_PAIR_WAVES
+#define G1_PAIR_WAVES 2   // waves per SIMD of the pair kernel (VGPR budget 256: no spills; 168 at 3 spilled 34 and measured 2 % slower)
+#endif
+extern "C" __global__ void __launch_bounds__(64, G1_PAIR_WAVES) g1_pair_kernel(PairLaunch Q) {
+  __shared__ NpLds Wl;
+  const int lane = threadIdx.x;
+  const Dev &T = *Q.T;
+  const NpStage W = {Wl.geo, Wl.geoi, reinterpret_cast<Con *>(&Wl.rc[0][0]), Wl.poly[0], Wl.poly[1], reinterpret_cast<Sup *>(&Wl.mpr_ps[0][0])};
+  const MeshPtrs M = {Q.mesh_vert, Q.mesh_oidx, Q.mesh_clus};
+  const int nA = Q.qctr[0], nB = Q.qctr[1];      // written by the env launch in front of this one
+  for (;;) {   // every wave leaves as soon as the queue is empty
+    int t = 0;
+    if (lane == 0) t = atomicAdd(&Q.qctr[2], 1);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= nA + nB) break;
+    const int tk = t < nA ? Q.tick[t] : Q.tick[(size_t)Q.N * PAIRCAP + (t - nA)];
+    const int env = tk >> 8, s = tk & 255;
+    const size_t slot = (size_t)env * PAIRCAP + s;
+    const int p = Q.pq_pair[slot];
+    if (lane < 36) Wl.geo[lane / 18][lane % 18] = Q.pq_geo[slot * 36 + lane];
+    if (lane == 0) { stage_geoi(T, W, T.p_g1[p], 0); stage_geoi(T, W, T.p_g2[p], 1); }
+    SYNC();
+    const int n = narrow_pair(M, W, Q.sepc2 + ((size_t)env * 1024 + p) * 4, true, p, 0, lane);
+    SYNC();
+    if (lane == 0) Q.pq_cnt[slot] = n;
+    if (lane < n) {
+      float dist, pos[3], fr[9];
+      contact_record(W.rc[lane], dist, pos, fr);
+      float4 *o = reinterpret_cast<float4 *>(Q.pq_con + (slot * 8 + lane) * 16);
+      o[0] = make_float4(dist, pos[0], pos[1], pos[2]);
+      o[1] = make_float4(fr[0], fr[1], fr[2], fr[3]);
+      o[2] = make_float4(fr[4], fr[5], fr[6], fr[7]);
+      o[3] = make_float4(fr[8], 0.f, 0.f, 0.f);
+    }
+    SYNC();
+  }
 }
 
 // Longest-first launch order: env costs vary by an order of magnitude (a robot lying on the floor solves 100 rows for 50
@@ -2442,6 +2764,12 @@ struct DmG1Engine {
   int L[DMG1_MAX_CLIPS] = {}, flags[DMG1_MAX_CLIPS] = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
+  // split pipeline (dmg1_step of batches >= 512 envs, or DmG1Config.pipeline = 2)
+  bool split = false;
+  char *dWs = nullptr;
+  double *dPqGeo = nullptr;
+  int32_t *dPqPair = nullptr, *dPqCnt = nullptr, *dTick = nullptr, *dQctr = nullptr;
+  float *dPqCon = nullptr, *dSepc2 = nullptr;
 };
 
 static int g1_fail(DmG1Engine *e, int code, const char *msg) {
@@ -2454,6 +2782,7 @@ extern "C" void dmg1_default_config(DmG1Config *c) {
   c->num_envs = 1; c->max_ep_length = 1000; c->vel_obs_scale = 0.1f; c->high_z = 2.0f; c->obs_bound = 100.0f;
   c->seed = 0; c->auto_reset = 1; c->device = 0;
   c->task = 0; c->amnesty_steps = 150; c->to_getup_len = 180;
+  c->pipeline = 0;
 }
 extern "C" size_t dmg1_model_sizeof(void) { return sizeof(DmModelG1); }
 
@@ -2718,6 +3047,17 @@ extern "C" int dmg1_create(const void *model, size_t model_bytes, const DmG1Conf
   if (ok) hipMemset(e->dSepc, 0xFF, N * (4 * g1::SEPC + 4) * sizeof(float));   // pair id -1 everywhere
   ok = ok && hipMalloc(&e->dOrder, N * sizeof(int32_t)) == hipSuccess && hipMalloc(&e->dCost, N * sizeof(int32_t)) == hipSuccess;
   if (ok) hipMemset(e->dCost, 0, N * sizeof(int32_t));
+  e->split = cfg->pipeline == 2 || (cfg->pipeline == 0 && e->N >= 512);
+  if (e->split) {   // ~135 KB per env: 0.55 GB at 4 096 envs
+    const size_t NP = N * g1::PAIRCAP;
+    ok = ok && hipMalloc(&e->dWs, N * g1::WS_BYTES) == hipSuccess;
+    ok = ok && hipMalloc(&e->dPqGeo, NP * 36 * sizeof(double)) == hipSuccess;
+    ok = ok && hipMalloc(&e->dPqPair, NP * sizeof(int32_t)) == hipSuccess && hipMalloc(&e->dPqCnt, NP * sizeof(int32_t)) == hipSuccess;
+    ok = ok && hipMalloc(&e->dPqCon, NP * 8 * 16 * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc(&e->dTick, 2 * NP * sizeof(int32_t)) == hipSuccess && hipMalloc(&e->dQctr, 8 * 4 * sizeof(int32_t)) == hipSuccess;
+    ok = ok && hipMalloc(&e->dSepc2, N * 1024 * 4 * sizeof(float)) == hipSuccess;
+    if (ok) hipMemset(e->dSepc2, 0xFF, N * 1024 * 4 * sizeof(float));   // pair id -1 everywhere
+  }
   if (!ok) { dmg1_destroy(e); return DM_ENOMEM; }
   std::vector<float> init(N * g1::STATE, 0.f);
   for (size_t i = 0; i < N; i++)
@@ -2730,6 +3070,7 @@ extern "C" int dmg1_create(const void *model, size_t model_bytes, const DmG1Conf
 
 extern "C" int dmg1_destroy(DmG1Handle e) {
   if (!e) return DM_EINVAL;
+  hipFree(e->dWs); hipFree(e->dPqGeo); hipFree(e->dPqPair); hipFree(e->dPqCnt); hipFree(e->dPqCon); hipFree(e->dTick); hipFree(e->dQctr); hipFree(e->dSepc2);
   hipFree(e->dT); hipFree(e->dMesh); hipFree(e->dOidx); hipFree(e->dClus); hipFree(e->dState); hipFree(e->dJT); hipFree(e->dBT); hipFree(e->dAR); hipFree(e->dRowsE); hipFree(e->dSepc); hipFree(e->dOrder); hipFree(e->dCost);
   for (int c = 0; c < DMG1_MAX_CLIPS; c++) { hipFree(e->dRows[c]); hipFree(e->dReset[c]); hipFree(e->dCom[c]); }
   if (e->ev0) hipEventDestroy(e->ev0);
@@ -2799,7 +3140,27 @@ static int g1_launch(DmG1Engine *e, g1::Launch &P, void *stream, bool time_it) {
     P.order = e->dOrder;
   }
   if (P.mode == g1::MODE_STEP) P.cost = e->dCost;
-  hipLaunchKernelGGL(g1::g1_step_kernel, dim3(e->N), dim3(64), 0, s, P);
+  if (P.mode == g1::MODE_STEP && e->split) {
+    // split pipeline: 6 env launches around 5 pair launches (4 RK stages + the evaluation at the reset state of envs that ended)
+    P.ws = e->dWs; P.pq_geo = e->dPqGeo; P.pq_pair = e->dPqPair; P.pq_cnt = e->dPqCnt; P.pq_con = e->dPqCon; P.tick = e->dTick;
+    P.qctr = e->dQctr; P.sepc2 = e->dSepc2;
+    hipMemsetAsync(e->dQctr, 0, 8 * 4 * sizeof(int32_t), s);
+    g1::PairLaunch Q;
+    memset(&Q, 0, sizeof Q);
+    Q.T = e->dT; Q.mesh_vert = e->dMesh; Q.mesh_oidx = e->dOidx; Q.mesh_clus = e->dClus; Q.pq_geo = e->dPqGeo; Q.pq_pair = e->dPqPair;
+    Q.pq_cnt = e->dPqCnt; Q.pq_con = e->dPqCon; Q.tick = e->dTick; Q.sepc2 = e->dSepc2; Q.N = e->N;
+    const int pair_waves = std::min(e->N * 8, 256 * 4 * G1_PAIR_WAVES);   // persistent: every wave pulls tickets until the queue is empty
+    for (int r = 0; r < 6; r++) {
+      P.round = r;
+      hipLaunchKernelGGL(g1::g1_env_kernel, dim3(e->N), dim3(64), 0, s, P);
+      if (r < 5) {
+        Q.qctr = e->dQctr + 4 * r;
+        hipLaunchKernelGGL(g1::g1_pair_kernel, dim3(pair_waves), dim3(64), 0, s, Q);
+      }
+    }
+  } else {
+    hipLaunchKernelGGL(g1::g1_step_kernel, dim3(e->N), dim3(64), 0, s, P);
+  }
   if (time_it) { hipEventRecord(e->ev1, s); e->timed = true; }
   return hipGetLastError() == hipSuccess ? DM_OK : g1_fail(e, DM_EHIP, "kernel launch failed");
 }
@@ -2862,6 +3223,21 @@ extern "C" int dmg1_set_counters(DmG1Handle e, const int32_t *idx, const int32_t
   if (eplen) hipLaunchKernelGGL(g1::g1_scatter_int_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, e->dState, e->N, g1::S_EPLEN, g1::STATE, eplen);
   return DM_OK;
 }
+extern "C" int dmg1_queue_counters(DmG1Handle e, int32_t *host_out24) {
+  if (!e || !host_out24) return DM_EINVAL;
+  memset(host_out24, 0, 24 * sizeof(int32_t));
+  if (!e->split) return DM_OK;
+  if (hipSetDevice(e->cfg.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return DM_EHIP;
+  return hipMemcpy(host_out24, e->dQctr, 24 * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess ? DM_OK : DM_EHIP;
+}
+#ifdef G1_PAIRSTATS
+extern "C" int dmg1_pairstats(unsigned long long *host_out8, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(host_out8, HIP_SYMBOL(g1::g_pairstats), 8 * sizeof(unsigned long long));
+  if (reset) { unsigned long long z[8] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g1::g_pairstats), z, sizeof z); }
+  return 0;
+}
+#endif
 extern "C" int dmg1_set_seed(DmG1Handle e, uint64_t seed) {
   if (!e) return DM_EINVAL;
   e->cfg.seed = seed;

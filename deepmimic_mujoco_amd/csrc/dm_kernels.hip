@@ -1651,6 +1651,9 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
   if (TASK) idx_curr = idx_curr < 0 ? 0 : idx_curr;  // n_steps: not wrapped (:454)
   else idx_curr = idx_curr < 0 ? 0 : (idx_curr >= clip.L ? clip.L - 1 : idx_curr);
   float ep_rew = st[DMS_EPREW];
+  // F8 option (DmConfig.stale_contact_slots, src/deepmimic_env.py:88): mujoco-py hands the WHOLE contact array to the foot-contact
+  // scan, so slots >= ncon still show what an earlier evaluation wrote.  One bit per slot and foot, kept in the state row.
+  unsigned f8r = P.f8 ? (unsigned)sti[DMS_F8R] : 0u, f8l = P.f8 ? (unsigned)sti[DMS_F8L] : 0u;
   if (lane < DMK_NQ) S.qpos[lane] = st[DMS_QPOS + lane];
   if (lane < DMK_NV) { S.qvel[lane] = st[DMS_QVEL + lane]; S.warm[lane] = st[DMS_WARM + lane]; }
   if (lane < DMK_NU) S.ctrl[lane] = st[DMS_CTRL + lane];
@@ -1749,6 +1752,18 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
       nefc = S.info[1]; nlimit = S.info[2]; solver_iter = S.info[3]; overflow = S.info[4];
       if (it < 4) { stage_ncon |= (unsigned)(ncon & 0xFF) << (8 * it); stage_nefc |= (unsigned)(nefc & 0xFF) << (8 * it); }
       work += 64 + (nefc > 0 ? 48 + 4 * nefc : 0) + nefc * solver_iter;
+      if (P.f8) {   // every evaluation rewrites slots [0, ncon) of the contact array and leaves the rest
+        bool rfs = false, lfs = false;
+        if (lane < ncon) {
+          const int g1 = S.c_g1[lane], g2 = S.c_g2[lane];
+          const bool fl = (g1 == Ts.floor_geom || g2 == Ts.floor_geom);
+          rfs = fl && (g1 == Ts.rfoot_geom || g2 == Ts.rfoot_geom);
+          lfs = fl && (g1 == Ts.lfoot_geom || g2 == Ts.lfoot_geom);
+        }
+        const unsigned keep = ncon >= 32 ? 0u : (~0u << ncon);
+        f8r = (f8r & keep) | (unsigned)__ballot(rfs);
+        f8l = (f8l & keep) | (unsigned)__ballot(lfs);
+      }
     }
     // ============================================================== end of forward evaluation
     if (it == 0 || (it == 4 && mode == DMK_MODE_FORCED && !after_reset)) {  // mj_checkAcc
@@ -1827,6 +1842,7 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
     PROF(10);
     if (mode == DMK_MODE_PHYSICS) {   // dm_physics_step: sim.step() alone; an instability resets the data as MuJoCo does
       if (sim_err) {
+        f8r = f8l = 0;
         SYNC();
         if (lane < DMK_NQ) S.qpos[lane] = T.qpos0[lane];
         if (lane < DMK_NV) { S.qvel[lane] = 0; S.warm[lane] = 0; }
@@ -1844,6 +1860,7 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
     if (sim_err) {
       // MujocoException path (:366-378): zero obs, zero reward, done, empty info; MuJoCo resets mjData
       reward = 0; done = true; reason = DM_REASON_SIM_ERROR;
+      f8r = f8l = 0;   // mj_resetData clears the contact array
       SYNC();
       if (lane < DMK_NQ) S.qpos[lane] = T.qpos0[lane];
       if (lane < DMK_NV) { S.qvel[lane] = 0; S.warm[lane] = 0; }
@@ -1873,7 +1890,7 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
         rf = fl && (g1 == T.rfoot_geom || g2 == T.rfoot_geom);
         lf = fl && (g1 == T.lfoot_geom || g2 == T.lfoot_geom);
       }
-      const float rff = __any(rf) ? 1.f : 0.f, lff = __any(lf) ? 1.f : 0.f;
+      const float rff = (P.f8 ? f8r != 0 : __any(rf)) ? 1.f : 0.f, lff = (P.f8 ? f8l != 0 : __any(lf)) ? 1.f : 0.f;
       // TASK 1: motion length / frame of the current motion; to_getup is a 180-step pseudo clip whose target is
       // frame 1 of getup (MotionTransition getters, combined_env.py:67-99)
       const int Lm = (TASK && motion == 3) ? P.to_getup_len : clip.L;
@@ -2061,6 +2078,7 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
   if (lane < DMK_NU) st[DMS_CTRL + lane] = S.ctrl[lane];
   if (lane == 0) { sti[DMS_IDX] = idx_curr; sti[DMS_EPLEN] = ep_len; st[DMS_EPREW] = ep_rew; sti[DMS_RCNT] = rcnt; }
   if (TASK && lane == 0) sti[DMS_CLIP] = motion;
+  if (P.f8 && lane == 0) { sti[DMS_F8R] = (int)f8r; sti[DMS_F8L] = (int)f8l; }
   if (P.cost && lane == 0) P.cost[env] = work;
 }
 

@@ -29,7 +29,7 @@ REASONS = {0: None, 1: "low_z", 2: "high_z", 3: "max_ep_len", 4: "acyclical_end"
 EXPORTS = ["dmg1_default_config", "dmg1_model_sizeof", "dmg1_create", "dmg1_destroy", "dmg1_last_error", "dmg1_load_clip",
            "dmg1_reset", "dmg1_step", "dmg1_step_forced", "dmg1_set_state", "dmg1_get_state", "dmg1_get_counters",
            "dmg1_set_counters", "dmg1_set_debug", "dmg1_last_kernel_ms", "dmg1_obs_dim", "dmg1_get_motion", "dmg1_set_motion",
-           "dmg1_set_seed", "dmg1_set_env_clips", "dmg1_get_env_clips"]
+           "dmg1_set_seed", "dmg1_set_env_clips", "dmg1_get_env_clips", "dmg1_queue_counters"]
 
 _i32, _f64 = C.c_int32, C.c_double
 
@@ -137,7 +137,7 @@ def load_g1_model():
 class DmG1Config(C.Structure):
     _fields_ = [("num_envs", C.c_int32), ("max_ep_length", C.c_int32), ("vel_obs_scale", C.c_float), ("high_z", C.c_float),
                 ("obs_bound", C.c_float), ("seed", C.c_uint64), ("auto_reset", C.c_int32), ("device", C.c_int32),
-                ("task", C.c_int32), ("amnesty_steps", C.c_int32), ("to_getup_len", C.c_int32)]
+                ("task", C.c_int32), ("amnesty_steps", C.c_int32), ("to_getup_len", C.c_int32), ("pipeline", C.c_int32)]
 
 
 _BOUND = []
@@ -185,7 +185,7 @@ def _ptr(t):
 class G1HipEngine:
     """Batch of N Unitree G1 DeepMimic environments resident on one MI355X (tensors in, tensors out)."""
 
-    def __init__(self, num_envs, device=0, seed=0, auto_reset=True, max_ep_length=1000, task=TASK_DPENV):
+    def __init__(self, num_envs, device=0, seed=0, auto_reset=True, max_ep_length=1000, task=TASK_DPENV, pipeline=0):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("G1HipEngine needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
@@ -198,6 +198,7 @@ class G1HipEngine:
         self.L.dmg1_default_config(C.byref(cfg))
         cfg.num_envs, cfg.seed, cfg.auto_reset, cfg.device, cfg.max_ep_length = self.N, seed, int(auto_reset), device, max_ep_length
         cfg.task = int(task)
+        cfg.pipeline = int(pipeline)        # 0 auto (split pipeline from 512 envs up), 1 monolithic, 2 split
         self.task = int(task)
         self.obs_dim = NOBS_COMBINED if task else NOBS
         self.terms_dim = 8 if task else 5
@@ -303,6 +304,13 @@ class G1HipEngine:
 
     def last_kernel_ms(self):
         return float(self.L.dmg1_last_kernel_ms(self.h))
+
+    def queue_counters(self):
+        """split pipeline: per round of the last step (support-query pair tickets, analytic pair tickets, tickets pulled)."""
+        buf = (C.c_int32 * 24)()
+        self.L.dmg1_queue_counters.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(self.L.dmg1_queue_counters(self.h, buf), "dmg1_queue_counters")
+        return [tuple(buf[4 * r:4 * r + 3]) for r in range(6)]
 
 
 # ------------------------------------------------------------------------------------------ Gym / VecEnv surfaces

@@ -49,6 +49,9 @@ typedef struct DmG1Config {
                             * max_ep_length 2000 */
   int32_t amnesty_steps;   /* 150 (DPCombinedEnvConfig.AMNESTY_STEPS, combined_env.py:34) */
   int32_t to_getup_len;    /* 180 (MTToGetup.length, combined_env.py:97) */
+  int32_t pipeline;        /* how dmg1_step runs: 0 (default) = split pipeline from 512 envs up, else monolithic; 1 = monolithic (one wave
+                            * runs its env's whole step); 2 = split (per evaluation a per-env launch and a batch-wide narrowphase launch with
+                            * one wave per colliding PAIR; ~135 KB of device memory per env).  Same results either way. */
 } DmG1Config;
 
 void dmg1_default_config(DmG1Config *cfg);
@@ -107,6 +110,10 @@ int dmg1_set_motion(DmG1Handle h, const int32_t *motion, void *stream);
  *  after a step, per RK stage k = 0..3: 1000+k contacts, 1004+k rows (low byte), 1012+k a 24-bit hash of the stage's contact
  *  list h <- (131 h + 97 geom1 + geom2 + 1) mod 2^24 (the oracle keeps the same: "stage_chash<k>") */
 int dmg1_set_debug(DmG1Handle h, float *debug);
+
+/* Diagnostics of the split pipeline: per round r = 0..5 of the LAST dmg1_step, host_out[4 r + 0 / 1 / 2] = tickets of
+ * support-query pairs (MPR, plane-mesh), of analytic pairs, and tickets pulled.  Synchronises the device.  Zeros when monolithic. */
+int dmg1_queue_counters(DmG1Handle h, int32_t *host_out24);
 
 /* Kernel time of the last dmg1_step in ms (HIP events on the launch stream), or < 0. */
 float dmg1_last_kernel_ms(DmG1Handle h);

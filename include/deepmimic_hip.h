@@ -75,7 +75,10 @@ typedef struct DmConfig {
   int32_t integrator;      /* DM_CFG_INT_MODEL (default): <option integrator> of the XML (RK4, xml :9);
                             * DM_CFG_INT_EULER: MuJoCo's semi-implicit Euler with implicit joint damping [EXT mj_Euler]
                             * (one forward evaluation per step instead of four); DM_CFG_INT_RK4 */
-  int32_t reserved0;
+  int32_t stale_contact_slots; /* 0 (default): the foot-contact observation reads the ACTIVE contacts [0, ncon).  1: SURVEY F8, the
+                            * reference's literal behaviour (src/deepmimic_env.py:88,113): mujoco-py's `mjdata.contact` is the whole
+                            * contact array, so slots >= ncon still show the pair an earlier evaluation left there (until a later
+                            * evaluation with more contacts overwrites it, or a simulator error resets the data). */
 } DmConfig;
 
 void dm_default_config(DmConfig *cfg);

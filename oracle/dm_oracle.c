@@ -164,6 +164,7 @@ void dmo_data_reset(const DmModel *m, DmoData *d) {
   memset(d->qacc_warmstart, 0, sizeof d->qacc_warmstart);
   d->time = 0;
   d->ncon = d->nefc = 0;
+  memset(d->contact, 0, sizeof d->contact); /* mj_resetData clears the contact array: what F8's stale slots can hold */
 }
 
 /* ------------------------------------------------------------------ position stage */
@@ -1199,8 +1200,9 @@ void dmo_get_obs(const DmModel *m, const DmoData *d, int idx_curr, int L, double
   obs[T0] = rpy[0] * S; obs[T0 + 1] = rpy[1] * S;
   obs[T0 + 2] = vx * S; obs[T0 + 3] = vy * S; obs[T0 + 4] = vz * S;
   obs[T0 + 5] = cv[0] * S; obs[T0 + 6] = cv[1] * S; obs[T0 + 7] = cv[2] * S;
-  double rf = 0, lf = 0;                                         /* :78-105, active contacts only (F8) */
-  for (int c = 0; c < d->ncon; c++) {
+  double rf = 0, lf = 0;                                         /* :78-105; F8: the reference scans every slot of mjdata.contact */
+  const int nslot = d->stale_contact_slots ? d->maxcon : d->ncon; /* (slots >= ncon keep what earlier evaluations wrote there) */
+  for (int c = 0; c < nslot; c++) {
     int g1 = d->contact[c].geom1, g2 = d->contact[c].geom2;
     int floor = (g1 == m->floor_geom || g2 == m->floor_geom);
     if ((g1 == m->rfoot_geom || g2 == m->rfoot_geom) && floor) rf = 1;
@@ -1600,6 +1602,11 @@ int dmo_get_int(const DmoData *d, const char *name) {
   return -1;
 }
 int dmo_model_sizeof(void) { return (int)sizeof(DmModel); }
+int dmo_set_flag(DmoData *d, const char *name, int v) {
+  if (!strcmp(name, "stale_contact_slots")) { d->stale_contact_slots = v; return 0; }
+  return -1;
+}
+
 int dmo_set_caps(DmoData *d, int maxcon, int maxrow) {
   if (maxcon < 1 || maxcon > DMO_MAXCON || maxrow < 1 || maxrow > DMO_MAXROW) return -1;
   d->maxcon = maxcon; d->maxrow = maxrow;

@@ -66,6 +66,9 @@ typedef struct DmoData {
   int32_t ncon, nefc, solver_iter, nlimit, nfriction, pad_i;
   int32_t overflow_con, overflow_row; /* counts of dropped contacts / rows */
   int32_t stage_ncon[4], stage_nefc[4]; /* per RK stage of the last dmo_step (test diagnostics) */
+  int32_t stale_contact_slots;          /* F8 (src/deepmimic_env.py:88,113): the foot-contact observation scans ALL maxcon slots of the
+                                         * contact array, stale ones included, as mujoco-py's `mjdata.contact` does; 0 (default): [0, ncon) */
+  int32_t pad_f8;
   int32_t stage_chash[4];               /* 24-bit hash of the stage's contact list: h <- (131 h + 97 geom1 + geom2 + 1) mod 2^24 */
   DmoContact contact[DMO_MAXCON];
   int32_t efc_type[DMO_MAXROW], efc_id[DMO_MAXROW]; /* 0 limit, 1 frictionless, 2 pyramidal */

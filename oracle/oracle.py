@@ -143,6 +143,11 @@ class OracleSim:
     def set_caps(self, maxcon, maxrow):
         assert self.L.dmo_set_caps(self.d, maxcon, maxrow) == 0
 
+    def set_flag(self, name, v):
+        """per-sim behaviour switches: "stale_contact_slots" (F8, src/deepmimic_env.py:88)."""
+        self.L.dmo_set_flag.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        assert self.L.dmo_set_flag(self.d, name.encode(), int(v)) == 0
+
     def reset_data(self):
         self.L.dmo_data_reset(C.byref(self.cm), self.d)
 

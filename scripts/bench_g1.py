@@ -12,9 +12,10 @@ from deepmimic_mujoco_amd.mocap import MocapDM  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 motion = sys.argv[3] if len(sys.argv) > 3 else "walk"
+pipeline = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # 0 auto, 1 monolithic kernel, 2 split pipeline
 mc = MocapDM(robot="unitree_g1")
 mc.load_mocap(MotionConfig(motion, robot="unitree_g1").mocap_path)
-eng = G1HipEngine(n, auto_reset=True, seed=3)
+eng = G1HipEngine(n, auto_reset=True, seed=3, pipeline=pipeline)
 eng.load_clip(mc, floor="getup" in motion, acyclic="getup" in motion)
 out = eng.alloc_outputs()
 eng.reset(out["obs"])
@@ -32,5 +33,7 @@ for t in range(steps):
         dn += float(out["done"].float().mean())
 torch.cuda.synchronize()
 dt = time.time() - t0
-print({"envs": n, "motion": motion, "env_steps_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3, "kernel_ms": sum(ks) / len(ks),
+print({"envs": n, "motion": motion, "pipeline": pipeline, "env_steps_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3, "kernel_ms": sum(ks) / len(ks),
        "done_fraction": dn / len(ks), "mean_reward": float(out["rew"].mean())})
+if pipeline != 1:
+    print("pair tickets per round (support-query, analytic, pulled):", eng.queue_counters())

@@ -24,7 +24,7 @@ def main():
                     c, i = r["Counter_Name"], int(r["Dispatch_Id"])
                     per[c][i] = per[c].get(i, 0.0) + float(r["Counter_Value"])
             for c, dv in per.items():
-                last = [dv[i] for i in sorted(dv)[-10:]]
+                last = [dv[i] for i in sorted(dv)[-(12 if kernel == 'g1_env_kernel' else 10):]]   # two steps of the split G1 pipeline: 12 env launches
                 rows.append((c, sum(last) / len(last)))
     with open(out, "w") as fh:
         fh.write("counter,mean_per_dispatch_over_last_10_dispatches\n")

@@ -126,14 +126,14 @@ def _forward_parity(q, v, label, cnrm_tol=1e-5):
     return ncons, nefcs
 
 
-def _teacher_forced(n, steps, act_scale, seed, stride=4):
+def _teacher_forced(n, steps, act_scale, seed, stride=4, pipeline=0):
     import torch
     from deepmimic_mujoco_amd.g1 import G1HipEngine
     from oracle import oracle_g1 as og
     g, _ = og.g1_model()
     mc = _clip("walk")
     clip = og.G1Clip(*mc.tables())
-    eng = G1HipEngine(n, auto_reset=False)
+    eng = G1HipEngine(n, auto_reset=False, pipeline=pipeline)
     eng.load_clip(mc)
     out = eng.alloc_outputs()
     idx = torch.arange(n, dtype=torch.int32, device=eng.device) * stride
@@ -189,12 +189,13 @@ def test_g1_teacher_forced_steps_small_actions():
     assert np.median(r[:, 0]) < 1e-6
 
 
-def test_g1_teacher_forced_steps_large_actions():
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_g1_teacher_forced_steps_large_actions(pipeline):
     """The same with full-scale random torques: the robots thrash, fall and self-collide (mesh-mesh contacts through MPR).
     north_star's gate on every env-step, no exclusion set: qpos L-inf < 1e-4 (measured: max 7e-7), contact lists of all four RK
     stages and termination identical.  (r2 saw ~3 % of these steps off by up to 1e-2: not fp32 poses but a support TIE that
     libccd's MPR constructs at edge-edge contacts and decides by the last bit — oracle/dm_convex.h "ties")"""
-    r = _teacher_forced(24, 80, 1.0, 1, stride=3)
+    r = _teacher_forced(24, 80, 1.0, 1, stride=3, pipeline=pipeline)      # 1: monolithic kernel, 2: split pipeline (pair kernel)
     e = r[:, 0]
     print("G1 teacher-forced, full-scale actions: %d env-steps (%d with MPR contacts); qpos err median %.2e p99 %.2e max %.2e; qvel rel max %.2e" %
           (len(e), int(r[:, 4].sum()), np.median(e), np.percentile(e, 99), e.max(), r[:, 1].max()))
@@ -328,6 +329,48 @@ def test_g1_combined_surfaces():
         obs, rew, done, infos = venv.step(np.zeros((16, 23), np.float32))
         assert obs.shape == (16, 98) and np.isfinite(obs).all() and len(infos) == 16
     venv.close()
+
+
+@pytest.mark.parametrize("task", ["dpenv", "combined"])
+def test_g1_split_pipeline_is_bit_identical_to_the_monolithic_kernel(task):
+    """DmG1Config.pipeline: dmg1_step as ONE launch (a wave runs its env's whole step) or as the split pipeline (6 per-env launches
+    around 5 batch-wide narrowphase launches, one wave per colliding pair).  Same arithmetic in the same order: observations,
+    rewards, terminations, info terms and states are bit-identical over a rollout with auto-resets — robots standing, thrashing,
+    falling, lying on the floor (mesh-floor and mesh-mesh contacts), for DPEnv and for DPCombinedEnv()."""
+    import torch
+    from deepmimic_mujoco_amd.g1 import G1HipEngine, TASK_COMBINED, TASK_DPENV, COMBINED_CLIPS
+    n, steps = 96, 60
+    engs = []
+    for pl in (1, 2):
+        e = G1HipEngine(n, auto_reset=True, seed=9, pipeline=pl, task=TASK_COMBINED if task == "combined" else TASK_DPENV,
+                        max_ep_length=2000 if task == "combined" else 1000)
+        if task == "combined":
+            for cid, m in enumerate(COMBINED_CLIPS):
+                e.load_clip(_clip(m), clip_id=cid)
+        else:
+            e.load_clip(_clip("walk"))
+        engs.append((e, e.alloc_outputs()))
+    for e, o in engs:
+        e.reset(o["obs"])
+    assert torch.equal(engs[0][1]["obs"], engs[1][1]["obs"])
+    g = torch.Generator(device=engs[0][0].device).manual_seed(4)
+    ndone = 0
+    for t in range(steps):
+        act = (torch.rand(n, 23, device=engs[0][0].device, generator=g) * 2 - 1) * (0.25 if task == "combined" else 1.0)
+        for e, o in engs:
+            e.step(act, o)
+        torch.cuda.synchronize()
+        a, b = engs[0][1], engs[1][1]
+        for k in ("obs", "rew", "done", "terms", "reason", "terminal_obs"):
+            assert torch.equal(a[k], b[k]), (task, t, k, int((a[k] != b[k]).sum()))
+        for x, y in zip(engs[0][0].get_state(), engs[1][0].get_state()):
+            assert torch.equal(x, y), (task, t)
+        for x, y in zip(engs[0][0].get_counters(), engs[1][0].get_counters()):
+            assert torch.equal(x, y), (task, t)
+        ndone += int(a["done"].sum())
+    assert ndone >= (3 if task == "combined" else 20)
+    for e, _ in engs:
+        e.close()
 
 
 def test_g1_multi_clip_batches_and_sub_batches_replay_bit_equal():

@@ -404,3 +404,55 @@ def test_three_wave_kernel_variant_parity(model, clips, oracle_clips, torch_mod)
     # identical inputs in every tile -> identical outputs (the variant is deterministic across slots)
     q = res["qpos"].reshape(7, -1)
     assert np.array_equal(q[0], q[3]) and np.array_equal(q[0], q[6])
+
+
+def test_f8_stale_contact_slots_option(model, clips, oracle_clips, torch_mod):
+    """SURVEY F8 as a selectable behaviour (DmConfig.stale_contact_slots, default off): the reference's foot-contact observation
+    (src/deepmimic_env.py:78-105) scans ALL of mujoco-py's `mjdata.contact`, so a foot bit stays set while a stale slot >= ncon
+    still holds the foot-floor pair.  Sequential teacher-forced rollouts, kernel against oracle with the option on both sides:
+    the two foot bits agree on every step, and the option is exercised (steps where the stale scan differs from the active one)."""
+    from deepmimic_mujoco_amd._lib import HipEngine
+    from oracle.oracle import OracleSim
+    torch = torch_mod
+    n, T = 12, 150
+    clip = oracle_clips["walk"]
+    eng = HipEngine(model, n, auto_reset=False, stale_contact_slots=1)
+    eng.load_clip(0, clips["walk"])
+    out = eng.alloc_outputs()
+    idx = (np.arange(n) * 5) % clip.L
+    eng.reset(out["obs"], idx_init=torch.tensor(idx, dtype=torch.int32, device=eng.device))
+    sims = []
+    for i in range(n):
+        s = OracleSim(model)
+        s.set_caps(32, 128)
+        s.set_flag("stale_contact_slots", 1)
+        s.env_reset(clip, int(idx[i]))
+        sims.append(s)
+    rng = np.random.default_rng(8)
+    differs = compared = 0
+    floor, rfoot, lfoot = model.floor_geom, model.rfoot_geom, model.lfoot_geom
+    for t in range(T):
+        st = [np.array([s.get(k) for s in sims]) for k in ("qpos", "qvel", "qacc_warmstart", "ctrl")]
+        eng.set_state(*[torch.tensor(x, dtype=torch.float32, device=eng.device) for x in st], run_forward=False)
+        act = rng.uniform(-0.6, 0.6, (n, 28)).astype(np.float32)
+        eng.step(torch.tensor(act, device=eng.device), out)
+        torch.cuda.synchronize()
+        obs, done = out["obs"].cpu().numpy(), out["done"].cpu().numpy()
+        redo = np.zeros(n, np.uint8)
+        for i, s in enumerate(sims):
+            o, r, d, terms, reason = s.env_step(clip, act[i].astype(np.float64))
+            assert tuple(obs[i, 64:66]) == tuple(o[64:66]), (t, i, obs[i, 64:66], o[64:66])
+            assert np.abs(obs[i] - o).max() < 1e-4 and bool(done[i]) == d
+            con = s.get("contact")
+            active = (float(any({int(c[13]), int(c[14])} == {floor, rfoot} for c in con)), float(any({int(c[13]), int(c[14])} == {floor, lfoot} for c in con)))
+            differs += active != tuple(o[64:66])
+            compared += 1
+            if d:
+                redo[i] = 1
+                s.env_reset(clip, int((idx[i] + t) % clip.L))
+        if redo.any():
+            eng.reset(out["obs"], mask=torch.tensor(redo, device=eng.device),
+                      idx_init=torch.tensor((idx + t) % clip.L, dtype=torch.int32, device=eng.device))
+    print("F8: %d env-steps compared, stale scan differs from the active-contact scan on %d" % (compared, differs))
+    assert compared == n * T and differs >= 10
+    eng.close()
