@@ -27,7 +27,8 @@ EXPORTS = ["dm_default_config", "dm_create", "dm_destroy", "dm_last_error", "dm_
            "dm_fill_random_actions", "dm_last_step_ms", "dm_enable_timing", "dm_get_work",
            "dm_set_clip_flags", "dm_obs_dim", "dm_terms_dim", "dm_get_env_clips", "dm_mean_step_ms", "dm_ppo_loss", "dm_forward", "dm_linear_wgrad", "dm_ppo_gather", "dm_flat_adam_step", "dm_policy_sample",
            "dm_rollout_store", "dm_policy_pack", "dm_policy_forward", "dm_policy_packed_floats", "dm_ppo_mlp_grad", "dm_ppo_mlp_workspace_floats", "dm_flat_adam_update", "dm_colsum", "dm_set_seed",
-           "dm_linear_tanh", "dm_tanh_linear_wgrad", "dm_tanh_bwd_colsum"]
+           "dm_linear_tanh", "dm_tanh_linear_wgrad", "dm_tanh_bwd_colsum",
+           "dm_ppo_wide_grad", "dm_ppo_wide_packed_elems", "dm_ppo_wide_dp", "dm_ppo_wide_supported"]
 
 
 class DmConfig(C.Structure):
@@ -53,6 +54,20 @@ class DmPpoMlpStep(C.Structure):
                 ("log_std", C.c_void_p),
                 ("W", (C.c_void_p * 3) * 2), ("b", (C.c_void_p * 3) * 2), ("gW", (C.c_void_p * 3) * 2), ("gb", (C.c_void_p * 3) * 2),
                 ("g_log_std", C.c_void_p), ("out8", C.c_void_p), ("workspace", C.c_void_p), ("workspace_floats", C.c_longlong),
+                ("zero_ptr", C.c_void_p), ("zero_floats", C.c_longlong), ("adam_state2", C.c_void_p), ("loss_acc", C.c_void_p)]
+
+
+class DmPpoWideStep(C.Structure):
+    """include/deepmimic_hip.h: DmPpoWideStep"""
+    _fields_ = [("B", C.c_int32), ("D", C.c_int32), ("H1", C.c_int32), ("H2", C.c_int32), ("A", C.c_int32),
+                ("normalize_advantage", C.c_int32), ("clip_range", C.c_float), ("vf_coef", C.c_float), ("ent_coef", C.c_float),
+                ("reserved", C.c_int32),
+                ("obs", C.c_void_p), ("act", C.c_void_p), ("adv", C.c_void_p), ("ret", C.c_void_p), ("old_logp", C.c_void_p),
+                ("log_std", C.c_void_p),
+                ("W", (C.c_void_p * 3) * 2), ("b", (C.c_void_p * 3) * 2), ("gW", (C.c_void_p * 3) * 2), ("gb", (C.c_void_p * 3) * 2),
+                ("g_log_std", C.c_void_p),
+                ("wpk", C.c_void_p * 2), ("xbT", C.c_void_p), ("h1T", C.c_void_p * 2), ("dz1T", C.c_void_p * 2), ("h2T", C.c_void_p * 2),
+                ("dz2T", C.c_void_p * 2), ("dz3T", C.c_void_p * 2), ("part", C.c_void_p), ("stats8", C.c_void_p), ("out8", C.c_void_p),
                 ("zero_ptr", C.c_void_p), ("zero_floats", C.c_longlong), ("adam_state2", C.c_void_p), ("loss_acc", C.c_void_p)]
 
 
@@ -98,6 +113,10 @@ def load_library():
     L.dm_policy_packed_floats.argtypes = [i32] * 4
     L.dm_ppo_mlp_workspace_floats.argtypes = [i32] * 5
     L.dm_ppo_mlp_grad.argtypes = [C.POINTER(DmPpoMlpStep), vp]
+    L.dm_ppo_wide_grad.argtypes = [C.POINTER(DmPpoWideStep), vp]
+    L.dm_ppo_wide_packed_elems.argtypes = [i32, i32, i32]
+    L.dm_ppo_wide_dp.argtypes = [i32]
+    L.dm_ppo_wide_supported.argtypes = [i32] * 5
     L.dm_policy_pack.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
     L.dm_policy_forward.argtypes = [vp] + [i32] * 5 + [vp] * 9 + [C.c_uint64, vp, C.c_uint32, i32] + [vp] * 9
     L.dm_flat_adam_step.argtypes = [vp, vp, vp, vp, i32] + [C.c_float] * 6 + [vp, i32, vp]
@@ -120,7 +139,7 @@ def load_library():
     L.dm_mean_step_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     for name in EXPORTS:
         if name not in ("dm_default_config", "dm_last_error"):
-            getattr(L, name).restype = C.c_longlong if name in ("dm_policy_packed_floats", "dm_ppo_mlp_workspace_floats") else C.c_int
+            getattr(L, name).restype = C.c_longlong if name in ("dm_policy_packed_floats", "dm_ppo_mlp_workspace_floats", "dm_ppo_wide_packed_elems") else C.c_int
     _LIB = L
     return L
 

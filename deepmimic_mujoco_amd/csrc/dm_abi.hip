@@ -16,6 +16,7 @@
 #include "dm_ppo.hip"
 #include "dm_policy.hip"
 #include "dm_ppo_mlp.hip"
+#include "dm_ppo_wide.hip"
 
 struct DmEngine {
   DmConfig cfg;

@@ -1,0 +1,581 @@
+// One PPO minibatch of the WIDE actor-critic MLP (net_arch = [1024, 512], the net BASELINE configs 3-5 name) on the bf16 matrix pipe.
+//
+// Reference: src/sb3_ppo.py:254-271,307-312 -> [EXT] SB3 PPO.train on MlpPolicy: per minibatch evaluate_actions (both trunks), the
+// clipped-surrogate / value / entropy loss, backward through both trunks.  The library path of this net is six ~55 us fp32 GEMMs per
+// trunk on a two-stream dependency chain plus a dozen small launches (0.39 ms per optimizer step; with bf16 library GEMMs 0.37 ms: the
+// chain, not the GEMMs, bounds it).  Here the whole forward / loss / input-gradient chain of BOTH trunks is ONE launch:
+//   1. wide_pack_kernel    fp32 master weights -> bf16 in the two layouts the chain reads (W for X W^T, W^T for dZ W); advantage
+//                          statistics; optional folds: clearing the gradient arena, Adam's begin                            (1 launch)
+//   2. wide_fwdbwd_kernel  a workgroup of eight waves carries 32 minibatch rows of one trunk through layer 1, layer 2, the head, the
+//                          loss (the arithmetic of ppo_loss_kernel), and back: d head, d layer 2 (x tanh'), d layer 1 (x tanh');
+//                          activations live in LDS as bf16 (64 + 32 + 32 KB), every product is v_mfma_f32_32x32x16_bf16 with fp32
+//                          accumulation, weights stream from L2 in operand order (a lane's 8 k-values are 16 contiguous bytes of a
+//                          weight row); outputs: the bf16 activations / pre-activation gradients the weight gradients need, the
+//                          bias gradients (column sums, fp32 atomics) and per-workgroup loss partials                         (1 launch)
+//   3. wide_wgrad_kernel   dW = dZ^T X of all six layers: the chain leaves its activations and pre-activation gradients TRANSPOSED
+//                          ([features][batch], written straight from the accumulator registers: four consecutive batch rows of a
+//                          column are 8 bytes), so both operands of dW are 16-byte row reads; a wave owns a 32 x 128 block of dW
+//                          (four accumulators share every A fragment), split-K over workgroups, fp32 atomics into the gradient
+//                          arena; its last block also sums the loss partials                                                  (1 launch)
+// fp32 master weights, fp32 loss arithmetic, fp32 gradients and Adam; bf16 operands of the products only (north_star: "MFMA used
+// only for the policy-MLP GEMMs").  Included by dm_abi.hip after dm_ppo_mlp.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/deepmimic_hip.h"
+
+namespace {
+
+typedef short wide_b8 __attribute__((ext_vector_type(8)));      // 8 bf16 = one MFMA operand fragment (4 VGPRs)
+typedef float wide_f16 __attribute__((ext_vector_type(16)));    // 32 x 32 accumulator: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+
+__device__ __forceinline__ unsigned short wide_f2bf(float x) {  // round to nearest even
+  unsigned u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float wide_bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ float wide_tanh(float x) { return 1.f - __fdividef(2.f, 1.f + __expf(2.f * x)); }
+__device__ __forceinline__ int wide_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+constexpr int WIDE_R = 32, WIDE_NW = 8, WIDE_THREADS = 64 * WIDE_NW, WIDE_PART = 40;
+
+struct WidePackArgs {
+  const float *W[2][3];
+  unsigned short *pk[2];          // per trunk: W1 [H1][Dp] | W2 [H2][H1] | W2T [H1][H2] | W3 [32][H2] | W3T [H2][32]
+  int D, Dp, H1, H2, A[2];
+  long long total;                // elements of one trunk's packed block
+  int pack_blocks;                // blocks [0, 2 * pack_blocks) pack, block 2 * pack_blocks = statistics, the rest clear zero_ptr
+  const float *adv; int B, normalize; float *stats, *out8;
+  float *zero_ptr; long long zero_floats; float *adam_state2;
+};
+
+__global__ void __launch_bounds__(256) wide_pack_kernel(WidePackArgs a) {
+  const int blk = blockIdx.x;
+  if (blk == 2 * a.pack_blocks) {
+    ppo_prepare_body(a.adv, a.B, a.normalize, a.stats, a.out8, nullptr, 0);
+    if (a.adam_state2 && threadIdx.x == 0) { a.adam_state2[0] = 0.f; a.adam_state2[1] += 1.f; }     // Adam's begin
+    return;
+  }
+  if (blk > 2 * a.pack_blocks) {
+    const long long i = ((long long)(blk - 2 * a.pack_blocks - 1) * 256 + threadIdx.x) * 4;
+#pragma unroll
+    for (int c = 0; c < 4; c++) if (i + c < a.zero_floats) a.zero_ptr[i + c] = 0.f;
+    return;
+  }
+  const int t = blk / a.pack_blocks;
+  const long long n1 = (long long)a.H1 * a.Dp, n2 = (long long)a.H2 * a.H1, n3 = 32ll * a.H2;
+  for (long long i = (long long)(blk % a.pack_blocks) * 256 + threadIdx.x; i < a.total; i += (long long)a.pack_blocks * 256) {
+    float v;
+    if (i < n1) { const int o = (int)(i / a.Dp), k = (int)(i % a.Dp); v = k < a.D ? a.W[t][0][(size_t)o * a.D + k] : 0.f; }
+    else if (i < n1 + n2) v = a.W[t][1][i - n1];
+    else if (i < n1 + 2 * n2) { const long long j = i - n1 - n2; const int k = (int)(j / a.H2), o = (int)(j % a.H2); v = a.W[t][1][(size_t)o * a.H1 + k]; }
+    else if (i < n1 + 2 * n2 + n3) { const long long j = i - n1 - 2 * n2; const int o = (int)(j / a.H2), k = (int)(j % a.H2); v = o < a.A[t] ? a.W[t][2][(size_t)o * a.H2 + k] : 0.f; }
+    else { const long long j = i - n1 - 2 * n2 - n3; const int k = (int)(j / 32), o = (int)(j % 32); v = o < a.A[t] ? a.W[t][2][(size_t)o * a.H2 + k] : 0.f; }
+    a.pk[t][i] = wide_f2bf(v);
+  }
+}
+
+struct WideArgs {
+  int B, D, Dp, H1, H2, A;
+  const float *obs, *act, *adv, *ret, *old_logp, *log_std, *stats;
+  const unsigned short *pk[2];
+  const float *b1[2], *b2[2], *b3[2];
+  float *gb1[2], *gb2[2], *gb3[2];
+  unsigned short *xbT, *h1T[2], *dz1T[2], *h2T[2], *dz2T[2], *dz3T[2];   // [features][B] bf16
+  float *part;
+  float clip, vf_coef;
+};
+
+// four consecutive batch rows of one column (accumulator registers 4 q .. 4 q + 3 of a lane) as 8 bytes of a [features][B] array
+__device__ __forceinline__ void wide_store_t4(unsigned short *T, size_t B, int col, int row0, float v0, float v1, float v2, float v3) {
+  uint2 u;
+  u.x = (unsigned)wide_f2bf(v0) | ((unsigned)wide_f2bf(v1) << 16);
+  u.y = (unsigned)wide_f2bf(v2) | ((unsigned)wide_f2bf(v3) << 16);
+  *reinterpret_cast<uint2 *>(T + (size_t)col * B + row0) = u;
+}
+
+__global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
+  extern __shared__ __align__(16) char wide_lds[];
+  const int trunk = blockIdx.y, b0 = blockIdx.x * WIDE_R;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int Dp = a.Dp, H1 = a.H1, H2 = a.H2, At = trunk ? 1 : a.A;      // head width: actions (policy trunk) / 1 (value trunk)
+  const size_t B = (size_t)a.B;
+  const int SX = 2 * Dp + 16, S1 = 2 * H1 + 16, S2 = 2 * H2 + 16, S3 = 64 + 16;     // row strides (bytes): 16-byte reads of 32 rows spread over the banks
+  const int RZ = WIDE_R * S2 > WIDE_NW * 4096 ? WIDE_R * S2 : WIDE_NW * 4096;      // dZ2s shares its block with the head's partial tiles
+  char *Xs = wide_lds, *H1s = Xs + WIDE_R * SX, *H2s = H1s + WIDE_R * S1, *dZ2s = H2s + WIDE_R * S2, *dZ3s = dZ2s + RZ;
+  float *red = reinterpret_cast<float *>(dZ2s);                 // head: eight K-slices of the 32 x 32 output (32 KB; dZ2s is not live yet)
+  float *outs = reinterpret_cast<float *>(dZ3s + WIDE_R * S3);  // [32][33] head outputs (+ bias)
+  float *accs = outs + 32 * 33;                                 // [16][36] loss partials of the half-waves
+  const unsigned short *W1 = a.pk[trunk], *W2 = W1 + (size_t)H1 * Dp, *W2T = W2 + (size_t)H2 * H1, *W3 = W2T + (size_t)H1 * H2,
+                       *W3T = W3 + 32 * (size_t)H2;
+
+  // ---- observations -> bf16 rows (zero-padded to Dp); trunk 0 also files them, transposed, for the weight gradient of layer 1
+  for (int i = tid; i < WIDE_R * Dp; i += WIDE_THREADS) {
+    const int k = i >> 5, m = i & 31;                                  // (consecutive threads: consecutive rows of one column)
+    const unsigned short v = wide_f2bf(k < a.D ? a.obs[(size_t)(b0 + m) * a.D + k] : 0.f);
+    *reinterpret_cast<unsigned short *>(Xs + m * SX + 2 * k) = v;
+    if (trunk == 0) a.xbT[(size_t)k * B + b0 + m] = v;
+  }
+  __syncthreads();
+
+  // ---- layer 1: H1 = tanh(X W1^T + b1).  A = X rows from LDS (lane: row r, k = 8 h + j), B = W1 rows from L2 (lane: column r)
+  for (int t = wave; t < (H1 >> 5); t += WIDE_NW) {
+    wide_f16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc[j] = 0.f;
+    const unsigned short *wrow = W1 + (size_t)(t * 32 + r) * Dp + 8 * h;
+    for (int ks = 0; ks < (Dp >> 4); ks++) {
+      const wide_b8 av = *reinterpret_cast<const wide_b8 *>(Xs + r * SX + (ks * 16 + 8 * h) * 2);
+      const wide_b8 bv = *reinterpret_cast<const wide_b8 *>(wrow + ks * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+    }
+    const float bias = a.b1[trunk][t * 32 + r];
+    const int n = t * 32 + r;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        v[i] = wide_tanh(acc[4 * q + i] + bias);
+        *reinterpret_cast<unsigned short *>(H1s + (8 * q + 4 * h + i) * S1 + 2 * n) = wide_f2bf(v[i]);
+      }
+      wide_store_t4(a.h1T[trunk], B, n, b0 + 8 * q + 4 * h, v[0], v[1], v[2], v[3]);
+    }
+  }
+  __syncthreads();
+
+  // ---- layer 2: H2 = tanh(H1 W2^T + b2): two 32-column tiles per wave per pass share every A fragment; the weight rows stream
+  // from L2 through a two-deep ring of register blocks (eight k-steps each), so sixteen loads per lane are always in flight
+  for (int t0 = 2 * wave; t0 < (H2 >> 5); t0 += 2 * WIDE_NW) {
+    wide_f16 acc0, acc1;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { acc0[j] = 0.f; acc1[j] = 0.f; }
+    const char *ap = H1s + r * S1 + 16 * h;
+    const unsigned short *wr0 = W2 + (size_t)(t0 * 32 + r) * H1 + 8 * h, *wr1 = wr0 + 32 * (size_t)H1;
+    constexpr int KB = 8;
+    wide_b8 p0[KB], p1[KB], q0[KB], q1[KB];
+    const int nblk = (H1 >> 4) / KB;                       // H1 % 256 == 0: an even number of blocks
+#pragma unroll
+    for (int i = 0; i < KB; i++) { p0[i] = *reinterpret_cast<const wide_b8 *>(wr0 + i * 16); p1[i] = *reinterpret_cast<const wide_b8 *>(wr1 + i * 16); }
+    for (int kb = 0; kb < nblk; kb += 2) {
+#pragma unroll
+      for (int i = 0; i < KB; i++) { q0[i] = *reinterpret_cast<const wide_b8 *>(wr0 + ((kb + 1) * KB + i) * 16); q1[i] = *reinterpret_cast<const wide_b8 *>(wr1 + ((kb + 1) * KB + i) * 16); }
+#pragma unroll
+      for (int i = 0; i < KB; i++) {
+        const wide_b8 av = *reinterpret_cast<const wide_b8 *>(ap + (kb * KB + i) * 32);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, p0[i], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, p1[i], acc1, 0, 0, 0);
+      }
+      if (kb + 2 < nblk) {
+#pragma unroll
+        for (int i = 0; i < KB; i++) { p0[i] = *reinterpret_cast<const wide_b8 *>(wr0 + ((kb + 2) * KB + i) * 16); p1[i] = *reinterpret_cast<const wide_b8 *>(wr1 + ((kb + 2) * KB + i) * 16); }
+      }
+#pragma unroll
+      for (int i = 0; i < KB; i++) {
+        const wide_b8 av = *reinterpret_cast<const wide_b8 *>(ap + ((kb + 1) * KB + i) * 32);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, q0[i], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, q1[i], acc1, 0, 0, 0);
+      }
+    }
+    const int n0 = t0 * 32 + r, n1 = n0 + 32;
+    const float bias0 = a.b2[trunk][n0], bias1 = a.b2[trunk][n1];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      float v[4], w[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        v[i] = wide_tanh(acc0[4 * q + i] + bias0); w[i] = wide_tanh(acc1[4 * q + i] + bias1);
+        *reinterpret_cast<unsigned short *>(H2s + (8 * q + 4 * h + i) * S2 + 2 * n0) = wide_f2bf(v[i]);
+        *reinterpret_cast<unsigned short *>(H2s + (8 * q + 4 * h + i) * S2 + 2 * n1) = wide_f2bf(w[i]);
+      }
+      wide_store_t4(a.h2T[trunk], B, n0, b0 + 8 * q + 4 * h, v[0], v[1], v[2], v[3]);
+      wide_store_t4(a.h2T[trunk], B, n1, b0 + 8 * q + 4 * h, w[0], w[1], w[2], w[3]);
+    }
+  }
+  __syncthreads();
+
+  // ---- head: out = H2 W3^T (32 columns, padded): K split over the eight waves, partial tiles summed through LDS
+  {
+    wide_f16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc[j] = 0.f;
+    const int kper = (H2 >> 4) / WIDE_NW;                     // k-steps per wave (H2 = 512: 4)
+    for (int q = 0; q < kper; q++) {
+      const int ks = wave * kper + q;
+      const wide_b8 av = *reinterpret_cast<const wide_b8 *>(H2s + r * S2 + (ks * 16 + 8 * h) * 2);
+      const wide_b8 bv = *reinterpret_cast<const wide_b8 *>(W3 + (size_t)r * H2 + ks * 16 + 8 * h);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) red[wave * 1024 + j * 64 + lane] = acc[j];
+  }
+  __syncthreads();
+  for (int e = tid; e < 1024; e += WIDE_THREADS) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < WIDE_NW; w++) s += red[w * 1024 + e];
+    const int l = e & 63, j = e >> 6, n = l & 31;
+    outs[wide_row(j, l >> 5) * 33 + n] = s + (n < At ? a.b3[trunk][n] : 0.f);
+  }
+  __syncthreads();
+
+  // ---- loss (arithmetic of ppo_loss_kernel): a half-wave per row, lane = action index; d out -> dZ3s (bf16) and, transposed, HBM
+  {
+    const int j = tid & 31, hw = tid >> 5;                    // 16 half-waves, two rows each
+    const bool ja = j < a.A;
+    const float invB = 1.0f / (float)a.B, amean = a.stats[0], ainv = a.stats[1];
+    float g_ls = 0.f, pg = 0.f, vl = 0.f, kl = 0.f, cf = 0.f;
+    float ls = 0.f, iv = 0.f, lconst = 0.f;
+    if (trunk == 0) {
+      ls = ja ? a.log_std[j] : 0.f;
+      iv = ja ? expf(-2.f * ls) : 0.f;
+      float sum_ls = ls;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) sum_ls += __shfl_xor(sum_ls, o);
+      lconst = -sum_ls - 0.5f * 1.8378770664093453f * (float)a.A;
+    }
+    for (int m = hw; m < WIDE_R; m += 16) {
+      const int b = b0 + m;
+      float dz = 0.f;
+      if (trunk == 0) {
+        const float d = ja ? a.act[(size_t)b * a.A + j] - outs[m * 33 + j] : 0.f;
+        const float z2 = d * d * iv;
+        float zs = z2;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) zs += __shfl_xor(zs, o);
+        const float logp = -0.5f * zs + lconst;
+        const float a_n = (a.adv[b] - amean) * ainv;
+        const float lr = logp - a.old_logp[b];
+        const float ratio = expf(lr);
+        const float rc = fminf(fmaxf(ratio, 1.f - a.clip), 1.f + a.clip);
+        const float p1 = a_n * ratio, p2 = a_n * rc;
+        const bool inside = (ratio >= 1.f - a.clip) && (ratio <= 1.f + a.clip);
+        const float dr = (inside || p1 < p2) ? a_n : 0.f;
+        const float dlogp = -invB * dr * ratio;
+        dz = ja ? dlogp * d * iv : 0.f;
+        g_ls += ja ? dlogp * (z2 - 1.f) : 0.f;
+        if (j == 0) { pg += -fminf(p1, p2); kl += (ratio - 1.f) - lr; cf += (fabsf(ratio - 1.f) > a.clip) ? 1.f : 0.f; }
+      } else {
+        const float dv = outs[m * 33] - a.ret[b];
+        dz = (j == 0) ? a.vf_coef * 2.f * invB * dv : 0.f;
+        if (j == 0) vl += dv * dv;
+      }
+      const unsigned short dzb = wide_f2bf(dz);
+      *reinterpret_cast<unsigned short *>(dZ3s + m * S3 + 2 * j) = dzb;
+      a.dz3T[trunk][(size_t)j * B + b] = dzb;
+    }
+    accs[hw * 36 + j] = g_ls;
+    if (j == 0) { accs[hw * 36 + 32] = pg; accs[hw * 36 + 33] = vl; accs[hw * 36 + 34] = kl; accs[hw * 36 + 35] = cf; }
+  }
+  __syncthreads();
+  if (tid < 36) {   // this workgroup's partial sums (summed in fixed order by the weight-gradient launch's last block)
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) t += accs[i * 36 + tid];
+    a.part[((size_t)trunk * gridDim.x + blockIdx.x) * WIDE_PART + tid] = t;
+  }
+  // bias gradient of the head: column sums of dZ3 over the workgroup's rows
+  if (tid < At) {
+    float s = 0.f;
+    for (int m = 0; m < WIDE_R; m++) s += wide_bf2f(*reinterpret_cast<const unsigned short *>(dZ3s + m * S3 + 2 * tid));
+    atomicAdd(&a.gb3[trunk][tid], s);
+  }
+
+  // ---- d layer 2: dZ2 = (dZ3 W3) x (1 - H2^2).  A = dZ3 rows (K = 32: two k-steps), B[k = a][col = n] = W3T row n
+  for (int t0 = 2 * wave; t0 < (H2 >> 5); t0 += 2 * WIDE_NW) {
+    wide_f16 acc0, acc1;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { acc0[j] = 0.f; acc1[j] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      const wide_b8 av = *reinterpret_cast<const wide_b8 *>(dZ3s + r * S3 + (ks * 16 + 8 * h) * 2);
+      const wide_b8 b0v = *reinterpret_cast<const wide_b8 *>(W3T + (size_t)(t0 * 32 + r) * 32 + ks * 16 + 8 * h);
+      const wide_b8 b1v = *reinterpret_cast<const wide_b8 *>(W3T + (size_t)(t0 * 32 + 32 + r) * 32 + ks * 16 + 8 * h);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b0v, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b1v, acc1, 0, 0, 0);
+    }
+    const int n0 = t0 * 32 + r, n1 = n0 + 32;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      float v[4], w[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int m = 8 * q + 4 * h + i;
+        const float x0 = wide_bf2f(*reinterpret_cast<const unsigned short *>(H2s + m * S2 + 2 * n0));
+        const float x1 = wide_bf2f(*reinterpret_cast<const unsigned short *>(H2s + m * S2 + 2 * n1));
+        v[i] = acc0[4 * q + i] * (1.f - x0 * x0); w[i] = acc1[4 * q + i] * (1.f - x1 * x1);
+        s0 += v[i]; s1 += w[i];
+        *reinterpret_cast<unsigned short *>(dZ2s + m * S2 + 2 * n0) = wide_f2bf(v[i]);
+        *reinterpret_cast<unsigned short *>(dZ2s + m * S2 + 2 * n1) = wide_f2bf(w[i]);
+      }
+      wide_store_t4(a.dz2T[trunk], B, n0, b0 + 8 * q + 4 * h, v[0], v[1], v[2], v[3]);
+      wide_store_t4(a.dz2T[trunk], B, n1, b0 + 8 * q + 4 * h, w[0], w[1], w[2], w[3]);
+    }
+    s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32);
+    if (h == 0) { atomicAdd(&a.gb2[trunk][n0], s0); atomicAdd(&a.gb2[trunk][n1], s1); }
+  }
+  __syncthreads();
+
+  // ---- d layer 1: dZ1 = (dZ2 W2) x (1 - H1^2).  A = dZ2 rows (K = H2), B[k = n][col = k1] = W2T row k1; four 32-column tiles per
+  // wave share every A fragment; weight rows through a two-deep ring of four-k-step register blocks
+  for (int t0 = 4 * wave; t0 < (H1 >> 5); t0 += 4 * WIDE_NW) {
+    wide_f16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int j = 0; j < 16; j++) acc[q][j] = 0.f;
+    const char *ap = dZ2s + r * S2 + 16 * h;
+    const unsigned short *wrow = W2T + (size_t)(t0 * 32 + r) * H2 + 8 * h;
+    constexpr int KB = 4;
+    wide_b8 pb[4][KB], qb[4][KB];
+    const int nblk = (H2 >> 4) / KB;                       // H2 % 128 == 0: an even number of blocks
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int i = 0; i < KB; i++) pb[q][i] = *reinterpret_cast<const wide_b8 *>(wrow + (size_t)q * 32 * H2 + i * 16);
+    for (int kb = 0; kb < nblk; kb += 2) {
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int i = 0; i < KB; i++) qb[q][i] = *reinterpret_cast<const wide_b8 *>(wrow + (size_t)q * 32 * H2 + ((kb + 1) * KB + i) * 16);
+#pragma unroll
+      for (int i = 0; i < KB; i++) {
+        const wide_b8 av = *reinterpret_cast<const wide_b8 *>(ap + (kb * KB + i) * 32);
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pb[q][i], acc[q], 0, 0, 0);
+      }
+      if (kb + 2 < nblk) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+          for (int i = 0; i < KB; i++) pb[q][i] = *reinterpret_cast<const wide_b8 *>(wrow + (size_t)q * 32 * H2 + ((kb + 2) * KB + i) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < KB; i++) {
+        const wide_b8 av = *reinterpret_cast<const wide_b8 *>(ap + ((kb + 1) * KB + i) * 32);
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, qb[q][i], acc[q], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      float s = 0.f;
+      const int n = (t0 + q) * 32 + r;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const float x = wide_bf2f(*reinterpret_cast<const unsigned short *>(H1s + (8 * g + 4 * h + i) * S1 + 2 * n));
+          v[i] = acc[q][4 * g + i] * (1.f - x * x);
+          s += v[i];
+        }
+        wide_store_t4(a.dz1T[trunk], B, n, b0 + 8 * g + 4 * h, v[0], v[1], v[2], v[3]);
+      }
+      s += __shfl_xor(s, 32);
+      if (h == 0) atomicAdd(&a.gb1[trunk][n], s);
+    }
+  }
+}
+
+// dW = dZ^T X for the six layers.  Operands are the TRANSPOSED arrays the chain wrote: AT = dZ^T [O][B], XT = X^T [I][B], so both
+// MFMA fragments are 16-byte row reads (lane: row / column r, batch rows 8 h .. 8 h + 7).  ONE wave owns a block of eight 32 x 32
+// tiles of dW — 64 x 128 (RO = 2), or 32 x 256 for the heads (RO = 1) — over its slice of the batch: per k-step 6 (9) fragment
+// loads feed 8 MFMAs, and no operand is fetched twice inside a workgroup.  (Measured alternatives: 32 x 128 per wave with four waves
+// per workgroup re-reads X four times: 87 us, bound by those reads; sixteen tiles per wave — 128 x 128 — do not register-allocate:
+// 928 spilled VGPRs, 245 us.)  Split-K over workgroups, fp32 atomics into the gradient arena (zero on entry).  The last block sums
+// the loss partials (fixed order).
+struct WideWgradJob { const unsigned short *AT, *XT; float *dW; int O, I, ldw, ro, otiles, itiles, splitk, first; };
+struct WideWgradArgs {
+  WideWgradJob j[6];
+  int njobs, nblocks, B;
+  const float *part; int nblk, A; const float *log_std; float vf_coef, ent_coef; const float *stats; float *g_log_std, *out8, *loss_acc;
+};
+
+template <int RO>
+__device__ __forceinline__ void wide_wgrad_tile(const WideWgradJob &J, const int Bn, const int ot, const int it, const int ks, const int lane) {
+  constexpr int CI = 8 / RO;
+  const int r = lane & 31, h = lane >> 5;
+  const int o0 = ot * 32 * RO, i0 = it * 32 * CI;
+  const size_t B = (size_t)Bn;
+  const int kchunk = Bn / J.splitk, k0 = ks * kchunk;           // batch rows of this split (a multiple of 32)
+  const unsigned short *ap = J.AT + (size_t)(o0 + r) * B + k0 + 8 * h;
+  const unsigned short *xp = J.XT + (size_t)(i0 + r) * B + k0 + 8 * h;
+  bool oa[RO], ia[CI];
+#pragma unroll
+  for (int p = 0; p < RO; p++) oa[p] = (o0 + 32 * p + r) < J.O;
+#pragma unroll
+  for (int q = 0; q < CI; q++) ia[q] = (i0 + 32 * q + r) < J.I;
+  wide_f16 acc[RO][CI];
+#pragma unroll
+  for (int p = 0; p < RO; p++)
+#pragma unroll
+    for (int q = 0; q < CI; q++)
+#pragma unroll
+      for (int j = 0; j < 16; j++) acc[p][q][j] = 0.f;
+  const wide_b8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  // two-deep ring of register blocks of two k-steps: the loads of the next block are in flight under the 16 MFMAs of this one
+  constexpr int KB = 2;
+  wide_b8 av[RO][KB], xv[CI][KB], aw[RO][KB], xw[CI][KB];
+  auto load_blk = [&](wide_b8 (&A_)[RO][KB], wide_b8 (&X_)[CI][KB], const int kk) {
+#pragma unroll
+    for (int i = 0; i < KB; i++) {
+#pragma unroll
+      for (int p = 0; p < RO; p++) A_[p][i] = oa[p] ? *reinterpret_cast<const wide_b8 *>(ap + (size_t)p * 32 * B + (kk + i) * 16) : zero;
+#pragma unroll
+      for (int q = 0; q < CI; q++) X_[q][i] = ia[q] ? *reinterpret_cast<const wide_b8 *>(xp + (size_t)q * 32 * B + (kk + i) * 16) : zero;
+    }
+  };
+  auto mma_blk = [&](const wide_b8 (&A_)[RO][KB], const wide_b8 (&X_)[CI][KB]) {
+#pragma unroll
+    for (int i = 0; i < KB; i++)
+#pragma unroll
+      for (int p = 0; p < RO; p++)
+#pragma unroll
+        for (int q = 0; q < CI; q++) acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[p][i], X_[q][i], acc[p][q], 0, 0, 0);
+  };
+  const int nks = kchunk >> 4;                       // a multiple of 2 KB (kchunk % 64 == 0)
+  load_blk(av, xv, 0);
+  for (int kk = 0; kk < nks; kk += 2 * KB) {
+    if (kk + KB < nks) load_blk(aw, xw, kk + KB);
+    mma_blk(av, xv);
+    if (kk + 2 * KB < nks) load_blk(av, xv, kk + 2 * KB);
+    if (kk + KB < nks) mma_blk(aw, xw);
+  }
+#pragma unroll
+  for (int p = 0; p < RO; p++)
+#pragma unroll
+    for (int q = 0; q < CI; q++) {
+      if (!ia[q]) continue;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const int row = o0 + 32 * p + wide_row(j, h);
+        if (row < J.O) atomicAdd(&J.dW[(size_t)row * J.ldw + i0 + 32 * q + r], acc[p][q][j]);
+      }
+    }
+}
+
+__global__ void __launch_bounds__(64) wide_wgrad_kernel(WideWgradArgs a) {
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  if (blk == a.nblocks) {   // loss scalars and the log_std gradient from the per-workgroup partials (one wave, fixed order)
+    __shared__ float red[2][36];
+    if (tid < 36) {
+      for (int t = 0; t < 2; t++) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;       // four independent chains: the loads overlap
+        int i = 0;
+        for (; i + 3 < a.nblk; i += 4) {
+          s0 += a.part[((size_t)t * a.nblk + i) * WIDE_PART + tid]; s1 += a.part[((size_t)t * a.nblk + i + 1) * WIDE_PART + tid];
+          s2 += a.part[((size_t)t * a.nblk + i + 2) * WIDE_PART + tid]; s3 += a.part[((size_t)t * a.nblk + i + 3) * WIDE_PART + tid];
+        }
+        for (; i < a.nblk; i++) s0 += a.part[((size_t)t * a.nblk + i) * WIDE_PART + tid];
+        red[t][tid] = (s0 + s1) + (s2 + s3);
+      }
+    }
+    __syncthreads();
+    if (tid < a.A) a.g_log_std[tid] += red[0][tid] - a.ent_coef;
+    if (tid == 0) {
+      const float invB = 1.0f / (float)a.B;
+      float ent = 0.f;
+      for (int j = 0; j < a.A; j++) ent += 0.5f + 0.5f * 1.8378770664093453f + a.log_std[j];
+      const float pg = red[0][32] * invB, vl = red[1][33] * invB;
+      a.out8[1] = pg; a.out8[2] = vl; a.out8[3] = ent; a.out8[4] = red[0][34] * invB; a.out8[5] = red[0][35] * invB;
+      a.out8[0] = pg + a.vf_coef * vl - a.ent_coef * ent;
+      a.out8[6] = a.stats[0]; a.out8[7] = a.stats[1];
+      if (a.loss_acc) { a.loss_acc[0] += a.out8[0]; a.loss_acc[1] += 1.f; }
+    }
+    return;
+  }
+  int jq = 0;
+  for (int i = 1; i < a.njobs; i++) if (blk >= a.j[i].first) jq = i;
+  const WideWgradJob &J = a.j[jq];
+  int rem = blk - J.first;
+  const int ks = rem % J.splitk; rem /= J.splitk;
+  const int it = rem % J.itiles, ot = rem / J.itiles;
+  if (J.ro == 2) wide_wgrad_tile<2>(J, a.B, ot, it, ks, tid);
+  else wide_wgrad_tile<1>(J, a.B, ot, it, ks, tid);
+}
+
+inline int wide_dp(int D) { return (D + 15) & ~15; }
+inline long long wide_packed_elems(int D, int H1, int H2) { return (long long)H1 * wide_dp(D) + 2ll * H2 * H1 + 64ll * H2; }
+inline int wide_lds_bytes(int D, int H1, int H2) {
+  const int z2 = WIDE_R * (2 * H2 + 16), rz = z2 > WIDE_NW * 4096 ? z2 : WIDE_NW * 4096;
+  return WIDE_R * (2 * wide_dp(D) + 16) + WIDE_R * (2 * H1 + 16) + z2 + rz + WIDE_R * 80 + (32 * 33 + 16 * 36) * 4;
+}
+inline bool wide_supported(int B, int D, int H1, int H2, int A) {
+  return B >= 64 && B % 64 == 0 && D >= 1 && D <= 112 && H1 % 256 == 0 && H1 >= 256 && H1 <= 1024 && H2 % 128 == 0 && H2 >= 128 && H2 <= 512 && A >= 1 &&
+         A <= 32 && wide_lds_bytes(D, H1, H2) <= 160 * 1024;
+}
+
+}  // namespace
+
+extern "C" long long dm_ppo_wide_packed_elems(int D, int H1, int H2) { return wide_packed_elems(D, H1, H2); }
+extern "C" int dm_ppo_wide_dp(int D) { return wide_dp(D); }
+extern "C" int dm_ppo_wide_supported(int B, int D, int H1, int H2, int A) { return wide_supported(B, D, H1, H2, A) ? 1 : 0; }
+
+extern "C" int dm_ppo_wide_grad(const DmPpoWideStep *s, void *stream) {
+  if (!s || !wide_supported(s->B, s->D, s->H1, s->H2, s->A)) return -22;
+  if (!s->obs || !s->act || !s->adv || !s->ret || !s->old_logp || !s->log_std || !s->g_log_std || !s->xbT || !s->part || !s->stats8 || !s->out8) return -22;
+  for (int t = 0; t < 2; t++) {
+    if (!s->wpk[t] || !s->h1T[t] || !s->dz1T[t] || !s->h2T[t] || !s->dz2T[t] || !s->dz3T[t]) return -22;
+    for (int l = 0; l < 3; l++) if (!s->W[t][l] || !s->b[t][l] || !s->gW[t][l] || !s->gb[t][l]) return -22;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  static int lds_set_for = -1;
+  const int lds = wide_lds_bytes(s->D, s->H1, s->H2);
+  int dev = 0;
+  hipGetDevice(&dev);
+  if (lds_set_for != dev) {   // (per device: ADVICE r1)
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(wide_fwdbwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -5;
+    lds_set_for = dev;
+  }
+  const int Dp = wide_dp(s->D);
+  WidePackArgs p;
+  memset(&p, 0, sizeof p);
+  for (int t = 0; t < 2; t++) { for (int l = 0; l < 3; l++) p.W[t][l] = s->W[t][l]; p.pk[t] = (unsigned short *)s->wpk[t]; }
+  p.D = s->D; p.Dp = Dp; p.H1 = s->H1; p.H2 = s->H2; p.A[0] = s->A; p.A[1] = 1;
+  p.total = wide_packed_elems(s->D, s->H1, s->H2);
+  p.pack_blocks = 256;
+  p.adv = s->adv; p.B = s->B; p.normalize = s->normalize_advantage; p.stats = s->stats8; p.out8 = s->out8;
+  p.zero_ptr = s->zero_ptr; p.zero_floats = s->zero_ptr ? s->zero_floats : 0; p.adam_state2 = s->adam_state2;
+  const int zero_blocks = (int)((p.zero_floats + 1023) / 1024);
+  hipLaunchKernelGGL(wide_pack_kernel, dim3(2 * p.pack_blocks + 1 + zero_blocks), dim3(256), 0, st, p);
+  WideArgs a;
+  memset(&a, 0, sizeof a);
+  a.B = s->B; a.D = s->D; a.Dp = Dp; a.H1 = s->H1; a.H2 = s->H2; a.A = s->A;
+  a.obs = s->obs; a.act = s->act; a.adv = s->adv; a.ret = s->ret; a.old_logp = s->old_logp; a.log_std = s->log_std; a.stats = s->stats8;
+  for (int t = 0; t < 2; t++) {
+    a.pk[t] = (const unsigned short *)s->wpk[t];
+    a.b1[t] = s->b[t][0]; a.b2[t] = s->b[t][1]; a.b3[t] = s->b[t][2];
+    a.gb1[t] = s->gb[t][0]; a.gb2[t] = s->gb[t][1]; a.gb3[t] = s->gb[t][2];
+    a.h1T[t] = (unsigned short *)s->h1T[t]; a.dz1T[t] = (unsigned short *)s->dz1T[t]; a.h2T[t] = (unsigned short *)s->h2T[t];
+    a.dz2T[t] = (unsigned short *)s->dz2T[t]; a.dz3T[t] = (unsigned short *)s->dz3T[t];
+  }
+  a.xbT = (unsigned short *)s->xbT; a.part = s->part; a.clip = s->clip_range; a.vf_coef = s->vf_coef;
+  hipLaunchKernelGGL(wide_fwdbwd_kernel, dim3(s->B / WIDE_R, 2), dim3(WIDE_THREADS), lds, st, a);
+  // weight gradients: per trunk dW2 (the big one), dW1, dW3; split-K chosen so that every job brings ~64-128 workgroups
+  WideWgradArgs g;
+  memset(&g, 0, sizeof g);
+  int first = 0, nj = 0;
+  auto add = [&](const void *AT, const void *XT, float *dW, int O, int I, int ldw, int ro, int want) {
+    WideWgradJob &J = g.j[nj++];
+    J.AT = (const unsigned short *)AT; J.XT = (const unsigned short *)XT; J.dW = dW; J.O = O; J.I = I; J.ldw = ldw; J.ro = ro;
+    J.otiles = (O + 32 * ro - 1) / (32 * ro);
+    J.itiles = (I + 32 * (8 / ro) - 1) / (32 * (8 / ro));
+    int sk = 1;
+    while (J.otiles * J.itiles * sk * 2 <= want && (s->B / (sk * 2)) % 64 == 0) sk *= 2;
+    J.splitk = sk; J.first = first;
+    first += J.otiles * J.itiles * sk;
+  };
+  for (int t = 0; t < 2; t++) {
+    add(s->dz2T[t], s->h1T[t], s->gW[t][1], s->H2, s->H1, s->H1, 2, 256);
+    add(s->dz1T[t], s->xbT, s->gW[t][0], s->H1, s->D, s->D, 2, 128);
+    add(s->dz3T[t], s->h2T[t], s->gW[t][2], t ? 1 : s->A, s->H2, s->H2, 1, 32);
+  }
+  g.njobs = nj; g.nblocks = first; g.B = s->B;
+  g.part = s->part; g.nblk = s->B / WIDE_R; g.A = s->A; g.log_std = s->log_std; g.vf_coef = s->vf_coef; g.ent_coef = s->ent_coef; g.stats = s->stats8;
+  g.g_log_std = s->g_log_std; g.out8 = s->out8; g.loss_acc = s->loss_acc;
+  hipLaunchKernelGGL(wide_wgrad_kernel, dim3(first + 1), dim3(64), 0, st, g);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}

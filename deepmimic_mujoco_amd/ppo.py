@@ -351,6 +351,64 @@ class FusedMlpGrad:
         return self.out8[0]
 
 
+class WideMlpGrad:
+    """One minibatch gradient of the WIDE net ([1024,512]-class, the net BASELINE configs 3-5 name) with bf16 matrix-pipe products
+    (`dm_ppo_wide_grad`, csrc/dm_ppo_wide.hip): weights -> bf16, the fused forward / loss / input-gradient chain of both trunks, the
+    six weight gradients — three launches.  fp32 master weights, fp32 loss, gradients and Adam.  Leaves every gradient in
+    ``opt.flat_g`` (cleared by the first launch, which also performs Adam's begin) and adds the loss to ``loss_acc``."""
+
+    def __init__(self, policy, opt, B, loss_acc):
+        import ctypes as C
+        from . import _lib
+        self.lib, self.C = _lib.load_library(), C
+        lin = lambda seq: [m for m in seq if isinstance(m, nn.Linear)]
+        pi, vf = lin(policy.pi) + [policy.action_net], lin(policy.vf) + [policy.value_net]
+        dev = policy.log_std.device
+        D, H1, H2, A = pi[0].in_features, pi[0].out_features, pi[1].out_features, pi[2].out_features
+        Dp = int(self.lib.dm_ppo_wide_dp(D))
+        bf = lambda *shape: torch.zeros(*shape, device=dev, dtype=torch.bfloat16)
+        npk = int(self.lib.dm_ppo_wide_packed_elems(D, H1, H2))
+        self.buf = dict(wpk=[bf(npk), bf(npk)], xbT=bf(Dp, B), h1T=[bf(H1, B), bf(H1, B)], dz1T=[bf(H1, B), bf(H1, B)], h2T=[bf(H2, B), bf(H2, B)],
+                        dz2T=[bf(H2, B), bf(H2, B)], dz3T=[bf(32, B), bf(32, B)], part=torch.zeros(2 * (B // 32) * 40, device=dev),
+                        stats8=torch.zeros(8, device=dev), out8=torch.zeros(8, device=dev))
+        grad = {id(p): g for p, g in zip(opt.params, opt.slices)}
+        st = _lib.DmPpoWideStep()
+        st.B, st.D, st.H1, st.H2, st.A = B, D, H1, H2, A
+        for t, layers in enumerate((pi, vf)):
+            for l, m in enumerate(layers):
+                st.W[t][l], st.b[t][l] = m.weight.data_ptr(), m.bias.data_ptr()
+                st.gW[t][l], st.gb[t][l] = grad[id(m.weight)].data_ptr(), grad[id(m.bias)].data_ptr()
+            for k in ("wpk", "h1T", "dz1T", "h2T", "dz2T", "dz3T"):
+                getattr(st, k)[t] = self.buf[k][t].data_ptr()
+        st.xbT, st.part, st.stats8, st.out8 = (self.buf[k].data_ptr() for k in ("xbT", "part", "stats8", "out8"))
+        st.log_std, st.g_log_std = policy.log_std.data_ptr(), grad[id(policy.log_std)].data_ptr()
+        st.zero_ptr, st.zero_floats = opt.flat_g.data_ptr(), opt.n
+        st.adam_state2, st.loss_acc = opt.state2.data_ptr(), loss_acc.data_ptr()
+        self.st, self.B, self.dev = st, B, dev
+
+    @staticmethod
+    def supported(policy, B):
+        if not isinstance(policy, MlpPolicy) or policy.log_std.device.type != "cuda":
+            return False
+        lin = [m for m in policy.pi if isinstance(m, nn.Linear)]
+        if len(lin) != 2 or len([m for m in policy.vf if isinstance(m, nn.Linear)]) != 2:
+            return False
+        from . import _lib
+        return bool(_lib.load_library().dm_ppo_wide_supported(int(B), lin[0].in_features, lin[0].out_features, lin[1].out_features,
+                                                              policy.action_net.out_features))
+
+    def __call__(self, obs, act, adv, ret, old_logp, clip_range, vf_coef, ent_coef, normalize):
+        st = self.st
+        for t in (obs, act, adv, ret, old_logp):
+            assert t.is_contiguous() and t.dtype == torch.float32 and t.shape[0] == self.B
+        st.obs, st.act, st.adv, st.ret, st.old_logp = (t.data_ptr() for t in (obs, act, adv, ret, old_logp))
+        st.clip_range, st.vf_coef, st.ent_coef, st.normalize_advantage = clip_range, vf_coef, ent_coef, int(bool(normalize))
+        rc = self.lib.dm_ppo_wide_grad(self.C.byref(st), self.C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("dm_ppo_wide_grad failed (%d)" % rc)
+        return self.buf["out8"][0]
+
+
 class ExtractedPolicy:
     """The reference's exported walk policy: a = tanh(tanh(o W0 + B0) W2 + B2) WA + BA
     (src/extracted_policy.py:471-478; used with obs[:66] and clip +-0.5, src/play_extracted.py:36-38)."""
@@ -580,7 +638,7 @@ class PPO:
                  gamma=0.99, gae_lambda=0.95, clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5,
                  normalize_advantage=True, seed=0, device=None, buffer_dtype=torch.float32, policy=None,
                  use_hip_graph=None, fused_loss=True, flat_adam=True, two_stream=True, rollout_graph=True, fused_rollout=True,
-                 fused_policy=True, fused_mlp=True, epoch_graph=True, dist_graph=True, mlp_dtype=torch.float32):
+                 fused_policy=True, fused_mlp=True, epoch_graph=True, dist_graph=True, mlp_dtype=torch.float32, fused_wide=True):
         # rollout_graph only takes effect for an env built with sub_batches > 1
         self.env = env
         self.device = device if device is not None else getattr(env, "device", torch.device("cpu"))
@@ -619,11 +677,14 @@ class PPO:
         # mixed-precision learner (library-GEMM path only): bf16 MFMA GEMMs and activations against bf16 shadows of the fp32
         # master weights, fp32 loss / gradients-arena / Adam.  fp32 (the reference's dtype) is the default.
         self.mlp_dtype = mlp_dtype
+        self._wide_ok = False
         if mlp_dtype == torch.bfloat16:
             if not self.flat_adam:
                 raise ValueError("mlp_dtype=bfloat16 needs the flat Adam path (GPU)")
             self.fused_mlp = False                     # the fused [256,128]-class kernel is fp32
-            self.optimizer.enable_bf16_shadow()
+            self._wide_ok = bool(fused_wide) and self.fused_loss and WideMlpGrad.supported(self.policy, self.batch_size)
+            if not self._wide_ok:
+                self.optimizer.enable_bf16_shadow()    # library path: bf16 shadow weights for hipBLASLt
         self._graph = None
         self._mlp_grads = {}                                                        # FusedMlpGrad per minibatch size
         self._loss_acc = torch.zeros(2, device=self.device) if on_gpu else None     # device-side (sum of losses, count)
@@ -914,8 +975,8 @@ class PPO:
         n = flat["obs"].shape[0]
         loss_sum = torch.zeros((), device=self.device)
         nsteps = 0
-        on_dev = (self.flat_adam and self.fused_mlp and self.fused_loss and self.device.type == "cuda"
-                  and FusedMlpGrad.supported(self.policy, self.batch_size) and n % self.batch_size == 0)
+        on_dev = (self.flat_adam and self.fused_loss and self.device.type == "cuda" and n % self.batch_size == 0
+                  and ((self.fused_mlp and FusedMlpGrad.supported(self.policy, self.batch_size)) or self._wide_ok))
         self._on_dev = on_dev
         if on_dev:
             self._loss_acc.zero_()
@@ -1018,6 +1079,14 @@ class PPO:
             if mg is None:
                 mg = self._mlp_grads[obs.shape[0]] = FusedMlpGrad(self.policy, self.optimizer, obs.shape[0], loss_acc=self._loss_acc)
             loss = mg(obs.contiguous(), act.contiguous(), adv.contiguous(), ret.contiguous(), old_logp.contiguous(), self.clip_range,
+                      self.vf_coef, self.ent_coef, self.normalize_advantage and obs.shape[0] > 1)
+            return loss, False
+        if self._wide_ok and obs.is_cuda and obs.shape[0] == self.batch_size:
+            # wide nets with bf16 matrix-pipe products: the fused chain of dm_ppo_wide_grad + six library weight-gradient GEMMs
+            wg = self._mlp_grads.get(("wide", obs.shape[0]))
+            if wg is None:
+                wg = self._mlp_grads[("wide", obs.shape[0])] = WideMlpGrad(self.policy, self.optimizer, obs.shape[0], self._loss_acc)
+            loss = wg(obs.contiguous(), act.contiguous(), adv.contiguous(), ret.contiguous(), old_logp.contiguous(), self.clip_range,
                       self.vf_coef, self.ent_coef, self.normalize_advantage and obs.shape[0] > 1)
             return loss, False
         # library-GEMM learner (nets beyond the [256,128] class): every gradient lands in one flat buffer (one memset)

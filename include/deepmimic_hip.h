@@ -293,6 +293,38 @@ typedef struct DmPpoMlpStep {
 long long dm_ppo_mlp_workspace_floats(int B, int D, int H1, int H2, int A);
 int dm_ppo_mlp_grad(const DmPpoMlpStep *step, void *stream);
 
+/* One PPO minibatch gradient of the WIDE actor-critic MLP (net_arch up to [1024, 512], the net BASELINE configs 3-5 name) on the bf16
+ * matrix pipe: replaces optimizer.zero_grad(), evaluate_actions, the loss and loss.backward() of SB3's PPO.train [EXT]
+ * (src/sb3_ppo.py:254-271,307-312).  Three launches: weights -> bf16 operand layouts (+ advantage statistics and the optional folds);
+ * the fused forward / loss / input-gradient chain of both trunks (v_mfma_f32_32x32x16_bf16, fp32 accumulation, activations in LDS as
+ * bf16); the six weight gradients dW = dZ^T X (+ the loss scalars).  fp32 master weights, loss arithmetic and gradients; gradients
+ * are ACCUMULATED into the caller's fp32 buffers (zero on entry, or pass the arena as zero_ptr); out8 as dm_ppo_loss.
+ * trunk 0 = policy (pi, action_net), 1 = value (vf, value_net); W / b / gW / gb in torch layout [out][in].
+ * Supported: B % 64 == 0, D <= 112, H1 in {256, 512, 768, 1024}, H2 in {128, 256, 384, 512}, A <= 32 (dm_ppo_wide_supported). */
+typedef struct DmPpoWideStep {
+  int32_t B, D, H1, H2, A, normalize_advantage;
+  float clip_range, vf_coef, ent_coef;
+  int32_t reserved;
+  const float *obs, *act, *adv, *ret, *old_logp, *log_std;
+  const float *W[2][3], *b[2][3];
+  float *gW[2][3], *gb[2][3];
+  float *g_log_std;
+  void *wpk[2];                 /* bf16 scratch, dm_ppo_wide_packed_elems(D, H1, H2) elements per trunk */
+  void *xbT;                    /* bf16 scratch [dm_ppo_wide_dp(D)][B]: the observations, transposed */
+  void *h1T[2], *dz1T[2];       /* bf16 scratch [H1][B]: tanh output of layer 1, d loss / d (pre-activation of layer 1), transposed */
+  void *h2T[2], *dz2T[2];       /* bf16 scratch [H2][B] */
+  void *dz3T[2];                /* bf16 scratch [32][B] */
+  float *part;                  /* scratch, 2 * (B / 32) * 40 floats */
+  float *stats8, *out8;         /* 8 floats each */
+  float *zero_ptr;              /* optional folds, as DmPpoMlpStep */
+  long long zero_floats;
+  float *adam_state2, *loss_acc;
+} DmPpoWideStep;
+long long dm_ppo_wide_packed_elems(int D, int H1, int H2);
+int dm_ppo_wide_dp(int D);
+int dm_ppo_wide_supported(int B, int D, int H1, int H2, int A);
+int dm_ppo_wide_grad(const DmPpoWideStep *step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

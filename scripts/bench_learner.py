@@ -1,5 +1,6 @@
 """Optimizer step of the PPO learner alone (captured hipGraph, replayed): us per minibatch step.
-usage: python scripts/bench_learner.py [H1,H2] [steps] [--no-fused-mlp] [--no-epoch-graph] [--mb=4096] [--bf16]"""
+usage: python scripts/bench_learner.py [H1,H2] [steps] [--no-fused-mlp] [--no-epoch-graph] [--mb=4096] [--bf16] [--no-fused-wide]
+(--bf16: wide nets run the fused bf16 chain of dm_ppo_wide_grad; with --no-fused-wide the bf16 library-GEMM path)"""
 import sys, time
 import torch
 sys.path.insert(0, ".")
@@ -16,12 +17,12 @@ buf = dict(obs=torch.randn(T, N, 67, generator=g), act=torch.randn(T, N, 28, gen
 buf = {k: v.to(dev) for k, v in buf.items()}
 epochs = max(1, steps // T)
 ppo = PPO(None, net_arch=arch, n_epochs=epochs, batch_size=MB, device=dev, fused_mlp="--no-fused-mlp" not in sys.argv,
-          epoch_graph="--no-epoch-graph" not in sys.argv, mlp_dtype=torch.bfloat16 if "--bf16" in sys.argv else torch.float32)
+          epoch_graph="--no-epoch-graph" not in sys.argv, mlp_dtype=torch.bfloat16 if "--bf16" in sys.argv else torch.float32, fused_wide="--no-fused-wide" not in sys.argv)
 ppo.train(buf)                       # capture
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 ppo.train(buf)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print("arch %s: %.1f us per optimizer step (%d steps, PPO.train of %d epochs x %d minibatches), loss %.5f" % (
-    arch, dt / (epochs * T) * 1e6, epochs * T, epochs, T, ppo.stats["loss"]))
+print("arch %s%s: %.1f us per optimizer step (%d steps, PPO.train of %d epochs x %d minibatches), loss %.5f" % (
+    arch, " bf16 fused-wide" if getattr(ppo, "_wide_ok", False) else (" bf16 library" if "--bf16" in sys.argv else ""), dt / (epochs * T) * 1e6, epochs * T, epochs, T, ppo.stats["loss"]))

@@ -811,7 +811,7 @@ def test_bf16_learner_option_tracks_the_fp32_learner():
     for dt in (torch.float32, torch.bfloat16):
         torch.manual_seed(11)
         pol = MlpPolicy(net_arch=(1024, 512)).to(dev)
-        ppo = PPO(None, policy=pol, device=dev, batch_size=B, use_hip_graph=False, learning_rate=1e-3, mlp_dtype=dt)
+        ppo = PPO(None, policy=pol, device=dev, batch_size=B, use_hip_graph=False, learning_rate=1e-3, mlp_dtype=dt, fused_wide=False)
         with torch.no_grad():
             _, logp, _ = pol.evaluate_actions(obs, act)
         old_logp = (logp + 0.1 * torch.randn(B, device=dev, generator=torch.Generator(device=dev).manual_seed(3))).contiguous()
@@ -831,3 +831,54 @@ def test_bf16_learner_option_tracks_the_fp32_learner():
     assert cos > 0.995 and rel < 0.08
     assert abs(l16[0] - l32[0]) < 0.02 * max(1.0, abs(l32[0]))
     assert l16[-1] < l16[0] and abs(l16[-1] - l32[-1]) < 0.05 * max(1.0, abs(l32[-1]))
+
+
+@pytest.mark.parametrize("arch,D,A,B", [((1024, 512), 67, 28, 4096), ((1024, 512), 98, 23, 1024), ((512, 256), 72, 28, 512), ((256, 128), 85, 23, 256)])
+def test_wide_fused_learner_gradient_matches_fp32_autograd(arch, D, A, B):
+    """dm_ppo_wide_grad (csrc/dm_ppo_wide.hip): the fused bf16 matrix-pipe forward / loss / backward chain of the [1024,512]-class
+    net (BASELINE configs 3-5) + the split-K bf16 weight-gradient kernel, against the fp32 loss of SB3's PPO.train written with plain
+    PyTorch ops and autograd.  bf16 operands (8-bit mantissa), fp32 accumulation: per parameter tensor the gradient points where
+    the fp32 gradient does (cosine > 0.999) with a relative L2 difference < 3 %, the loss agrees to 1e-3 relative; five optimizer
+    steps through the product path reduce the loss like the fp32 learner's."""
+    import torch
+    from deepmimic_mujoco_amd.ppo import PPO, MlpPolicy, WideMlpGrad
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    obs = torch.randn(B, D, device=dev, generator=g)
+    act = torch.randn(B, A, device=dev, generator=g) * 0.5
+    adv = torch.randn(B, device=dev, generator=g)
+    ret = torch.randn(B, device=dev, generator=g)
+    torch.manual_seed(13)
+    pol = MlpPolicy(obs_dim=D, act_dim=A, net_arch=arch).to(dev)
+    assert WideMlpGrad.supported(pol, B)
+    with torch.no_grad():
+        pol.log_std.add_(0.1 * torch.randn(A, device=dev, generator=g))
+        _, logp, _ = pol.evaluate_actions(obs, act)
+    old_logp = (logp + 0.1 * torch.randn(B, device=dev, generator=g)).contiguous()
+    ppo = PPO(None, policy=pol, device=dev, batch_size=B, use_hip_graph=False, learning_rate=3e-4, mlp_dtype=torch.bfloat16, ent_coef=0.01)
+    assert ppo._wide_ok
+    loss_w, begin = ppo._minibatch_grad(obs, act, adv, ret, old_logp)
+    torch.cuda.synchronize()
+    assert begin is False
+    gw = {id(p): s_.clone() for p, s_ in zip(ppo.optimizer.params, ppo.optimizer.slices)}
+    # the fp32 reference: the loss of SB3's PPO.train in PyTorch ops; the layers' fp32 backward files its gradients in the same arena
+    ppo.optimizer.zero_grad()
+    loss_t = ppo._loss_torch(obs, act, adv, ret, old_logp)
+    loss_t.backward()
+    ppo.optimizer.gather_grads()
+    torch.cuda.synchronize()
+    loss_t = loss_t.detach()
+    assert abs(float(loss_w) - float(loss_t)) < 2e-3 * max(1.0, abs(float(loss_t))), (float(loss_w), float(loss_t))
+    ref = {id(p): s_.clone() for p, s_ in zip(ppo.optimizer.params, ppo.optimizer.slices)}
+    worst_cos, worst_rel = 1.0, 0.0
+    for name, p_ in pol.named_parameters():
+        a, b = gw[id(p_)].reshape(-1), ref[id(p_)].reshape(-1)
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+        rel = float((a - b).norm() / (b.norm() + 1e-30))
+        worst_cos, worst_rel = min(worst_cos, cos), max(worst_rel, rel)
+        assert cos > 0.999 and rel < 0.03, (name, cos, rel)
+    print("wide fused learner %s D %d A %d B %d: loss %.6f / %.6f, worst cosine %.5f, worst relative L2 %.4f" % (arch, D, A, B, float(loss_w), float(loss_t), worst_cos, worst_rel))
+    l0 = float(ppo._minibatch_step(obs, act, adv, ret, old_logp))
+    for _ in range(4):
+        l1 = float(ppo._minibatch_step(obs, act, adv, ret, old_logp))
+    assert l1 < l0
