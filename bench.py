@@ -41,10 +41,26 @@ def _newest_pmc():
 
 
 def _newest_g1_pmc():
+    """Counters of the split G1 pipeline from the newest committed PMC profile (scripts/pmc_g1_split.sh, 4 096 envs): one step
+    is six launches of g1_env_kernel and five of g1_pair_kernel; the files hold means per launch.  Returns
+    ({"g1_env_kernel": {...}, "g1_pair_kernel": {...}}, [file names]) or (None, [])."""
+    import csv
     import glob
     import re
-    files = glob.glob(os.path.join(ROOT, "profiles", "r*_g1*_pmc_g1_step_kernel.csv"))
-    return max(files, key=lambda f: tuple(int(x) for x in re.findall(r"\d+", os.path.basename(f)))) if files else None
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*_g1*_pmc_g1_env_kernel.csv"))
+    if not files:
+        return None, []
+    envf = max(files, key=lambda f: tuple(int(x) for x in re.findall(r"\d+", os.path.basename(f))))
+    pairf = envf.replace("g1_env_kernel", "g1_pair_kernel")
+    out = {}
+    for k, f in (("g1_env_kernel", envf), ("g1_pair_kernel", pairf)):
+        rows = list(csv.DictReader(open(f)))
+        col = [c for c in rows[0] if c != "counter"][0]
+        out[k] = {r["counter"]: float(r[col]) for r in rows}
+    return out, [os.path.basename(envf), os.path.basename(pairf)]
+
+
+G1_LAUNCHES = {"g1_env_kernel": 6, "g1_pair_kernel": 5}     # per step of the split pipeline (dm_g1.hip: four RK stages + reset evaluation)
 
 
 def measured_traffic_bytes():
@@ -124,37 +140,40 @@ def g1_record(local_rank, n=4096, steps=20, warmup=5, with_cpu=False):
     G1_ALGO_BYTES = 4 * (44 + 43 + 43 + 23 + 4 + 44 + 43 + 43 + 85 + 1 + 5 + 2 + 2)     # state row in / out, action, outputs: 1 528 B
     rec = {"robot": "unitree_g1 (43 DoF, 32 convex meshes, friction loss)", "envs_per_gpu": n, "steps": steps,
            "window": "steps %d..%d after reset (throughput), %d..%d (kernel time)" % (warmup, warmup + steps - 1, warmup + steps, warmup + steps + 9),
-           "env_steps_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3, "kernel": "g1_step_kernel",
+           "env_steps_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3,
+           "kernel": "6 x g1_env_kernel + 5 x g1_pair_kernel (split pipeline)" if eng.split else "g1_step_kernel",
            "kernel_ms": kms, "done_fraction_last_step": float(out["done"].float().mean()),
            "reference_published_env_steps_per_s": 1390, "note": "auxiliary: SURVEY 8f-2 (next row), not the headline metric"}
-    pmc_path, traffic = _newest_g1_pmc(), None
+    pmc, pmc_src = _newest_g1_pmc()
+    traffic = None
     try:
-        import csv
-        v = {r["counter"]: float(r["mean_per_dispatch_over_last_10_dispatches"]) for r in csv.DictReader(open(pmc_path))}
-        traffic = (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
+        traffic = sum(G1_LAUNCHES[k] * (pmc[k]["FETCH_SIZE"] + pmc[k]["WRITE_SIZE"]) * 1024.0 for k in G1_LAUNCHES)
     except Exception:
         pass
     ach = n * G1_ALGO_BYTES / (kms * 1e-3) / 1e9
     rec["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                       "traffic": traffic, "kernel": "g1_step_kernel", "kernel_ms": kms, "kernel_launches_timed": len(kms_list),
+                       "traffic": traffic, "kernel": rec["kernel"], "kernel_ms": kms, "kernel_launches_timed": len(kms_list),
                        "algorithmic_bytes_per_env_step": G1_ALGO_BYTES,
-                       "note": "nominal bound like the humanoid's: the kernel is latency / issue bound (valu below); traffic from "
-                               "profiles/%s" % os.path.basename(pmc_path or "-")}
-    try:   # what bounds g1_step_kernel: instruction issue / latency, from the committed PMC file of the same command
-        import csv
-        path = _newest_g1_pmc()
-        v = {r["counter"]: float(r["mean_per_dispatch_over_last_10_dispatches"]) for r in csv.DictReader(open(path))}
-        w = v["SQ_WAVES"]
-        wave_cycles = 4.0 * v["SQ_WAVE_CYCLES"] / w
-        launch_cycles = kms * 1e-3 * 2.4e9
-        rec["valu"] = {"valu_per_env_step": v["SQ_INSTS_VALU"] / w, "salu_per_env_step": v["SQ_INSTS_SALU"] / w,
-                       "lds_per_env_step": v["SQ_INSTS_LDS"] / w, "vmem_per_env_step": v["SQ_INSTS_VMEM"] / w,
-                       "wave_cycles_per_env_step": wave_cycles, "cycles_per_instruction": wave_cycles / ((v["SQ_INSTS_VALU"] + v["SQ_INSTS_SALU"] + v["SQ_INSTS_LDS"] + v["SQ_INSTS_VMEM"]) / w),
-                       "issue_frac_launch": n * (v["SQ_INSTS_VALU"] / w) * 2.0 / (1024 * launch_cycles),
-                       "wait_frac": v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], "resident_waves_per_simd": 2,
-                       "hbm_bytes_per_env_step": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 / n,
-                       "algorithmic_bytes_per_env_step": G1_ALGO_BYTES,
-                       "counters_from": "profiles/" + os.path.basename(path)}
+                       "note": "nominal bound like the humanoid's: both kernels are latency / issue bound (valu below); kernel_ms = HIP events "
+                               "around the eleven launches of one step; traffic = 6 x g1_env_kernel + 5 x g1_pair_kernel launches, from "
+                               "profiles/%s" % " + ".join(pmc_src or ["-"])}
+    try:   # what bounds the two kernels: instruction issue / latency, from the committed PMC files of scripts/bench_g1.py at 4 096 envs
+        view = {}
+        for k, v in pmc.items():
+            w = v["SQ_WAVES"]
+            insts = v["SQ_INSTS_VALU"] + v["SQ_INSTS_SALU"] + v["SQ_INSTS_LDS"] + v["SQ_INSTS_VMEM"]
+            view[k] = {"launches_per_step": G1_LAUNCHES[k], "waves_per_launch": w, "valu_per_launch": v["SQ_INSTS_VALU"],
+                       "salu_per_launch": v["SQ_INSTS_SALU"], "lds_per_launch": v["SQ_INSTS_LDS"], "vmem_per_launch": v["SQ_INSTS_VMEM"],
+                       "wave_cycles_per_wave": 4.0 * v["SQ_WAVE_CYCLES"] / w, "cycles_per_instruction": 4.0 * v["SQ_WAVE_CYCLES"] / insts,
+                       "wait_frac": v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"],
+                       "hbm_bytes_per_launch": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0}
+        tot_valu = sum(G1_LAUNCHES[k] * pmc[k]["SQ_INSTS_VALU"] for k in G1_LAUNCHES)
+        view["valu_per_env_step"] = tot_valu / n
+        view["issue_frac_step"] = tot_valu * 2.0 / (1024 * kms * 1e-3 * 2.4e9)
+        view["hbm_bytes_per_env_step"] = None if traffic is None else traffic / n
+        view["algorithmic_bytes_per_env_step"] = G1_ALGO_BYTES
+        view["counters_from"] = ["profiles/" + x for x in pmc_src]
+        rec["valu"] = view
     except Exception as e:  # noqa: BLE001
         rec["valu"] = {"error": repr(e)[:200]}
     eng.close()
@@ -229,13 +248,13 @@ def ppo_loop_record(args, dev, local_rank, rank, world, launched, barrier):
     import torch
     import torch.distributed as dist
     from deepmimic_mujoco_amd.deepmimic_env import HipDeepMimicVecEnv
-    from deepmimic_mujoco_amd.ppo import PPO
+    from deepmimic_mujoco_amd.ppo import PPO, FusedMlpGrad
     motion = "spinkick" if world > 1 else "walk"
     rec = {"motion": motion, "envs_per_gpu": args.envs, "horizon": 32, "epochs": 20, "minibatch": 4096, "n_gpus": world,
            "timed_iterations": args.ppo_iters, "window": "PPO iterations 1..%d (iteration 0 untimed: graph capture), 32 env steps each, "
                                                          "fresh envs, untrained policy" % args.ppo_iters}
     for arch, mdt in (((256, 128), torch.float32), ((1024, 512), torch.float32), ((1024, 512), torch.bfloat16)):
-        key = "%d,%d" % arch + ("" if mdt == torch.float32 else " bf16-gemm")     # bf16-gemm: auxiliary mixed-precision learner option
+        key = "%d,%d" % arch + ("" if mdt == torch.float32 else " bf16-gemm")     # bf16-gemm: mixed-precision learner (dm_ppo_wide_grad)
         env = ppo = err = None
         try:
             env = HipDeepMimicVecEnv(args.envs, motion=motion, device=local_rank, seed=1234 + 7919 * rank)
@@ -290,12 +309,17 @@ def ppo_loop_record(args, dev, local_rank, rank, world, launched, barrier):
             rec[key] = {"loop_env_steps_per_s": args.ppo_iters * steps_per_iter / dt,
                         "rollout_env_steps_per_s": args.ppo_iters * steps_per_iter / t_roll,
                         "optimizer_step_us": opt_us, "optimizer_steps_per_iteration": nopt,
-                        "mfma_frac": flops / (opt_us * 1e-6) / 157.3e12, "flops_per_optimizer_step": flops,
+                        "mfma_frac": flops / (opt_us * 1e-6) / (157.3e12 if mdt == torch.float32 else 2.5e15),
+                        "mfma_peak_tflops": 157.3 if mdt == torch.float32 else 2500.0, "flops_per_optimizer_step": flops,
                         "collective_us": coll_us, "collectives_per_iteration": nopt if world > 1 else 0,
                         "grad_floats": int(sum(p.numel() for p in ppo.policy.parameters())),
                         "mlp_dtype": "f32" if mdt == torch.float32 else "bf16 GEMMs / activations, f32 master weights, loss and Adam",
                         "learner_path": ("dist two-graph" if getattr(ppo, "_dg", None) is not None else
                                          "epoch graph" if getattr(ppo, "_eg", None) is not None else "eager"),
+                        "gradient_kernels": ("dm_ppo_wide_grad (fused bf16 chain + split-K weight gradients)"
+                                             if getattr(ppo, "_wide_ok", False) else
+                                             "dm_ppo_mlp_grad (fused fp32 chain)" if (ppo.fused_mlp and FusedMlpGrad.supported(ppo.policy, ppo.batch_size)) else
+                                             "library GEMMs"),
                         "mean_reward": ppo.stats.get("mean_reward")}
             env.close()
         except Exception as e:  # noqa: BLE001  (never lose the headline line to the auxiliary record)

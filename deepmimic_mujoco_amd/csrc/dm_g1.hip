@@ -87,7 +87,7 @@ struct Lds {   // per-env working set (one wave): 19.2 KB, eight waves per CU
   float x0q[NQ], x0v[44], accq[44], accv[44];
   int32_t info[8];   // ncon, nefc, nlimit, solver_iter, overflow, nsurv
 #ifdef G1_PROFILE
-  long long prof_t; unsigned prof[16];
+  long long prof_t; unsigned prof[18];   // 16 used; 80 bytes keep the head of the working set a multiple of 16
 #endif
   union {
     struct {   // smooth-dynamics scratch: dead once qacc_smooth is known
@@ -3048,6 +3048,9 @@ extern "C" int dmg1_create(const void *model, size_t model_bytes, const DmG1Conf
   ok = ok && hipMalloc(&e->dOrder, N * sizeof(int32_t)) == hipSuccess && hipMalloc(&e->dCost, N * sizeof(int32_t)) == hipSuccess;
   if (ok) hipMemset(e->dCost, 0, N * sizeof(int32_t));
   e->split = cfg->pipeline == 2 || (cfg->pipeline == 0 && e->N >= 512);
+#ifdef G1_PROFILE
+  if (const char *pl = getenv("DMG1_PIPELINE")) e->split = atoi(pl) == 2;
+#endif
   if (e->split) {   // ~135 KB per env: 0.55 GB at 4 096 envs
     const size_t NP = N * g1::PAIRCAP;
     ok = ok && hipMalloc(&e->dWs, N * g1::WS_BYTES) == hipSuccess;

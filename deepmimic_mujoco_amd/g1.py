@@ -199,6 +199,7 @@ class G1HipEngine:
         cfg.num_envs, cfg.seed, cfg.auto_reset, cfg.device, cfg.max_ep_length = self.N, seed, int(auto_reset), device, max_ep_length
         cfg.task = int(task)
         cfg.pipeline = int(pipeline)        # 0 auto (split pipeline from 512 envs up), 1 monolithic, 2 split
+        self.split = int(pipeline) == 2 or (int(pipeline) == 0 and self.N >= 512)      # the rule of dmg1_create (csrc/dm_g1.hip)
         self.task = int(task)
         self.obs_dim = NOBS_COMBINED if task else NOBS
         self.terms_dim = 8 if task else 5
@@ -405,9 +406,23 @@ class HipG1VecEnv(_SB3VecEnv):
         return self.out["obs"]
 
     def step_tensor(self, actions):
+        """One step of the whole batch.  With sub_batches > 1 every engine's launches go to its own HIP stream, forked from and
+        joined back into the current one: while one engine's g1_env_kernel drains its heaviest envs, the CUs it has left idle
+        run the other engines' kernels (the envs of a batch are independent; results do not depend on the overlap)."""
+        t = self._torch
         actions = actions.contiguous()
-        for e, o, sl in zip(self.engines, self.sub_out, self.sub_slices):
-            e.step(actions[sl], o)
+        if self.sub_batches == 1:
+            self.engine.step(actions, self.out)
+            return self.out
+        cur = t.cuda.current_stream(self.device)
+        if getattr(self, "_streams", None) is None:
+            self._streams = [t.cuda.Stream(device=self.device) for _ in self.engines]
+        fork = cur.record_event()
+        for e, o, sl, s in zip(self.engines, self.sub_out, self.sub_slices, self._streams):
+            s.wait_event(fork)
+            with t.cuda.stream(s):
+                e.step(actions[sl], o)
+            cur.wait_event(s.record_event())
         return self.out
 
     def reset(self):
