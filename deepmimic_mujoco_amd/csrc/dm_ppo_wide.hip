@@ -9,14 +9,19 @@
 //   2. wide_fwdbwd_kernel  a workgroup of eight waves carries 32 minibatch rows of one trunk through layer 1, layer 2, the head, the
 //                          loss (the arithmetic of ppo_loss_kernel), and back: d head, d layer 2 (x tanh'), d layer 1 (x tanh');
 //                          activations live in LDS as bf16 (64 + 32 + 32 KB), every product is v_mfma_f32_32x32x16_bf16 with fp32
-//                          accumulation, weights stream from L2 in operand order (a lane's 8 k-values are 16 contiguous bytes of a
-//                          weight row); outputs: the bf16 activations / pre-activation gradients the weight gradients need, the
-//                          bias gradients (column sums, fp32 atomics) and per-workgroup loss partials                         (1 launch)
+//                          accumulation, weights stream from L2 in FRAGMENT order (below): one operand load of a wave is 1 KB of
+//                          consecutive bytes; outputs: the bf16 activations / pre-activation gradients the weight gradients need,
+//                          the bias gradients (column sums, fp32 atomics) and per-workgroup loss partials                     (1 launch)
 //   3. wide_wgrad_kernel   dW = dZ^T X of all six layers: the chain leaves its activations and pre-activation gradients TRANSPOSED
-//                          ([features][batch], written straight from the accumulator registers: four consecutive batch rows of a
-//                          column are 8 bytes), so both operands of dW are 16-byte row reads; a wave owns a 32 x 128 block of dW
-//                          (four accumulators share every A fragment), split-K over workgroups, fp32 atomics into the gradient
-//                          arena; its last block also sums the loss partials                                                  (1 launch)
+//                          (features x batch) in the same fragment order, written straight from the accumulator registers (four
+//                          consecutive batch rows of a column are 8 bytes of a fragment); a wave owns eight 32 x 32 tiles of dW,
+//                          split-K over workgroups, fp32 atomics into the gradient arena; its last block also sums the loss
+//                          partials                                                                                           (1 launch)
+// Fragment order of a matrix M[N][K] (N % 32 == 0, K % 16 == 0) that feeds v_mfma_f32_32x32x16_bf16 as the operand with row / column
+// index n and reduction index k: element (n, k) lives at ((((n >> 5) * (K >> 4) + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)) * 8
+// + (k & 7)) — tile of 32 rows, k-step of 16, then the 64 lanes' 16-byte fragments in lane order.  A wave's load of one fragment is
+// base + lane * 16 bytes: eight full 128-byte lines.  (Row-major operands made every load touch 32 lines for 32 bytes each and lean
+// on the 32 KB vector L1 to hold 512 half-used lines across k-steps: 92 us for the chain, 58 us for the weight gradients.)
 // fp32 master weights, fp32 loss arithmetic, fp32 gradients and Adam; bf16 operands of the products only (north_star: "MFMA used
 // only for the policy-MLP GEMMs").  Included by dm_abi.hip after dm_ppo_mlp.hip.
 #include <hip/hip_runtime.h>
@@ -37,12 +42,20 @@ __device__ __forceinline__ unsigned short wide_f2bf(float x) {  // round to near
 __device__ __forceinline__ float wide_bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 __device__ __forceinline__ float wide_tanh(float x) { return 1.f - __fdividef(2.f, 1.f + __expf(2.f * x)); }
 __device__ __forceinline__ int wide_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+// fragment order (file header): element index of (n, k) in a matrix with K / 16 = nks k-steps
+__device__ __forceinline__ size_t wide_frag(int n, int k, int nks) {
+  return ((((size_t)(n >> 5) * nks + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)) << 3) + (k & 7);
+}
+// the fragment of tile t, k-step ks for this lane
+__device__ __forceinline__ wide_b8 wide_ldfrag(const unsigned short *M, int t, int ks, int nks, int lane) {
+  return *reinterpret_cast<const wide_b8 *>(M + ((((size_t)t * nks + ks) * 64 + lane) << 3));
+}
 
 constexpr int WIDE_R = 32, WIDE_NW = 8, WIDE_THREADS = 64 * WIDE_NW, WIDE_PART = 40;
 
 struct WidePackArgs {
   const float *W[2][3];
-  unsigned short *pk[2];          // per trunk: W1 [H1][Dp] | W2 [H2][H1] | W2T [H1][H2] | W3 [32][H2] | W3T [H2][32]
+  unsigned short *pk[2];          // per trunk: W1 [H1][Dp] | W2 [H2][H1] | W2T [H1][H2] | W3 [32][H2] | W3T [H2][32], each in fragment order
   int D, Dp, H1, H2, A[2];
   long long total;                // elements of one trunk's packed block
   int pack_blocks;                // blocks [0, 2 * pack_blocks) pack, block 2 * pack_blocks = statistics, the rest clear zero_ptr
@@ -65,14 +78,35 @@ __global__ void __launch_bounds__(256) wide_pack_kernel(WidePackArgs a) {
   }
   const int t = blk / a.pack_blocks;
   const long long n1 = (long long)a.H1 * a.Dp, n2 = (long long)a.H2 * a.H1, n3 = 32ll * a.H2;
-  for (long long i = (long long)(blk % a.pack_blocks) * 256 + threadIdx.x; i < a.total; i += (long long)a.pack_blocks * 256) {
-    float v;
-    if (i < n1) { const int o = (int)(i / a.Dp), k = (int)(i % a.Dp); v = k < a.D ? a.W[t][0][(size_t)o * a.D + k] : 0.f; }
-    else if (i < n1 + n2) v = a.W[t][1][i - n1];
-    else if (i < n1 + 2 * n2) { const long long j = i - n1 - n2; const int k = (int)(j / a.H2), o = (int)(j % a.H2); v = a.W[t][1][(size_t)o * a.H1 + k]; }
-    else if (i < n1 + 2 * n2 + n3) { const long long j = i - n1 - 2 * n2; const int o = (int)(j / a.H2), k = (int)(j % a.H2); v = o < a.A[t] ? a.W[t][2][(size_t)o * a.H2 + k] : 0.f; }
-    else { const long long j = i - n1 - 2 * n2 - n3; const int k = (int)(j / 32), o = (int)(j % 32); v = o < a.A[t] ? a.W[t][2][(size_t)o * a.H2 + k] : 0.f; }
-    a.pk[t][i] = wide_f2bf(v);
+  // one thread per 16-byte fragment (8 consecutive k of one row n), every block in fragment order
+  for (long long c = (long long)(blk % a.pack_blocks) * 256 + threadIdx.x; c < (a.total >> 3); c += (long long)a.pack_blocks * 256) {
+    long long i = c << 3;
+    int which, nks;
+    if (i < n1) { which = 0; nks = a.Dp >> 4; }
+    else if (i < n1 + n2) { which = 1; nks = a.H1 >> 4; i -= n1; }
+    else if (i < n1 + 2 * n2) { which = 2; nks = a.H2 >> 4; i -= n1 + n2; }
+    else if (i < n1 + 2 * n2 + n3) { which = 3; nks = a.H2 >> 4; i -= n1 + 2 * n2; }
+    else { which = 4; nks = 2; i -= n1 + 2 * n2 + n3; }
+    const long long ch = i >> 3;
+    const int l = (int)(ch & 63), ks = (int)((ch >> 6) % nks), tt = (int)((ch >> 6) / nks);
+    const int n = tt * 32 + (l & 31), k0 = ks * 16 + 8 * (l >> 5);
+    unsigned short o[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = k0 + j;
+      float v;
+      switch (which) {
+        case 0: v = k < a.D ? a.W[t][0][(size_t)n * a.D + k] : 0.f; break;                 // W1 [H1][Dp]
+        case 1: v = a.W[t][1][(size_t)n * a.H1 + k]; break;                                // W2 [H2][H1]
+        case 2: v = a.W[t][1][(size_t)k * a.H1 + n]; break;                                // W2^T [H1][H2]
+        case 3: v = n < a.A[t] ? a.W[t][2][(size_t)n * a.H2 + k] : 0.f; break;             // W3 [32][H2]
+        default: v = k < a.A[t] ? a.W[t][2][(size_t)k * a.H2 + n] : 0.f; break;            // W3^T [H2][32]
+      }
+      o[j] = wide_f2bf(v);
+    }
+    uint4 u;
+    u.x = o[0] | ((unsigned)o[1] << 16); u.y = o[2] | ((unsigned)o[3] << 16); u.z = o[4] | ((unsigned)o[5] << 16); u.w = o[6] | ((unsigned)o[7] << 16);
+    *reinterpret_cast<uint4 *>(a.pk[t] + (c << 3)) = u;
   }
 }
 
@@ -87,17 +121,24 @@ struct WideArgs {
   float clip, vf_coef;
 };
 
-// four consecutive batch rows of one column (accumulator registers 4 q .. 4 q + 3 of a lane) as 8 bytes of a [features][B] array
+// four consecutive batch rows row0 .. row0 + 3 (row0 % 4 == 0) of one feature column — accumulator registers 4 q .. 4 q + 3 of a
+// lane — as 8 bytes of the transposed (features x batch) array in fragment order
 __device__ __forceinline__ void wide_store_t4(unsigned short *T, size_t B, int col, int row0, float v0, float v1, float v2, float v3) {
   uint2 u;
   u.x = (unsigned)wide_f2bf(v0) | ((unsigned)wide_f2bf(v1) << 16);
   u.y = (unsigned)wide_f2bf(v2) | ((unsigned)wide_f2bf(v3) << 16);
-  *reinterpret_cast<uint2 *>(T + (size_t)col * B + row0) = u;
+  *reinterpret_cast<uint2 *>(T + wide_frag(col, row0, (int)(B >> 4))) = u;
 }
 
 __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
   extern __shared__ __align__(16) char wide_lds[];
-  const int trunk = blockIdx.y, b0 = blockIdx.x * WIDE_R;
+  // workgroups go round the eight XCDs in launch order: even XCDs take the policy trunk, odd ones the value trunk, so an XCD's L2
+  // streams ONE trunk's 2.3 MB of weights (both trunks: 4.6 MB against 4 MB of L2)
+  const int nt = a.B / WIDE_R, id = blockIdx.x;
+  int trunk, tile;
+  if ((nt & 3) == 0) { const int xcd = id & 7; trunk = xcd & 1; tile = (id >> 3) * 4 + (xcd >> 1); }
+  else { trunk = id / nt; tile = id % nt; }
+  const int b0 = tile * WIDE_R;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int Dp = a.Dp, H1 = a.H1, H2 = a.H2, At = trunk ? 1 : a.A;      // head width: actions (policy trunk) / 1 (value trunk)
   const size_t B = (size_t)a.B;
@@ -115,7 +156,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
     const int k = i >> 5, m = i & 31;                                  // (consecutive threads: consecutive rows of one column)
     const unsigned short v = wide_f2bf(k < a.D ? a.obs[(size_t)(b0 + m) * a.D + k] : 0.f);
     *reinterpret_cast<unsigned short *>(Xs + m * SX + 2 * k) = v;
-    if (trunk == 0) a.xbT[(size_t)k * B + b0 + m] = v;
+    if (trunk == 0) a.xbT[wide_frag(k, b0 + m, (int)(B >> 4))] = v;
   }
   __syncthreads();
 
@@ -124,10 +165,9 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
     wide_f16 acc;
 #pragma unroll
     for (int j = 0; j < 16; j++) acc[j] = 0.f;
-    const unsigned short *wrow = W1 + (size_t)(t * 32 + r) * Dp + 8 * h;
     for (int ks = 0; ks < (Dp >> 4); ks++) {
       const wide_b8 av = *reinterpret_cast<const wide_b8 *>(Xs + r * SX + (ks * 16 + 8 * h) * 2);
-      const wide_b8 bv = *reinterpret_cast<const wide_b8 *>(wrow + ks * 16);
+      const wide_b8 bv = wide_ldfrag(W1, t, ks, Dp >> 4, lane);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
     }
     const float bias = a.b1[trunk][t * 32 + r];
@@ -152,15 +192,16 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
 #pragma unroll
     for (int j = 0; j < 16; j++) { acc0[j] = 0.f; acc1[j] = 0.f; }
     const char *ap = H1s + r * S1 + 16 * h;
-    const unsigned short *wr0 = W2 + (size_t)(t0 * 32 + r) * H1 + 8 * h, *wr1 = wr0 + 32 * (size_t)H1;
+    // fragments of tile t0 / t0 + 1: k-step ks at wr + ks * 512 elements (1 KB per wave), consecutive k-steps consecutive in memory
+    const unsigned short *wr0 = W2 + ((size_t)t0 * (H1 >> 4) * 64 + lane) * 8, *wr1 = wr0 + (size_t)(H1 >> 4) * 512;
     constexpr int KB = 8;
     wide_b8 p0[KB], p1[KB], q0[KB], q1[KB];
     const int nblk = (H1 >> 4) / KB;                       // H1 % 256 == 0: an even number of blocks
 #pragma unroll
-    for (int i = 0; i < KB; i++) { p0[i] = *reinterpret_cast<const wide_b8 *>(wr0 + i * 16); p1[i] = *reinterpret_cast<const wide_b8 *>(wr1 + i * 16); }
+    for (int i = 0; i < KB; i++) { p0[i] = *reinterpret_cast<const wide_b8 *>(wr0 + i * 512); p1[i] = *reinterpret_cast<const wide_b8 *>(wr1 + i * 512); }
     for (int kb = 0; kb < nblk; kb += 2) {
 #pragma unroll
-      for (int i = 0; i < KB; i++) { q0[i] = *reinterpret_cast<const wide_b8 *>(wr0 + ((kb + 1) * KB + i) * 16); q1[i] = *reinterpret_cast<const wide_b8 *>(wr1 + ((kb + 1) * KB + i) * 16); }
+      for (int i = 0; i < KB; i++) { q0[i] = *reinterpret_cast<const wide_b8 *>(wr0 + ((kb + 1) * KB + i) * 512); q1[i] = *reinterpret_cast<const wide_b8 *>(wr1 + ((kb + 1) * KB + i) * 512); }
 #pragma unroll
       for (int i = 0; i < KB; i++) {
         const wide_b8 av = *reinterpret_cast<const wide_b8 *>(ap + (kb * KB + i) * 32);
@@ -169,7 +210,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
       }
       if (kb + 2 < nblk) {
 #pragma unroll
-        for (int i = 0; i < KB; i++) { p0[i] = *reinterpret_cast<const wide_b8 *>(wr0 + ((kb + 2) * KB + i) * 16); p1[i] = *reinterpret_cast<const wide_b8 *>(wr1 + ((kb + 2) * KB + i) * 16); }
+        for (int i = 0; i < KB; i++) { p0[i] = *reinterpret_cast<const wide_b8 *>(wr0 + ((kb + 2) * KB + i) * 512); p1[i] = *reinterpret_cast<const wide_b8 *>(wr1 + ((kb + 2) * KB + i) * 512); }
       }
 #pragma unroll
       for (int i = 0; i < KB; i++) {
@@ -204,7 +245,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
     for (int q = 0; q < kper; q++) {
       const int ks = wave * kper + q;
       const wide_b8 av = *reinterpret_cast<const wide_b8 *>(H2s + r * S2 + (ks * 16 + 8 * h) * 2);
-      const wide_b8 bv = *reinterpret_cast<const wide_b8 *>(W3 + (size_t)r * H2 + ks * 16 + 8 * h);
+      const wide_b8 bv = wide_ldfrag(W3, 0, ks, H2 >> 4, lane);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
     }
 #pragma unroll
@@ -263,7 +304,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
       }
       const unsigned short dzb = wide_f2bf(dz);
       *reinterpret_cast<unsigned short *>(dZ3s + m * S3 + 2 * j) = dzb;
-      a.dz3T[trunk][(size_t)j * B + b] = dzb;
+      a.dz3T[trunk][wide_frag(j, b, (int)(B >> 4))] = dzb;
     }
     accs[hw * 36 + j] = g_ls;
     if (j == 0) { accs[hw * 36 + 32] = pg; accs[hw * 36 + 33] = vl; accs[hw * 36 + 34] = kl; accs[hw * 36 + 35] = cf; }
@@ -273,7 +314,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; i++) t += accs[i * 36 + tid];
-    a.part[((size_t)trunk * gridDim.x + blockIdx.x) * WIDE_PART + tid] = t;
+    a.part[((size_t)trunk * nt + tile) * WIDE_PART + tid] = t;
   }
   // bias gradient of the head: column sums of dZ3 over the workgroup's rows
   if (tid < At) {
@@ -290,8 +331,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
       const wide_b8 av = *reinterpret_cast<const wide_b8 *>(dZ3s + r * S3 + (ks * 16 + 8 * h) * 2);
-      const wide_b8 b0v = *reinterpret_cast<const wide_b8 *>(W3T + (size_t)(t0 * 32 + r) * 32 + ks * 16 + 8 * h);
-      const wide_b8 b1v = *reinterpret_cast<const wide_b8 *>(W3T + (size_t)(t0 * 32 + 32 + r) * 32 + ks * 16 + 8 * h);
+      const wide_b8 b0v = wide_ldfrag(W3T, t0, ks, 2, lane), b1v = wide_ldfrag(W3T, t0 + 1, ks, 2, lane);
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b0v, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b1v, acc1, 0, 0, 0);
     }
@@ -327,19 +367,20 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
 #pragma unroll
       for (int j = 0; j < 16; j++) acc[q][j] = 0.f;
     const char *ap = dZ2s + r * S2 + 16 * h;
-    const unsigned short *wrow = W2T + (size_t)(t0 * 32 + r) * H2 + 8 * h;
+    const unsigned short *wrow = W2T + ((size_t)t0 * (H2 >> 4) * 64 + lane) * 8;     // tile t0 + q: + q * (H2 / 16) * 512 elements
+    const size_t tstride = (size_t)(H2 >> 4) * 512;
     constexpr int KB = 4;
     wide_b8 pb[4][KB], qb[4][KB];
     const int nblk = (H2 >> 4) / KB;                       // H2 % 128 == 0: an even number of blocks
 #pragma unroll
     for (int q = 0; q < 4; q++)
 #pragma unroll
-      for (int i = 0; i < KB; i++) pb[q][i] = *reinterpret_cast<const wide_b8 *>(wrow + (size_t)q * 32 * H2 + i * 16);
+      for (int i = 0; i < KB; i++) pb[q][i] = *reinterpret_cast<const wide_b8 *>(wrow + q * tstride + i * 512);
     for (int kb = 0; kb < nblk; kb += 2) {
 #pragma unroll
       for (int q = 0; q < 4; q++)
 #pragma unroll
-        for (int i = 0; i < KB; i++) qb[q][i] = *reinterpret_cast<const wide_b8 *>(wrow + (size_t)q * 32 * H2 + ((kb + 1) * KB + i) * 16);
+        for (int i = 0; i < KB; i++) qb[q][i] = *reinterpret_cast<const wide_b8 *>(wrow + q * tstride + ((kb + 1) * KB + i) * 512);
 #pragma unroll
       for (int i = 0; i < KB; i++) {
         const wide_b8 av = *reinterpret_cast<const wide_b8 *>(ap + (kb * KB + i) * 32);
@@ -350,7 +391,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; q++)
 #pragma unroll
-          for (int i = 0; i < KB; i++) pb[q][i] = *reinterpret_cast<const wide_b8 *>(wrow + (size_t)q * 32 * H2 + ((kb + 2) * KB + i) * 16);
+          for (int i = 0; i < KB; i++) pb[q][i] = *reinterpret_cast<const wide_b8 *>(wrow + q * tstride + ((kb + 2) * KB + i) * 512);
       }
 #pragma unroll
       for (int i = 0; i < KB; i++) {
@@ -380,8 +421,8 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
   }
 }
 
-// dW = dZ^T X for the six layers.  Operands are the TRANSPOSED arrays the chain wrote: AT = dZ^T [O][B], XT = X^T [I][B], so both
-// MFMA fragments are 16-byte row reads (lane: row / column r, batch rows 8 h .. 8 h + 7).  ONE wave owns a block of eight 32 x 32
+// dW = dZ^T X for the six layers.  Operands are the TRANSPOSED arrays the chain wrote, in fragment order: AT = dZ^T (O x B),
+// XT = X^T (I x B): a wave's fragment load is 1 KB of consecutive bytes, the k-steps of a tile follow each other.  ONE wave owns a block of eight 32 x 32
 // tiles of dW — 64 x 128 (RO = 2), or 32 x 256 for the heads (RO = 1) — over its slice of the batch: per k-step 6 (9) fragment
 // loads feed 8 MFMAs, and no operand is fetched twice inside a workgroup.  (Measured alternatives: 32 x 128 per wave with four waves
 // per workgroup re-reads X four times: 87 us, bound by those reads; sixteen tiles per wave — 128 x 128 — do not register-allocate:
@@ -401,8 +442,9 @@ __device__ __forceinline__ void wide_wgrad_tile(const WideWgradJob &J, const int
   const int o0 = ot * 32 * RO, i0 = it * 32 * CI;
   const size_t B = (size_t)Bn;
   const int kchunk = Bn / J.splitk, k0 = ks * kchunk;           // batch rows of this split (a multiple of 32)
-  const unsigned short *ap = J.AT + (size_t)(o0 + r) * B + k0 + 8 * h;
-  const unsigned short *xp = J.XT + (size_t)(i0 + r) * B + k0 + 8 * h;
+  const size_t tstride = (B >> 4) * 512;                        // elements of one 32-feature tile: (B / 16) k-steps of 512
+  const unsigned short *ap = J.AT + (size_t)(o0 >> 5) * tstride + ((size_t)(k0 >> 4) * 64 + lane) * 8;
+  const unsigned short *xp = J.XT + (size_t)(i0 >> 5) * tstride + ((size_t)(k0 >> 4) * 64 + lane) * 8;
   bool oa[RO], ia[CI];
 #pragma unroll
   for (int p = 0; p < RO; p++) oa[p] = (o0 + 32 * p + r) < J.O;
@@ -423,9 +465,9 @@ __device__ __forceinline__ void wide_wgrad_tile(const WideWgradJob &J, const int
 #pragma unroll
     for (int i = 0; i < KB; i++) {
 #pragma unroll
-      for (int p = 0; p < RO; p++) A_[p][i] = oa[p] ? *reinterpret_cast<const wide_b8 *>(ap + (size_t)p * 32 * B + (kk + i) * 16) : zero;
+      for (int p = 0; p < RO; p++) A_[p][i] = oa[p] ? *reinterpret_cast<const wide_b8 *>(ap + p * tstride + (size_t)(kk + i) * 512) : zero;
 #pragma unroll
-      for (int q = 0; q < CI; q++) X_[q][i] = ia[q] ? *reinterpret_cast<const wide_b8 *>(xp + (size_t)q * 32 * B + (kk + i) * 16) : zero;
+      for (int q = 0; q < CI; q++) X_[q][i] = ia[q] ? *reinterpret_cast<const wide_b8 *>(xp + q * tstride + (size_t)(kk + i) * 512) : zero;
     }
   };
   auto mma_blk = [&](const wide_b8 (&A_)[RO][KB], const wide_b8 (&X_)[CI][KB]) {
@@ -553,7 +595,7 @@ extern "C" int dm_ppo_wide_grad(const DmPpoWideStep *s, void *stream) {
     a.dz2T[t] = (unsigned short *)s->dz2T[t]; a.dz3T[t] = (unsigned short *)s->dz3T[t];
   }
   a.xbT = (unsigned short *)s->xbT; a.part = s->part; a.clip = s->clip_range; a.vf_coef = s->vf_coef;
-  hipLaunchKernelGGL(wide_fwdbwd_kernel, dim3(s->B / WIDE_R, 2), dim3(WIDE_THREADS), lds, st, a);
+  hipLaunchKernelGGL(wide_fwdbwd_kernel, dim3(2 * (s->B / WIDE_R)), dim3(WIDE_THREADS), lds, st, a);
   // weight gradients: per trunk dW2 (the big one), dW1, dW3; split-K chosen so that every job brings ~64-128 workgroups
   WideWgradArgs g;
   memset(&g, 0, sizeof g);

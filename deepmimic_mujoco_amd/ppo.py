@@ -368,7 +368,7 @@ class WideMlpGrad:
         Dp = int(self.lib.dm_ppo_wide_dp(D))
         bf = lambda *shape: torch.zeros(*shape, device=dev, dtype=torch.bfloat16)
         npk = int(self.lib.dm_ppo_wide_packed_elems(D, H1, H2))
-        self.buf = dict(wpk=[bf(npk), bf(npk)], xbT=bf(Dp, B), h1T=[bf(H1, B), bf(H1, B)], dz1T=[bf(H1, B), bf(H1, B)], h2T=[bf(H2, B), bf(H2, B)],
+        self.buf = dict(wpk=[bf(npk), bf(npk)], xbT=bf((Dp + 31) // 32 * 32, B), h1T=[bf(H1, B), bf(H1, B)], dz1T=[bf(H1, B), bf(H1, B)], h2T=[bf(H2, B), bf(H2, B)],
                         dz2T=[bf(H2, B), bf(H2, B)], dz3T=[bf(32, B), bf(32, B)], part=torch.zeros(2 * (B // 32) * 40, device=dev),
                         stats8=torch.zeros(8, device=dev), out8=torch.zeros(8, device=dev))
         grad = {id(p): g for p, g in zip(opt.params, opt.slices)}

@@ -310,7 +310,8 @@ typedef struct DmPpoWideStep {
   float *gW[2][3], *gb[2][3];
   float *g_log_std;
   void *wpk[2];                 /* bf16 scratch, dm_ppo_wide_packed_elems(D, H1, H2) elements per trunk */
-  void *xbT;                    /* bf16 scratch [dm_ppo_wide_dp(D)][B]: the observations, transposed */
+  void *xbT;                    /* bf16 scratch, (dm_ppo_wide_dp(D) rounded up to 32) * B elements: the observations, transposed; this and
+                                   the five arrays below are opaque (MFMA fragment order, csrc/dm_ppo_wide.hip) */
   void *h1T[2], *dz1T[2];       /* bf16 scratch [H1][B]: tanh output of layer 1, d loss / d (pre-activation of layer 1), transposed */
   void *h2T[2], *dz2T[2];       /* bf16 scratch [H2][B] */
   void *dz3T[2];                /* bf16 scratch [32][B] */

@@ -870,13 +870,14 @@ def test_wide_fused_learner_gradient_matches_fp32_autograd(arch, D, A, B):
     loss_t = loss_t.detach()
     assert abs(float(loss_w) - float(loss_t)) < 2e-3 * max(1.0, abs(float(loss_t))), (float(loss_w), float(loss_t))
     ref = {id(p): s_.clone() for p, s_ in zip(ppo.optimizer.params, ppo.optimizer.slices)}
-    worst_cos, worst_rel = 1.0, 0.0
+    worst_cos, worst_rel, bad = 1.0, 0.0, []
     for name, p_ in pol.named_parameters():
         a, b = gw[id(p_)].reshape(-1), ref[id(p_)].reshape(-1)
         cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
         rel = float((a - b).norm() / (b.norm() + 1e-30))
         worst_cos, worst_rel = min(worst_cos, cos), max(worst_rel, rel)
-        assert cos > 0.999 and rel < 0.03, (name, cos, rel)
+        bad.append((name, round(cos, 5), round(rel, 4)))
+    assert worst_cos > 0.999 and worst_rel < 0.03, bad
     print("wide fused learner %s D %d A %d B %d: loss %.6f / %.6f, worst cosine %.5f, worst relative L2 %.4f" % (arch, D, A, B, float(loss_w), float(loss_t), worst_cos, worst_rel))
     l0 = float(ppo._minibatch_step(obs, act, adv, ret, old_logp))
     for _ in range(4):
