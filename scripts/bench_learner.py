@@ -3,7 +3,11 @@ usage: python scripts/bench_learner.py [H1,H2] [steps] [--no-fused-mlp] [--no-ep
 (--bf16: wide nets run the fused bf16 chain of dm_ppo_wide_grad; with --no-fused-wide the bf16 library-GEMM path)"""
 import sys, time
 import torch
+import os
 sys.path.insert(0, ".")
+import deepmimic_mujoco_amd._lib as _lib
+if os.environ.get("DM_LIB_VARIANT"):      # experiment builds: libdeepmimic_hip_<variant>.so next to the shipped library
+    _lib.LIB_PATH = _lib.LIB_PATH.replace("libdeepmimic_hip.so", "libdeepmimic_hip_%s.so" % os.environ["DM_LIB_VARIANT"])
 from deepmimic_mujoco_amd.ppo import PPO
 
 arch = tuple(int(x) for x in (sys.argv[1] if len(sys.argv) > 1 and "," in sys.argv[1] else "256,128").split(","))
