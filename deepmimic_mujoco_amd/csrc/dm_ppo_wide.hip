@@ -51,6 +51,7 @@ __device__ __forceinline__ wide_b8 wide_ldfrag(const unsigned short *M, int t, i
   return *reinterpret_cast<const wide_b8 *>(M + ((((size_t)t * nks + ks) * 64 + lane) << 3));
 }
 
+constexpr int WIDE_MAX_SPLITK = 8;      // more slices than this and the fp32 atomics into one tile queue up (sk = 64 on a [256,128] net: 46 us)
 constexpr int WIDE_R = 32, WIDE_NW = 8, WIDE_THREADS = 64 * WIDE_NW, WIDE_PART = 40;
 
 struct WidePackArgs {
@@ -459,7 +460,7 @@ __device__ __forceinline__ void wide_wgrad_tile(const WideWgradJob &J, const int
       for (int j = 0; j < 16; j++) acc[p][q][j] = 0.f;
   const wide_b8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
   // two-deep ring of register blocks of two k-steps: the loads of the next block are in flight under the 16 MFMAs of this one
-  constexpr int KB = 2;
+  constexpr int KB = RO == 2 ? 4 : 2;
   wide_b8 av[RO][KB], xv[CI][KB], aw[RO][KB], xw[CI][KB];
   auto load_blk = [&](wide_b8 (&A_)[RO][KB], wide_b8 (&X_)[CI][KB], const int kk) {
 #pragma unroll
@@ -500,20 +501,31 @@ __device__ __forceinline__ void wide_wgrad_tile(const WideWgradJob &J, const int
 }
 
 __global__ void __launch_bounds__(64) wide_wgrad_kernel(WideWgradArgs a) {
-  const int blk = blockIdx.x, tid = threadIdx.x;
-  if (blk == a.nblocks) {   // loss scalars and the log_std gradient from the per-workgroup partials (one wave, fixed order)
+  const int blk = (int)blockIdx.x - 1, tid = threadIdx.x;
+  if (blk < 0) {   // block 0 (dispatched first): loss scalars and the log_std gradient from the per-workgroup partials, in a fixed order
+    // lane l sums the rows l, l + 64, .. of a trunk's [nblk][40] table (ten independent 16-byte loads per row: the loads of
+    // all rows are in flight together; a first version walked the rows with 36 lanes and paid ~32 dependent L2 misses: 40 us,
+    // the whole launch's length for a small net), the 64 lane sums meet in LDS
     __shared__ float red[2][36];
-    if (tid < 36) {
-      for (int t = 0; t < 2; t++) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;       // four independent chains: the loads overlap
-        int i = 0;
-        for (; i + 3 < a.nblk; i += 4) {
-          s0 += a.part[((size_t)t * a.nblk + i) * WIDE_PART + tid]; s1 += a.part[((size_t)t * a.nblk + i + 1) * WIDE_PART + tid];
-          s2 += a.part[((size_t)t * a.nblk + i + 2) * WIDE_PART + tid]; s3 += a.part[((size_t)t * a.nblk + i + 3) * WIDE_PART + tid];
-        }
-        for (; i < a.nblk; i++) s0 += a.part[((size_t)t * a.nblk + i) * WIDE_PART + tid];
-        red[t][tid] = (s0 + s1) + (s2 + s3);
+    __shared__ float lsum[64][41];
+    for (int t = 0; t < 2; t++) {
+      float acc[WIDE_PART];
+#pragma unroll
+      for (int e = 0; e < WIDE_PART; e++) acc[e] = 0.f;
+      for (int i = tid; i < a.nblk; i += 64) {
+        const float4 *row = reinterpret_cast<const float4 *>(a.part + ((size_t)t * a.nblk + i) * WIDE_PART);
+#pragma unroll
+        for (int e = 0; e < WIDE_PART / 4; e++) { const float4 v = row[e]; acc[4 * e] += v.x; acc[4 * e + 1] += v.y; acc[4 * e + 2] += v.z; acc[4 * e + 3] += v.w; }
       }
+#pragma unroll
+      for (int e = 0; e < 36; e++) lsum[tid][e] = acc[e];
+      __syncthreads();
+      if (tid < 36) {
+        float s0 = 0.f;
+        for (int l = 0; l < 64; l++) s0 += lsum[l][tid];
+        red[t][tid] = s0;
+      }
+      __syncthreads();
     }
     __syncthreads();
     if (tid < a.A) a.g_log_std[tid] += red[0][tid] - a.ent_coef;
@@ -611,7 +623,7 @@ extern "C" int dm_ppo_wide_grad(const DmPpoWideStep *s, void *stream) {
     J.otiles = (O + 32 * ro - 1) / (32 * ro);
     J.itiles = (I + 32 * (8 / ro) - 1) / (32 * (8 / ro));
     int sk = 1;
-    while (J.otiles * J.itiles * sk * 2 <= want && (s->B / (sk * 2)) % 64 == 0) sk *= 2;
+    while (sk < WIDE_MAX_SPLITK && J.otiles * J.itiles * sk * 2 <= want && (s->B / (sk * 2)) % 64 == 0) sk *= 2;
     J.splitk = sk; J.first = first;                       // first % 8 == 0: a job's local block id & 7 is its XCD
     J.per = (J.otiles * J.itiles * sk + 7) / 8;
     first += 8 * J.per;
