@@ -213,6 +213,25 @@ def g1_record(local_rank, n=4096, steps=20, warmup=5, with_cpu=False):
                               "env_steps_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3,
                               "done_fraction_last_step": float(o["done"].float().mean()), "mean_reward": float(o["rew"].mean())}
     venv.close()
+    # the same two envs with the batch split into two engines of n / 2 envs, each on its own HIP stream (VecEnv sub_batches=2;
+    # one step still ends with both halves joined): one half's kernels fill the CUs the other half's heaviest envs leave idle
+    from deepmimic_mujoco_amd.g1 import HipG1VecEnv
+    rec["two_streams"] = {"sub_batches": 2, "window": "steps %d..%d after reset" % (warmup, warmup + steps - 1),
+                          "note": "auxiliary: HipG1VecEnv(sub_batches=2).step_tensor, every step joins both sub-batches"}
+    for key, make, sc in (("dp_env", lambda: HipG1VecEnv(n, motion="walk", device=local_rank, seed=3, sub_batches=2), 1.0),
+                          ("dp_combined_env", lambda: HipG1CombinedVecEnv(n, device=local_rank, seed=3, sub_batches=2), 0.25)):
+        venv = make()
+        venv.reset_tensor()
+        for t in range(warmup):
+            venv.step_tensor(acts[t % 8] * sc)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(steps):
+            venv.step_tensor(acts[t % 8] * sc)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rec["two_streams"][key] = {"env_steps_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3}
+        venv.close()
     if with_cpu:   # the fp64 G1 oracle on 16 host threads, bounded sample of the same workload (checker code: CPU leg only)
         import ctypes as C
         from concurrent.futures import ThreadPoolExecutor
@@ -560,15 +579,16 @@ def main():
     # half simulates): the ramp-down of one launch overlaps the next launch of the other half.
     pipelined = None
     if world == 1 and N % 2 == 0 and args.actions == "random" and not args.no_pipelined:
+        from deepmimic_mujoco_amd.streams import concurrent_streams
         K, n2 = 2, N // 2
-        subs = []
+        subs, sts = [], concurrent_streams(dev, 2)
         for k in range(K):
             e2 = HipEngine(model, n2, device=local_rank, seed=1234 + 17 * (k + 1), auto_reset=True)
             e2.load_clip(0, mocap)
             o2 = e2.alloc_outputs()
             a2 = torch.zeros(n2, 28, device=dev)
             e2.reset(o2["obs"], idx_init=((torch.arange(n2, device=dev) + k * n2) % L).to(torch.int32))
-            subs.append((e2, o2, a2, torch.cuda.Stream(device=dev)))
+            subs.append((e2, o2, a2, sts[k]))
 
         def run(nsteps, base):
             for i in range(nsteps):

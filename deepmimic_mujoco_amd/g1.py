@@ -416,7 +416,8 @@ class HipG1VecEnv(_SB3VecEnv):
             return self.out
         cur = t.cuda.current_stream(self.device)
         if getattr(self, "_streams", None) is None:
-            self._streams = [t.cuda.Stream(device=self.device) for _ in self.engines]
+            from .streams import concurrent_streams
+            self._streams = concurrent_streams(self.device, len(self.engines))      # on distinct hardware queues (probed)
         fork = cur.record_event()
         for e, o, sl, s in zip(self.engines, self.sub_out, self.sub_slices, self._streams):
             s.wait_event(fork)

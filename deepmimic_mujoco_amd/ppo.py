@@ -23,6 +23,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 from torch import nn
+from .streams import concurrent_streams
 
 
 class _HipLinearFn(torch.autograd.Function):
@@ -775,7 +776,7 @@ class PPO:
             last = (env.reset_tensor() if self._last_obs is None else self._last_obs).clone()
             self._rollout_scratch((N, 0))
             st = self._fp = dict(rb=rb, last=last, fwd=FusedPolicyForward(self.policy, dev), act_env=z(N, self.act_dim),
-                                 streams=[torch.cuda.Stream(device=dev) for _ in range(K)] if K > 1 else None, graph=None)
+                                 streams=concurrent_streams(dev, K) if K > 1 else None, graph=None)
         rb, last, fwd = st["rb"], st["last"], st["fwd"]
         if self._last_obs is not None and self._last_obs.data_ptr() != last.data_ptr():
             last.copy_(self._last_obs)
@@ -839,7 +840,7 @@ class PPO:
         z = lambda *shape, dt=torch.float32: torch.zeros(*shape, device=dev, dtype=dt)
         rb = dict(obs=z(T, N, self.obs_dim, dt=bd), act=z(T, N, self.act_dim, dt=bd), rew=z(T, N), done=z(T, N), val=z(T, N), logp=z(T, N))
         last = env.reset_tensor().clone() if self._last_obs is None else self._last_obs.clone()
-        streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
+        streams = concurrent_streams(dev, K)
 
         def chain(k, steps):
             sl = env.sub_slices[k]
@@ -893,7 +894,7 @@ class PPO:
             z = lambda *shape: torch.zeros(*shape, device=dev)
             rb = dict(obs=z(T, N, self.obs_dim), act=z(T, N, self.act_dim), rew=z(T, N), done=z(T, N), val=z(T, N), logp=z(T, N))
             last = env.reset_tensor().clone() if self._last_obs is None else self._last_obs.clone()
-            self._pipe = (rb, last, [torch.cuda.Stream(device=dev) for _ in range(K)])
+            self._pipe = (rb, last, concurrent_streams(dev, K))
         rb, last, streams = self._pipe
         cur = torch.cuda.current_stream(dev)
         with torch.no_grad():

@@ -15,5 +15,6 @@ for sb in [int(x) for x in sys.argv[3:]] or [1, 2, 4]:
     torch.cuda.synchronize(); t0 = time.time()
     for t in range(40): o = venv.step_tensor(acts[t % 8])
     torch.cuda.synchronize(); dt = time.time() - t0
+    if getattr(venv, "_streams", None): print("streams", [hex(s_.cuda_stream) for s_ in venv._streams], "current", hex(torch.cuda.current_stream().cuda_stream))
     print({"task": what, "envs": n, "sub_batches": sb, "env_steps_per_s": n * 40 / dt, "ms": dt / 40 * 1e3}, flush=True)
     venv.close()
