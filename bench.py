@@ -423,6 +423,8 @@ def main():
     ap.add_argument("--actions", default="random", choices=["random", "zero"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the auxiliary two-sub-batch measurement (profiling runs)")
+    ap.add_argument("--no-physics-only", action="store_true", help="skip the physics-only / full-step kernel comparison (profiling runs: "
+                                                                   "its launches would be averaged into the step kernel's counters)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--integrator", default="model", choices=["model", "RK4", "Euler"],
                     help="model = the XML's (RK4, the headline); Euler = north_star's semi-implicit Euler option (auxiliary figure)")
@@ -552,7 +554,7 @@ def main():
     # saved, dm_physics_step (the mj_step-equivalent alone: same kernel, task layer skipped, same launch order) is timed on it,
     # the state is put back and the full dm_step is timed on the SAME state.  Kernel times from the library's HIP events.
     physics_only = None
-    if args.actions == "random" and args.integrator != "Euler":
+    if args.actions == "random" and args.integrator != "Euler" and not args.no_physics_only:
         nphys, tp, tf = 24, 0.0, 0.0
         eng.enable_timing(True, stride=1)
         for i in range(nphys):
