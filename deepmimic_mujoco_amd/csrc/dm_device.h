@@ -93,7 +93,7 @@ struct EnvLds {
   float c_dist[DMK_MAXCON], c_pos[DMK_MAXCON][3], c_frame[DMK_MAXCON][9];
   int32_t c_g1[DMK_MAXCON], c_g2[DMK_MAXCON];
 #ifdef DM_PROFILE
-  unsigned long long prof_t; unsigned prof[16];  // diagnostic stamps (-DDM_PROFILE build only)
+  unsigned long long prof_t, prof_t0; unsigned prof[16], prof_stage[4];  // diagnostic stamps (-DDM_PROFILE build only)
 #endif
   int32_t info[8];                    // ncon, nefc, nlimit, solver_iter, overflow (last forward evaluation)
   int16_t rowinfo[DMK_MAXROW];        // contact rows: (contact << 3) | edge | 0x4000 (whole pyramid kept); limit rows: -(2 dof + side + 1)

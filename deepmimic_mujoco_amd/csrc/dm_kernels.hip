@@ -34,7 +34,9 @@
 // Diagnostic build only (-DDM_PROFILE): per-phase cycle stamps, written to the debug buffer
 // [352:368).  The shipped library never executes a stamp.
 #ifdef DM_PROFILE
-#define PROF_DECL do { if ((threadIdx.x & 63) == 0) { for (int _i = 0; _i < 16; _i++) g_S.prof[_i] = 0; g_S.prof_t = __builtin_amdgcn_s_memtime(); } } while (0)
+#define PROF_DECL do { if ((threadIdx.x & 63) == 0) { for (int _i = 0; _i < 16; _i++) g_S.prof[_i] = 0; for (int _i = 0; _i < 4; _i++) g_S.prof_stage[_i] = 0; g_S.prof_t = g_S.prof_t0 = __builtin_amdgcn_s_memtime(); } } while (0)
+// ticks from kernel entry to the end of RK stage i (scripts/sched_predict.py: how well stage 0 predicts the step)
+#define PROF_STAGE(i) do { if ((threadIdx.x & 63) == 0 && (i) < 4) g_S.prof_stage[i] = (unsigned)(__builtin_amdgcn_s_memtime() - g_S.prof_t0); } while (0)
 #define PROF(i) do { if ((threadIdx.x & 63) == 0) { unsigned long long _t = __builtin_amdgcn_s_memtime(); g_S.prof[i] += (unsigned)(_t - g_S.prof_t); g_S.prof_t = _t; } } while (0)
 #if DM_PROFILE == 2
 #define PROF2(i) PROF(i)
@@ -43,6 +45,7 @@
 #endif
 #else
 #define PROF2(i) do {} while (0)
+#define PROF_STAGE(i) do {} while (0)
 #define PROF_DECL do {} while (0)
 #define PROF(i) do {} while (0)
 #endif
@@ -1804,6 +1807,7 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
       if (lane >= 6 && lane < DMK_NV) S.qpos[lane + 1] = x0q + h * dq;
       if (lane < 4) S.qpos[3 + lane] = (lane == 0) ? qn[0] : (lane == 1) ? qn[1] : (lane == 2) ? qn[2] : qn[3];
       SYNC();
+      PROF_STAGE(it);
       it++;
       continue;
     }
@@ -1840,6 +1844,7 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
     }
 
     PROF(10);
+    PROF_STAGE(it);
     if (mode == DMK_MODE_PHYSICS) {   // dm_physics_step: sim.step() alone; an instability resets the data as MuJoCo does
       if (sim_err) {
         f8r = f8l = 0;
@@ -2070,7 +2075,8 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
   if (P.debug && lane < 16) { unsigned v = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) if (lane == i) v = g_S.prof[i];
-    P.debug[(size_t)env * DM_DEBUG_STRIDE + 352 + lane] = (float)v; }
+    P.debug[(size_t)env * DM_DEBUG_STRIDE + 352 + lane] = (float)v;
+    if (lane < 4) P.debug[(size_t)env * DM_DEBUG_STRIDE + 368 + lane] = (float)g_S.prof_stage[lane]; }
 #endif
   // ---------------------------------------------------------------- state write-back
   if (lane < DMK_NQ) st[DMS_QPOS + lane] = S.qpos[lane];
