@@ -833,7 +833,8 @@ def test_bf16_learner_option_tracks_the_fp32_learner():
     assert l16[-1] < l16[0] and abs(l16[-1] - l32[-1]) < 0.05 * max(1.0, abs(l32[-1]))
 
 
-@pytest.mark.parametrize("arch,D,A,B", [((1024, 512), 67, 28, 4096), ((1024, 512), 98, 23, 1024), ((512, 256), 72, 28, 512), ((256, 128), 85, 23, 256)])
+@pytest.mark.parametrize("arch,D,A,B", [((1024, 512), 67, 28, 4096), ((1024, 512), 98, 23, 1024), ((512, 256), 72, 28, 512), ((256, 128), 85, 23, 256),
+                                       ((512, 128), 112, 32, 192), ((256, 256), 1, 1, 64)])     # the last two: row tiles not a multiple of 4 (plain block order), widest / narrowest D and A
 def test_wide_fused_learner_gradient_matches_fp32_autograd(arch, D, A, B):
     """dm_ppo_wide_grad (csrc/dm_ppo_wide.hip): the fused bf16 matrix-pipe forward / loss / backward chain of the [1024,512]-class
     net (BASELINE configs 3-5) + the split-K bf16 weight-gradient kernel, against the fp32 loss of SB3's PPO.train written with plain
