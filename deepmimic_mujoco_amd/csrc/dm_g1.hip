@@ -1156,7 +1156,7 @@ __device__ __forceinline__ int np_plane_cylinder(Con *c, const Geo &p, const Geo
 }
 // [EXT] mjc_PlaneConvex for a mesh: support vertex towards the plane + three directions tilted by 0.3 (low-confidence
 // restatement of the multi-contact rule, identical to the oracle's)
-__device__ __noinline__ int np_plane_mesh(Con *c, const Geo &p, const Geo &g, const int lane) {
+__device__ __forceinline__ int np_plane_mesh_body(Con *c, const Geo &p, const Geo &g, const int lane) {
   double normal[3] = {p.mat[2], p.mat[5], p.mat[8]}, t1[3] = {p.mat[0], p.mat[3], p.mat[6]}, t2[3] = {p.mat[1], p.mat[4], p.mat[7]};
   int used[4], n = 0;
   for (int k = 0; k < 4; k++) {
@@ -1227,7 +1227,7 @@ __device__ __forceinline__ int np_sphere_box(Con *c, const Geo &s, const Geo &b)
   return 1;
 }
 // box-box (SAT + face clipping), same construction as the humanoid3d path (own construction, not MuJoCo's code)
-__device__ __noinline__ int np_box_box(Con *c, const Geo &A, const Geo &Bx, double (*poly)[3], double (*tmp)[3]) {
+__device__ __forceinline__ int np_box_box_body(Con *c, const Geo &A, const Geo &Bx, double (*poly)[3], double (*tmp)[3]) {
   const double *p1 = A.pos, *R1 = A.mat, *s1 = A.size, *p2 = Bx.pos, *R2 = Bx.mat, *s2 = Bx.size;
   double R[9], AR[9], t[3], tw[3];
   dsub(tw, p2, p1);
@@ -1499,8 +1499,18 @@ __device__ __forceinline__ int broadphase(const Dev &T, const int cap, int &over
 
 // [EXT] mj_collision, part 2: the narrowphase of ONE staged pair (geoms in W.geo / W.geoi): analytic routines for the pairs MuJoCo
 // has them for, MPR for everything with a cylinder or a mesh.  Returns the number of contacts left in W.rc.
+// out-of-line copies for the monolithic kernel (its register budget is the env phases'); the pair kernel inlines the bodies: the
+// Geo views then stay in registers instead of one scratch copy per lane (they were passed by reference to the calls), and the
+// kernel needs 190 instead of 226 VGPRs
+__device__ __noinline__ int np_plane_mesh(Con *c, const Geo &p, const Geo &g, const int lane) { return np_plane_mesh_body(c, p, g, lane); }
+__device__ __noinline__ int np_box_box(Con *c, const Geo &A, const Geo &Bx, double (*poly)[3], double (*tmp)[3]) { return np_box_box_body(c, A, Bx, poly, tmp); }
+
+template <bool INL>
 __device__ __forceinline__ int narrow_pair(const MeshPtrs &M, const NpStage &W, float *cache, const bool direct, const int pair,
                                            const int skip, const int lane) {
+  // (in the monolithic kernel A and B go to scratch, one copy per lane, because the two out-of-line routines take them by reference.
+  // Passing the staging pointers by value instead was 5 % SLOWER in the pair kernel — 5.07 against 4.81 ms per step — and needs the
+  // pointers laundered, or hipcc 7.2 folds the constant LDS address into an unencodable `v_cmp_ne_u32 0, src_shared_base`.)
   Geo A, B;
   view_geo(M, W, 0, A);
   view_geo(M, W, 1, B);
@@ -1511,10 +1521,10 @@ __device__ __forceinline__ int narrow_pair(const MeshPtrs &M, const NpStage &W, 
     if (t2 == DM_GEOM_SPHERE) n = np_plane_sphere(rc, A, B.pos, B.size[0]);
     else if (t2 == DM_GEOM_CYLINDER) n = np_plane_cylinder(rc, A, B);
     else if (t2 == DM_GEOM_BOX) n = np_plane_box(rc, A, B);
-    else if (t2 == DM_GEOM_MESH && !(skip & 128)) n = np_plane_mesh(rc, A, B, lane);
+    else if (t2 == DM_GEOM_MESH && !(skip & 128)) n = INL ? np_plane_mesh_body(rc, A, B, lane) : np_plane_mesh(rc, A, B, lane);
   } else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_SPHERE) n = np_sphere_sphere(rc, A.pos, A.size[0], B.pos, B.size[0]);
   else if (t1 == DM_GEOM_SPHERE && t2 == DM_GEOM_BOX) n = np_sphere_box(rc, A, B);
-  else if (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX) n = np_box_box(rc, A, B, W.poly0, W.poly1);
+  else if (t1 == DM_GEOM_BOX && t2 == DM_GEOM_BOX) n = INL ? np_box_box_body(rc, A, B, W.poly0, W.poly1) : np_box_box(rc, A, B, W.poly0, W.poly1);
   else if (!(skip & 64)) n = np_convex(rc, A, B, (skip & 256) ? nullptr : cache, direct, pair, W.ps, lane);
   return n;
 }
@@ -1546,7 +1556,7 @@ __device__ __noinline__ int collide(const Dev &T, const Launch &P, const int env
     SYNC();
     const int cls = pair_class(W.geoi[0][0], W.geoi[1][0]);
     n_an += cls == 0; n_pm += cls == 1; n_mpr += cls == 2;
-    const int n = narrow_pair(M, W, P.sepc + (size_t)env * (4 * SEPC + 4), false, p, P.pad, lane);
+    const int n = narrow_pair<false>(M, W, P.sepc + (size_t)env * (4 * SEPC + 4), false, p, P.pad, lane);
     SYNC();
     PROF(cls == 1 ? 5 : (cls == 0 ? 4 : 6));
     for (int k = 0; k < n; k++) {
@@ -1697,7 +1707,9 @@ __device__ __noinline__ int make_constraint(const Dev &T, float *JT, float *RW, 
 // A = J M^-1 J^T + R into the per-env scratch.  Up to 128 rows: lane r (and r + 64) keeps its row of B = D^-1/2 L^-T J^T in
 // 43 registers (solved with static indices), and A[i][:] is 43 broadcasts of row i (v_readlane: scalar operands) times the
 // lanes' own rows — no memory traffic except J in and A out.  More rows: the general path through the B^T scratch.
-__device__ __noinline__ void project_constraint(const Dev &T, const float *JT, float *BT, float *AR, const float *RW,
+// (body shared by the out-of-line copy the monolithic kernel calls and the split env kernel, which inlines it: as a callee it
+// saves and restores 112 VGPRs per call through scratch — 28 KB per env and evaluation, most of g1_env_kernel's HBM writes)
+__device__ __forceinline__ void project_constraint_body(const Dev &T, const float *JT, float *BT, float *AR, const float *RW,
                                                 const int nefc, const int lane) {
   const float *e_R = RW;
   if (nefc <= MAXROW) {
@@ -1822,7 +1834,7 @@ __device__ __noinline__ void project_constraint(const Dev &T, const float *JT, f
 }
 
 // [EXT] mj_fwdConstraint + mj_solPGS: dual PGS, rows unilateral (limits, pyramid edges) or boxed (friction loss)
-__device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const float *BT, const float *AR, float *RW, const int nefc, const int lane,
+__device__ __forceinline__ void fwd_constraint_body(const Dev &T, const float *JT, const float *BT, const float *AR, float *RW, const int nefc, const int lane,
                                              const int max_iter) {
   float *e_R = RW, *e_b = RW + MAXROW, *e_f = RW + 2 * MAXROW, *e_lim = RW + 3 * MAXROW;
   const int32_t *e_meta = (const int32_t *)(RW + 4 * MAXROW);
@@ -2082,6 +2094,15 @@ __device__ __forceinline__ void forward_pre(const Dev &T, const int lane, const 
   fwd_smooth(T, lane);   // before the collision stage: its scratch shares LDS with the contact arrays
   PROF(2);
 }
+__device__ __noinline__ void project_constraint(const Dev &T, const float *JT, float *BT, float *AR, const float *RW, const int nefc, const int lane) {
+  project_constraint_body(T, JT, BT, AR, RW, nefc, lane);
+}
+__device__ __noinline__ void fwd_constraint(const Dev &T, const float *JT, const float *BT, const float *AR, float *RW, const int nefc, const int lane,
+                                             const int max_iter) {
+  fwd_constraint_body(T, JT, BT, AR, RW, nefc, lane, max_iter);
+}
+
+template <bool INL>   // INL: the two constraint phases inlined (split env kernel) / called out of line (monolithic kernel)
 __device__ __forceinline__ void forward_post(const Launch &P, const Dev &T, const int env, const int lane, const int ncon) {
   float *JT = P.jt + (size_t)env * 44 * MAXROW, *BT = P.bt + (size_t)env * 44 * MAXROW, *AR = P.ar + (size_t)env * MAXROW * MAXROW;
   float *RW = P.rows + (size_t)env * 5 * MAXROW;
@@ -2090,10 +2111,11 @@ __device__ __forceinline__ void forward_post(const Launch &P, const Dev &T, cons
   if (!(P.pad & 8)) nefc = make_constraint(T, JT, RW, ncon, lane);
   else { if (lane == 0) { S.info[1] = 0; S.info[2] = 0; } SYNC(); }
   PROF(8);
-  if (!(P.pad & 4)) project_constraint(T, JT, BT, AR, RW, nefc, lane);
+  if (!(P.pad & 4)) { if (INL) project_constraint_body(T, JT, BT, AR, RW, nefc, lane); else project_constraint(T, JT, BT, AR, RW, nefc, lane); }
   PROF(9);
   if (P.pad & 16) nefc = 0;
-  fwd_constraint(T, JT, BT, AR, RW, nefc, lane, (P.pad & 1) ? 0 : T.iterations);
+  if (INL) fwd_constraint_body(T, JT, BT, AR, RW, nefc, lane, (P.pad & 1) ? 0 : T.iterations);
+  else fwd_constraint(T, JT, BT, AR, RW, nefc, lane, (P.pad & 1) ? 0 : T.iterations);
   PROF(10);
 }
 __device__ __noinline__ void forward(const Launch &P, const Dev &T, const int env, const int lane, const bool qlo) {
@@ -2101,7 +2123,7 @@ __device__ __noinline__ void forward(const Launch &P, const Dev &T, const int en
   int ncon = 0;
   if (!(P.pad & 2)) ncon = collide(T, P, env, lane);
   else { if (lane == 0) { S.info[0] = 0; S.info[4] = 0; } SYNC(); }
-  forward_post(P, T, env, lane, ncon);
+  forward_post<false>(P, T, env, lane, ncon);
 }
 
 // [EXT] mj_integratePos from the step's start state x0q (+ the low words of its normalised root quaternion), in fp64.  `lo`: keep
@@ -2655,7 +2677,7 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_env_kernel(Launch P) {
     if (wctx[WC_FINISHED]) return;
     ws_load(P, ws, X, lane);
     const int ncon = gather_contacts(T, P, env, lane);            // second half of the evaluation in flight
-    forward_post(P, T, env, lane, ncon);
+    forward_post<true>(P, T, env, lane, ncon);
     X.work += 4000 + S.info[1] * (8 + 6 * S.info[3]) + 3000 * ((S.info[6] >> 16) & 0xFF);
     bool again = false;
     if (!X.after_reset) again = rk_advance(P, T, env, lane, X);
@@ -2699,7 +2721,7 @@ extern "C" __global__ void __launch_bounds__(64, G1_PAIR_WAVES) g1_pair_kernel(P
     if (lane < 36) Wl.geo[lane / 18][lane % 18] = Q.pq_geo[slot * 36 + lane];
     if (lane == 0) { stage_geoi(T, W, T.p_g1[p], 0); stage_geoi(T, W, T.p_g2[p], 1); }
     SYNC();
-    const int n = narrow_pair(M, W, Q.sepc2 + ((size_t)env * 1024 + p) * 4, true, p, 0, lane);
+    const int n = narrow_pair<true>(M, W, Q.sepc2 + ((size_t)env * 1024 + p) * 4, true, p, 0, lane);
     SYNC();
     if (lane == 0) Q.pq_cnt[slot] = n;
     if (lane < n) {
