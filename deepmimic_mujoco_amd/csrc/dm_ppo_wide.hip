@@ -51,6 +51,7 @@ __device__ __forceinline__ wide_b8 wide_ldfrag(const unsigned short *M, int t, i
   return *reinterpret_cast<const wide_b8 *>(M + ((((size_t)t * nks + ks) * 64 + lane) << 3));
 }
 
+constexpr int WIDE_WG_WAVES = 4;        // waves of a weight-gradient workgroup: each takes a quarter of the workgroup's batch slice
 constexpr int WIDE_MAX_SPLITK = 8;      // more slices than this and the fp32 atomics into one tile queue up (sk = 64 on a [256,128] net: 46 us)
 constexpr int WIDE_R = 32, WIDE_NW = 8, WIDE_THREADS = 64 * WIDE_NW, WIDE_PART = 40;
 
@@ -437,12 +438,15 @@ struct WideWgradArgs {
 };
 
 template <int RO>
-__device__ __forceinline__ void wide_wgrad_tile(const WideWgradJob &J, const int Bn, const int ot, const int it, const int ks, const int lane) {
+__device__ __forceinline__ void wide_wgrad_tile(const WideWgradJob &J, const int Bn, const int ot, const int it, const int ks, const int wave, const int lane,
+                                                float *wl) {
   constexpr int CI = 8 / RO;
   const int r = lane & 31, h = lane >> 5;
   const int o0 = ot * 32 * RO, i0 = it * 32 * CI;
   const size_t B = (size_t)Bn;
-  const int kchunk = Bn / J.splitk, k0 = ks * kchunk;           // batch rows of this split (a multiple of 32)
+  // batch rows of this workgroup's split, in units of 64 rows; the four waves take a quarter of the units each
+  const int units = (Bn / J.splitk) >> 6, u0 = wave * units / WIDE_WG_WAVES, u1 = (wave + 1) * units / WIDE_WG_WAVES;
+  const int k0 = ks * (Bn / J.splitk) + u0 * 64;
   const size_t tstride = (B >> 4) * 512;                        // elements of one 32-feature tile: (B / 16) k-steps of 512
   const unsigned short *ap = J.AT + (size_t)(o0 >> 5) * tstride + ((size_t)(k0 >> 4) * 64 + lane) * 8;
   const unsigned short *xp = J.XT + (size_t)(i0 >> 5) * tstride + ((size_t)(k0 >> 4) * 64 + lane) * 8;
@@ -479,40 +483,55 @@ __device__ __forceinline__ void wide_wgrad_tile(const WideWgradJob &J, const int
 #pragma unroll
         for (int q = 0; q < CI; q++) acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[p][i], X_[q][i], acc[p][q], 0, 0, 0);
   };
-  const int nks = kchunk >> 4;                       // a multiple of 2 KB (kchunk % 64 == 0)
-  load_blk(av, xv, 0);
+  const int nks = (u1 - u0) * 4;                     // k-steps of 16 rows: a multiple of 4 (of KB), possibly 0
+  if (nks > 0) load_blk(av, xv, 0);
   for (int kk = 0; kk < nks; kk += 2 * KB) {
     if (kk + KB < nks) load_blk(aw, xw, kk + KB);
     mma_blk(av, xv);
     if (kk + 2 * KB < nks) load_blk(av, xv, kk + 2 * KB);
     if (kk + KB < nks) mma_blk(aw, xw);
   }
+  // the four partial blocks meet in LDS ([wave][tile][register][lane]: lane-contiguous, conflict-free); wave w then owns tiles
+  // 2 w and 2 w + 1: fixed summation order, and with splitk == 1 a plain store (no atomics, bit-reproducible gradients)
 #pragma unroll
   for (int p = 0; p < RO; p++)
 #pragma unroll
-    for (int q = 0; q < CI; q++) {
-      if (!ia[q]) continue;
+    for (int q = 0; q < CI; q++)
 #pragma unroll
-      for (int j = 0; j < 16; j++) {
-        const int row = o0 + 32 * p + wide_row(j, h);
-        if (row < J.O) atomicAdd(&J.dW[(size_t)row * J.ldw + i0 + 32 * q + r], acc[p][q][j]);   // (plain stores instead: 50 -> 35 us)
+      for (int j = 0; j < 16; j++) wl[((wave * 8 + p * CI + q) << 10) + j * 64 + lane] = acc[p][q][j];
+  __syncthreads();
+#pragma unroll
+  for (int tt = 0; tt < 2; tt++) {
+    const int t = 2 * wave + tt, p = t / CI, q = t % CI;
+    if (!((i0 + 32 * q + r) < J.I)) continue;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WIDE_WG_WAVES; w++) v += wl[((w * 8 + t) << 10) + j * 64 + lane];
+      const int row = o0 + 32 * p + wide_row(j, h);
+      if (row < J.O) {
+        float *dst = &J.dW[(size_t)row * J.ldw + i0 + 32 * q + r];
+        if (J.splitk == 1) *dst = v; else atomicAdd(dst, v);
       }
     }
+  }
 }
 
-__global__ void __launch_bounds__(64) wide_wgrad_kernel(WideWgradArgs a) {
+__global__ void __launch_bounds__(64 * WIDE_WG_WAVES) wide_wgrad_kernel(WideWgradArgs a) {
+  extern __shared__ __align__(16) float wide_wl[];      // 4 waves x 8 tiles x 4 KB
   const int blk = (int)blockIdx.x - 1, tid = threadIdx.x;
   if (blk < 0) {   // block 0 (dispatched first): loss scalars and the log_std gradient from the per-workgroup partials, in a fixed order
-    // lane l sums the rows l, l + 64, .. of a trunk's [nblk][40] table (ten independent 16-byte loads per row: the loads of
+    // thread l sums the rows l, l + 256, .. of a trunk's [nblk][40] table (ten independent 16-byte loads per row: the loads of
     // all rows are in flight together; a first version walked the rows with 36 lanes and paid ~32 dependent L2 misses: 40 us,
     // the whole launch's length for a small net), the 64 lane sums meet in LDS
     __shared__ float red[2][36];
-    __shared__ float lsum[64][41];
+    float (*lsum)[41] = reinterpret_cast<float (*)[41]>(wide_wl);      // [256][41]
     for (int t = 0; t < 2; t++) {
       float acc[WIDE_PART];
 #pragma unroll
       for (int e = 0; e < WIDE_PART; e++) acc[e] = 0.f;
-      for (int i = tid; i < a.nblk; i += 64) {
+      for (int i = tid; i < a.nblk; i += 64 * WIDE_WG_WAVES) {
         const float4 *row = reinterpret_cast<const float4 *>(a.part + ((size_t)t * a.nblk + i) * WIDE_PART);
 #pragma unroll
         for (int e = 0; e < WIDE_PART / 4; e++) { const float4 v = row[e]; acc[4 * e] += v.x; acc[4 * e + 1] += v.y; acc[4 * e + 2] += v.z; acc[4 * e + 3] += v.w; }
@@ -522,7 +541,7 @@ __global__ void __launch_bounds__(64) wide_wgrad_kernel(WideWgradArgs a) {
       __syncthreads();
       if (tid < 36) {
         float s0 = 0.f;
-        for (int l = 0; l < 64; l++) s0 += lsum[l][tid];
+        for (int l = 0; l < 64 * WIDE_WG_WAVES; l++) s0 += lsum[l][tid];
         red[t][tid] = s0;
       }
       __syncthreads();
@@ -552,8 +571,8 @@ __global__ void __launch_bounds__(64) wide_wgrad_kernel(WideWgradArgs a) {
   if ((loc >> 3) >= J.per || rem >= J.splitk * J.otiles * J.itiles) return;
   const int it = rem % J.itiles; rem /= J.itiles;
   const int ot = rem % J.otiles, ks = rem / J.otiles;
-  if (J.ro == 2) wide_wgrad_tile<2>(J, a.B, ot, it, ks, tid);
-  else wide_wgrad_tile<1>(J, a.B, ot, it, ks, tid);
+  if (J.ro == 2) wide_wgrad_tile<2>(J, a.B, ot, it, ks, tid >> 6, tid & 63, wide_wl);
+  else wide_wgrad_tile<1>(J, a.B, ot, it, ks, tid >> 6, tid & 63, wide_wl);
 }
 
 inline int wide_dp(int D) { return (D + 15) & ~15; }
@@ -587,6 +606,7 @@ extern "C" int dm_ppo_wide_grad(const DmPpoWideStep *s, void *stream) {
   hipGetDevice(&dev);
   if (lds_set_for != dev) {   // (per device: ADVICE r1)
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(wide_fwdbwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -5;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(wide_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_WG_WAVES * 8 * 4096) != hipSuccess) return -5;
     lds_set_for = dev;
   }
   const int Dp = wide_dp(s->D);
@@ -623,19 +643,19 @@ extern "C" int dm_ppo_wide_grad(const DmPpoWideStep *s, void *stream) {
     J.otiles = (O + 32 * ro - 1) / (32 * ro);
     J.itiles = (I + 32 * (8 / ro) - 1) / (32 * (8 / ro));
     int sk = 1;
-    while (sk < WIDE_MAX_SPLITK && J.otiles * J.itiles * sk * 2 <= want && (s->B / (sk * 2)) % 64 == 0) sk *= 2;
+    while (sk < WIDE_MAX_SPLITK && J.otiles * J.itiles * sk * 2 <= want && (s->B / (sk * 2)) % 64 == 0) sk *= 2;     // want: workgroups
     J.splitk = sk; J.first = first;                       // first % 8 == 0: a job's local block id & 7 is its XCD
     J.per = (J.otiles * J.itiles * sk + 7) / 8;
     first += 8 * J.per;
   };
   for (int t = 0; t < 2; t++) {
-    add(s->dz2T[t], s->h1T[t], s->gW[t][1], s->H2, s->H1, s->H1, 2, 256);
-    add(s->dz1T[t], s->xbT, s->gW[t][0], s->H1, s->D, s->D, 2, 128);
-    add(s->dz3T[t], s->h2T[t], s->gW[t][2], t ? 1 : s->A, s->H2, s->H2, 1, 32);
+    add(s->dz2T[t], s->h1T[t], s->gW[t][1], s->H2, s->H1, s->H1, 2, 64);
+    add(s->dz1T[t], s->xbT, s->gW[t][0], s->H1, s->D, s->D, 2, 16);
+    add(s->dz3T[t], s->h2T[t], s->gW[t][2], t ? 1 : s->A, s->H2, s->H2, 1, 4);
   }
   g.njobs = nj; g.nblocks = first; g.B = s->B;
   g.part = s->part; g.nblk = s->B / WIDE_R; g.A = s->A; g.log_std = s->log_std; g.vf_coef = s->vf_coef; g.ent_coef = s->ent_coef; g.stats = s->stats8;
   g.g_log_std = s->g_log_std; g.out8 = s->out8; g.loss_acc = s->loss_acc;
-  hipLaunchKernelGGL(wide_wgrad_kernel, dim3(first + 1), dim3(64), 0, st, g);
+  hipLaunchKernelGGL(wide_wgrad_kernel, dim3(first + 1), dim3(64 * WIDE_WG_WAVES), WIDE_WG_WAVES * 8 * 4096, st, g);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
