@@ -424,12 +424,18 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
 }
 
 // dW = dZ^T X for the six layers.  Operands are the TRANSPOSED arrays the chain wrote, in fragment order: AT = dZ^T (O x B),
-// XT = X^T (I x B): a wave's fragment load is 1 KB of consecutive bytes, the k-steps of a tile follow each other.  ONE wave owns a block of eight 32 x 32
-// tiles of dW — 64 x 128 (RO = 2), or 32 x 256 for the heads (RO = 1) — over its slice of the batch: per k-step 6 (9) fragment
-// loads feed 8 MFMAs, and no operand is fetched twice inside a workgroup.  (Measured alternatives: 32 x 128 per wave with four waves
-// per workgroup re-reads X four times: 87 us, bound by those reads; sixteen tiles per wave — 128 x 128 — do not register-allocate:
-// 928 spilled VGPRs, 245 us.)  Split-K over workgroups, fp32 atomics into the gradient arena (zero on entry).  The last block sums
-// the loss partials (fixed order).
+// XT = X^T (I x B): a wave's fragment load is 1 KB of consecutive bytes, the k-steps of a tile follow each other.  A workgroup of
+// four waves owns four 32 x 32 tiles of dW — 64 x 64 (RO = CI = 2), or 32 x 128 for the heads (RO = 1) — and the whole batch (or
+// 1 / splitk of it on small nets): every wave accumulates all four tiles over its quarter of the batch rows, the four partial
+// blocks meet in LDS (64 KB: two workgroups per CU) and each wave finishes one tile — a plain store when splitk == 1: no atomics,
+// fixed summation order.  Measured on the way (us per optimizer step of the [1024,512] learner, 4 096 rows):
+//   one wave per 32 x 128, four waves per workgroup re-reading X                                         216
+//   one wave per 128 x 128 (16 accumulators: 928 spilled VGPRs)                                            375
+//   one wave per 64 x 128, split-K 4-16 over workgroups with fp32 atomics                                  185 -> 132.6 (fragment order)
+//   four waves per 64 x 128 splitting the batch inside the workgroup, no atomics (128 KB LDS: 164 workgroups)  125.6
+//   ... with global split-K 2 on top (292 workgroups, atomics back)                                        136.2
+//   four waves per 64 x 64, 64 KB LDS, two workgroups per CU (328 workgroups), two-k-step ring             122.7  <- this
+// Block 0 sums the loss partials (fixed order).
 struct WideWgradJob { const unsigned short *AT, *XT; float *dW; int O, I, ldw, ro, otiles, itiles, splitk, first, per; };
 struct WideWgradArgs {
   WideWgradJob j[6];
@@ -437,10 +443,10 @@ struct WideWgradArgs {
   const float *part; int nblk, A; const float *log_std; float vf_coef, ent_coef; const float *stats; float *g_log_std, *out8, *loss_acc;
 };
 
-template <int RO>
+template <int RO, int CI>
 __device__ __forceinline__ void wide_wgrad_tile(const WideWgradJob &J, const int Bn, const int ot, const int it, const int ks, const int wave, const int lane,
                                                 float *wl) {
-  constexpr int CI = 8 / RO;
+  constexpr int NT = RO * CI;                    // 32 x 32 tiles of dW per wave (a multiple of 4)
   const int r = lane & 31, h = lane >> 5;
   const int o0 = ot * 32 * RO, i0 = it * 32 * CI;
   const size_t B = (size_t)Bn;
@@ -464,7 +470,7 @@ __device__ __forceinline__ void wide_wgrad_tile(const WideWgradJob &J, const int
       for (int j = 0; j < 16; j++) acc[p][q][j] = 0.f;
   const wide_b8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
   // two-deep ring of register blocks of two k-steps: the loads of the next block are in flight under the 16 MFMAs of this one
-  constexpr int KB = RO == 2 ? 4 : 2;
+  constexpr int KB = 2;       // (a four-k-step ring: 126.0 against 122.7 us per optimizer step)
   wide_b8 av[RO][KB], xv[CI][KB], aw[RO][KB], xw[CI][KB];
   auto load_blk = [&](wide_b8 (&A_)[RO][KB], wide_b8 (&X_)[CI][KB], const int kk) {
 #pragma unroll
@@ -491,35 +497,38 @@ __device__ __forceinline__ void wide_wgrad_tile(const WideWgradJob &J, const int
     if (kk + 2 * KB < nks) load_blk(av, xv, kk + 2 * KB);
     if (kk + KB < nks) mma_blk(aw, xw);
   }
-  // the four partial blocks meet in LDS ([wave][tile][register][lane]: lane-contiguous, conflict-free); wave w then owns tiles
-  // 2 w and 2 w + 1: fixed summation order, and with splitk == 1 a plain store (no atomics, bit-reproducible gradients)
+  // the four partial blocks meet in LDS, four tiles at a time ([wave][tile][register][lane]: lane-contiguous, conflict-free); wave w
+  // then owns tile 4 ph + w: fixed summation order, and with splitk == 1 a plain store (no atomics, bit-reproducible gradients)
 #pragma unroll
-  for (int p = 0; p < RO; p++)
+  for (int ph = 0; ph < NT / 4; ph++) {
+    if (ph) __syncthreads();
 #pragma unroll
-    for (int q = 0; q < CI; q++)
+    for (int tt = 0; tt < 4; tt++) {
+      constexpr int dummy = 0; (void)dummy;
+      const int t = 4 * ph + tt;
 #pragma unroll
-      for (int j = 0; j < 16; j++) wl[((wave * 8 + p * CI + q) << 10) + j * 64 + lane] = acc[p][q][j];
-  __syncthreads();
+      for (int j = 0; j < 16; j++) wl[((wave * 4 + tt) << 10) + j * 64 + lane] = acc[t / CI][t % CI][j];
+    }
+    __syncthreads();
+    const int t = 4 * ph + wave, p = t / CI, q = t % CI;
+    if ((i0 + 32 * q + r) < J.I) {
 #pragma unroll
-  for (int tt = 0; tt < 2; tt++) {
-    const int t = 2 * wave + tt, p = t / CI, q = t % CI;
-    if (!((i0 + 32 * q + r) < J.I)) continue;
+      for (int j = 0; j < 16; j++) {
+        float v = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < WIDE_WG_WAVES; w++) v += wl[((w * 8 + t) << 10) + j * 64 + lane];
-      const int row = o0 + 32 * p + wide_row(j, h);
-      if (row < J.O) {
-        float *dst = &J.dW[(size_t)row * J.ldw + i0 + 32 * q + r];
-        if (J.splitk == 1) *dst = v; else atomicAdd(dst, v);
+        for (int w = 0; w < WIDE_WG_WAVES; w++) v += wl[((w * 4 + wave) << 10) + j * 64 + lane];
+        const int row = o0 + 32 * p + wide_row(j, h);
+        if (row < J.O) {
+          float *dst = &J.dW[(size_t)row * J.ldw + i0 + 32 * q + r];
+          if (J.splitk == 1) *dst = v; else atomicAdd(dst, v);
+        }
       }
     }
   }
 }
 
-__global__ void __launch_bounds__(64 * WIDE_WG_WAVES) wide_wgrad_kernel(WideWgradArgs a) {
-  extern __shared__ __align__(16) float wide_wl[];      // 4 waves x 8 tiles x 4 KB
+__global__ void __launch_bounds__(64 * WIDE_WG_WAVES, 2) wide_wgrad_kernel(WideWgradArgs a) {
+  extern __shared__ __align__(16) float wide_wl[];      // 4 waves x 4 tiles x 4 KB
   const int blk = (int)blockIdx.x - 1, tid = threadIdx.x;
   if (blk < 0) {   // block 0 (dispatched first): loss scalars and the log_std gradient from the per-workgroup partials, in a fixed order
     // thread l sums the rows l, l + 256, .. of a trunk's [nblk][40] table (ten independent 16-byte loads per row: the loads of
@@ -571,8 +580,8 @@ __global__ void __launch_bounds__(64 * WIDE_WG_WAVES) wide_wgrad_kernel(WideWgra
   if ((loc >> 3) >= J.per || rem >= J.splitk * J.otiles * J.itiles) return;
   const int it = rem % J.itiles; rem /= J.itiles;
   const int ot = rem % J.otiles, ks = rem / J.otiles;
-  if (J.ro == 2) wide_wgrad_tile<2>(J, a.B, ot, it, ks, tid >> 6, tid & 63, wide_wl);
-  else wide_wgrad_tile<1>(J, a.B, ot, it, ks, tid >> 6, tid & 63, wide_wl);
+  if (J.ro == 2) wide_wgrad_tile<2, 2>(J, a.B, ot, it, ks, tid >> 6, tid & 63, wide_wl);
+  else wide_wgrad_tile<1, 4>(J, a.B, ot, it, ks, tid >> 6, tid & 63, wide_wl);
 }
 
 inline int wide_dp(int D) { return (D + 15) & ~15; }
@@ -606,7 +615,7 @@ extern "C" int dm_ppo_wide_grad(const DmPpoWideStep *s, void *stream) {
   hipGetDevice(&dev);
   if (lds_set_for != dev) {   // (per device: ADVICE r1)
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(wide_fwdbwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -5;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(wide_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_WG_WAVES * 8 * 4096) != hipSuccess) return -5;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(wide_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_WG_WAVES * 4 * 4096) != hipSuccess) return -5;
     lds_set_for = dev;
   }
   const int Dp = wide_dp(s->D);
@@ -641,7 +650,7 @@ extern "C" int dm_ppo_wide_grad(const DmPpoWideStep *s, void *stream) {
     WideWgradJob &J = g.j[nj++];
     J.AT = (const unsigned short *)AT; J.XT = (const unsigned short *)XT; J.dW = dW; J.O = O; J.I = I; J.ldw = ldw; J.ro = ro;
     J.otiles = (O + 32 * ro - 1) / (32 * ro);
-    J.itiles = (I + 32 * (8 / ro) - 1) / (32 * (8 / ro));
+    J.itiles = (I + 32 * (4 / ro) - 1) / (32 * (4 / ro));
     int sk = 1;
     while (sk < WIDE_MAX_SPLITK && J.otiles * J.itiles * sk * 2 <= want && (s->B / (sk * 2)) % 64 == 0) sk *= 2;     // want: workgroups
     J.splitk = sk; J.first = first;                       // first % 8 == 0: a job's local block id & 7 is its XCD
@@ -649,13 +658,13 @@ extern "C" int dm_ppo_wide_grad(const DmPpoWideStep *s, void *stream) {
     first += 8 * J.per;
   };
   for (int t = 0; t < 2; t++) {
-    add(s->dz2T[t], s->h1T[t], s->gW[t][1], s->H2, s->H1, s->H1, 2, 64);
-    add(s->dz1T[t], s->xbT, s->gW[t][0], s->H1, s->D, s->D, 2, 16);
+    add(s->dz2T[t], s->h1T[t], s->gW[t][1], s->H2, s->H1, s->H1, 2, 128);
+    add(s->dz1T[t], s->xbT, s->gW[t][0], s->H1, s->D, s->D, 2, 32);
     add(s->dz3T[t], s->h2T[t], s->gW[t][2], t ? 1 : s->A, s->H2, s->H2, 1, 4);
   }
   g.njobs = nj; g.nblocks = first; g.B = s->B;
   g.part = s->part; g.nblk = s->B / WIDE_R; g.A = s->A; g.log_std = s->log_std; g.vf_coef = s->vf_coef; g.ent_coef = s->ent_coef; g.stats = s->stats8;
   g.g_log_std = s->g_log_std; g.out8 = s->out8; g.loss_acc = s->loss_acc;
-  hipLaunchKernelGGL(wide_wgrad_kernel, dim3(first + 1), dim3(64 * WIDE_WG_WAVES), WIDE_WG_WAVES * 8 * 4096, st, g);
+  hipLaunchKernelGGL(wide_wgrad_kernel, dim3(first + 1), dim3(64 * WIDE_WG_WAVES), WIDE_WG_WAVES * 4 * 4096, st, g);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
