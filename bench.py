@@ -272,7 +272,7 @@ def ppo_loop_record(args, dev, local_rank, rank, world, launched, barrier):
     rec = {"motion": motion, "envs_per_gpu": args.envs, "horizon": 32, "epochs": 20, "minibatch": 4096, "n_gpus": world,
            "timed_iterations": args.ppo_iters, "window": "PPO iterations 1..%d (iteration 0 untimed: graph capture), 32 env steps each, "
                                                          "fresh envs, untrained policy" % args.ppo_iters}
-    for arch, mdt in (((256, 128), torch.float32), ((1024, 512), torch.float32), ((1024, 512), torch.bfloat16)):
+    for arch, mdt in (((256, 128), torch.float32), ((256, 128), torch.bfloat16), ((1024, 512), torch.float32), ((1024, 512), torch.bfloat16)):
         key = "%d,%d" % arch + ("" if mdt == torch.float32 else " bf16-gemm")     # bf16-gemm: mixed-precision learner (dm_ppo_wide_grad)
         env = ppo = err = None
         try:

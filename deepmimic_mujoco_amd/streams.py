@@ -24,11 +24,21 @@ def _serialized(torch, device, a, b, cycles=600_000):
     return two > 1.6 * one
 
 
+_CACHE = {}
+
+
 def concurrent_streams(device, k, max_candidates=24):
     """k streams on `device` (a torch.device) that pairwise execute concurrently; falls back to whatever it has after
-    `max_candidates` tries (the result is then correct but may not overlap)."""
+    `max_candidates` tries (the result is then correct but may not overlap).  The set is found once per process and device and
+    shared by every caller (a process has few hardware queues: every further stream raises the odds of sharing one; users order
+    their work with events, so sharing streams between them is safe)."""
     import torch
-    chosen, spare = [], []
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    have = _CACHE.setdefault(key, [])
+    if len(have) >= k:
+        return have[:k]
+    chosen, spare = list(have), []
     for _ in range(max_candidates):
         if len(chosen) == k:
             break
@@ -39,4 +49,5 @@ def concurrent_streams(device, k, max_candidates=24):
             spare.append(c)
     while len(chosen) < k:
         chosen.append(spare.pop() if spare else torch.cuda.Stream(device=device))
-    return chosen
+    _CACHE[key] = chosen
+    return chosen[:k]
