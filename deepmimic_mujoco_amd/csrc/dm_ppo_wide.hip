@@ -39,6 +39,14 @@ __device__ __forceinline__ unsigned short wide_f2bf(float x) {  // round to near
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
 }
+// two floats -> two bf16 in one dword (low half = a): gfx950's v_cvt_pk_bf16_f32, round to nearest even like wide_f2bf
+typedef __bf16 wide_bf2 __attribute__((ext_vector_type(2)));
+typedef float wide_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned wide_pk2(float a, float b) {
+  const wide_f2 v = {a, b};
+  const wide_bf2 r = __builtin_convertvector(v, wide_bf2);
+  return *reinterpret_cast<const unsigned *>(&r);
+}
 __device__ __forceinline__ float wide_bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 __device__ __forceinline__ float wide_tanh(float x) { return 1.f - __fdividef(2.f, 1.f + __expf(2.f * x)); }
 __device__ __forceinline__ int wide_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
@@ -51,6 +59,11 @@ __device__ __forceinline__ wide_b8 wide_ldfrag(const unsigned short *M, int t, i
   return *reinterpret_cast<const wide_b8 *>(M + ((((size_t)t * nks + ks) * 64 + lane) << 3));
 }
 
+#ifdef WIDE_PROFILE   // diagnostic build: s_memtime at the phase boundaries of workgroup 0 (thread 0), printed at the end
+#define WPROF(k) do { if (tid == 0 && blockIdx.x == 0) wprof[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WPROF(k) do {} while (0)
+#endif
 constexpr int WIDE_WG_WAVES = 4;        // waves of a weight-gradient workgroup: each takes a quarter of the workgroup's batch slice
 constexpr int WIDE_MAX_SPLITK = 8;      // more slices than this and the fp32 atomics into one tile queue up (sk = 64 on a [256,128] net: 46 us)
 constexpr int WIDE_R = 32, WIDE_NW = 8, WIDE_THREADS = 64 * WIDE_NW, WIDE_PART = 40;
@@ -127,15 +140,32 @@ struct WideArgs {
 // lane — as 8 bytes of the transposed (features x batch) array in fragment order
 __device__ __forceinline__ void wide_store_t4(unsigned short *T, size_t B, int col, int row0, float v0, float v1, float v2, float v3) {
   uint2 u;
-  u.x = (unsigned)wide_f2bf(v0) | ((unsigned)wide_f2bf(v1) << 16);
-  u.y = (unsigned)wide_f2bf(v2) | ((unsigned)wide_f2bf(v3) << 16);
+  u.x = wide_pk2(v0, v1);
+  u.y = wide_pk2(v2, v3);
   *reinterpret_cast<uint2 *>(T + wide_frag(col, row0, (int)(B >> 4))) = u;
+}
+
+// the same four values also into the LDS copy of the activations (rows row0 .. row0 + 3 of column col, row stride `stride` bytes)
+__device__ __forceinline__ void wide_put4(char *L, int stride, int lrow0, int col, unsigned short *T, size_t B, int grow0, float v0, float v1,
+                                          float v2, float v3) {
+  uint2 u;
+  u.x = wide_pk2(v0, v1);
+  u.y = wide_pk2(v2, v3);
+  char *p = L + lrow0 * stride + 2 * col;
+  *reinterpret_cast<unsigned short *>(p) = (unsigned short)u.x;
+  *reinterpret_cast<unsigned short *>(p + stride) = (unsigned short)(u.x >> 16);
+  *reinterpret_cast<unsigned short *>(p + 2 * stride) = (unsigned short)u.y;
+  *reinterpret_cast<unsigned short *>(p + 3 * stride) = (unsigned short)(u.y >> 16);
+  *reinterpret_cast<uint2 *>(T + wide_frag(col, grow0, (int)(B >> 4))) = u;
 }
 
 __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
   extern __shared__ __align__(16) char wide_lds[];
   // workgroups go round the eight XCDs in launch order: even XCDs take the policy trunk, odd ones the value trunk, so an XCD's L2
   // streams ONE trunk's 2.3 MB of weights (both trunks: 4.6 MB against 4 MB of L2)
+#ifdef WIDE_PROFILE
+  unsigned long long wprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   const int nt = a.B / WIDE_R, id = blockIdx.x;
   int trunk, tile;
   if ((nt & 3) == 0) { const int xcd = id & 7; trunk = xcd & 1; tile = (id >> 3) * 4 + (xcd >> 1); }
@@ -153,6 +183,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
   const unsigned short *W1 = a.pk[trunk], *W2 = W1 + (size_t)H1 * Dp, *W2T = W2 + (size_t)H2 * H1, *W3 = W2T + (size_t)H1 * H2,
                        *W3T = W3 + 32 * (size_t)H2;
 
+  WPROF(0);
   // ---- observations -> bf16 rows (zero-padded to Dp); trunk 0 also files them, transposed, for the weight gradient of layer 1
   for (int i = tid; i < WIDE_R * Dp; i += WIDE_THREADS) {
     const int k = i >> 5, m = i & 31;                                  // (consecutive threads: consecutive rows of one column)
@@ -162,31 +193,52 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
   }
   __syncthreads();
 
+  WPROF(1);
   // ---- layer 1: H1 = tanh(X W1^T + b1).  A = X rows from LDS (lane: row r, k = 8 h + j), B = W1 rows from L2 (lane: column r)
-  for (int t = wave; t < (H1 >> 5); t += WIDE_NW) {
-    wide_f16 acc;
+  // (the weight fragments of a tile — at most seven k-steps — are requested together, and those of the wave's NEXT tile before this
+  // tile's MFMAs: with one load per k-step inside the loop every MFMA waited for its own L2 round trip and this layer, a ninth of
+  // layer 2's work, took as long as layer 2: 25 k of the kernel's 102 k ticks)
+  {
+    const int nks1 = Dp >> 4, ntile = H1 >> 5;
+    const wide_b8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    wide_b8 pa[7], pb[7];
+    float ba = 0.f, bb = 0.f;                     // the tile's bias travels with its weights (a load after the MFMAs is an exposed round trip)
+    auto ld = [&](wide_b8 (&P)[7], float &bias, const int t) {
 #pragma unroll
-    for (int j = 0; j < 16; j++) acc[j] = 0.f;
-    for (int ks = 0; ks < (Dp >> 4); ks++) {
-      const wide_b8 av = *reinterpret_cast<const wide_b8 *>(Xs + r * SX + (ks * 16 + 8 * h) * 2);
-      const wide_b8 bv = wide_ldfrag(W1, t, ks, Dp >> 4, lane);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
-    }
-    const float bias = a.b1[trunk][t * 32 + r];
-    const int n = t * 32 + r;
+      for (int ks = 0; ks < 7; ks++) P[ks] = wide_ldfrag(W1, t, ks < nks1 ? ks : nks1 - 1, nks1, lane);   // no branch: a repeated fragment, unused
+      bias = a.b1[trunk][t * 32 + r];
+    };
+    auto run = [&](const wide_b8 (&P)[7], const float bias, const int t) {
+      wide_f16 acc;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      float v[4];
+      for (int j = 0; j < 16; j++) acc[j] = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        v[i] = wide_tanh(acc[4 * q + i] + bias);
-        *reinterpret_cast<unsigned short *>(H1s + (8 * q + 4 * h + i) * S1 + 2 * n) = wide_f2bf(v[i]);
+      for (int ks = 0; ks < 7; ks++) {   // straight-line: the k-steps beyond Dp multiply by a zero A fragment
+        const wide_b8 a0 = *reinterpret_cast<const wide_b8 *>(Xs + r * SX + ((ks < nks1 ? ks : 0) * 16 + 8 * h) * 2);
+        const wide_b8 av = ks < nks1 ? a0 : zero8;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, P[ks], acc, 0, 0, 0);
       }
-      wide_store_t4(a.h1T[trunk], B, n, b0 + 8 * q + 4 * h, v[0], v[1], v[2], v[3]);
+      const int n = t * 32 + r;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = wide_tanh(acc[4 * q + i] + bias);
+        wide_put4(H1s, S1, 8 * q + 4 * h, n, a.h1T[trunk], B, b0 + 8 * q + 4 * h, v[0], v[1], v[2], v[3]);
+      }
+    };
+    int t = wave;
+    if (t < ntile) ld(pa, ba, t);
+    for (; t < ntile; t += 2 * WIDE_NW) {
+      if (t + WIDE_NW < ntile) ld(pb, bb, t + WIDE_NW);
+      run(pa, ba, t);
+      if (t + 2 * WIDE_NW < ntile) ld(pa, ba, t + 2 * WIDE_NW);
+      if (t + WIDE_NW < ntile) run(pb, bb, t + WIDE_NW);
     }
   }
   __syncthreads();
 
+  WPROF(2);
   // ---- layer 2: H2 = tanh(H1 W2^T + b2): two 32-column tiles per wave per pass share every A fragment; the weight rows stream
   // from L2 through a two-deep ring of register blocks (eight k-steps each), so sixteen loads per lane are always in flight
   for (int t0 = 2 * wave; t0 < (H2 >> 5); t0 += 2 * WIDE_NW) {
@@ -194,6 +246,8 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
 #pragma unroll
     for (int j = 0; j < 16; j++) { acc0[j] = 0.f; acc1[j] = 0.f; }
     const char *ap = H1s + r * S1 + 16 * h;
+    const int n0 = t0 * 32 + r, n1 = n0 + 32;
+    const float bias0 = a.b2[trunk][n0], bias1 = a.b2[trunk][n1];      // requested with the first weights, used after the k loop
     // fragments of tile t0 / t0 + 1: k-step ks at wr + ks * 512 elements (1 KB per wave), consecutive k-steps consecutive in memory
     const unsigned short *wr0 = W2 + ((size_t)t0 * (H1 >> 4) * 64 + lane) * 8, *wr1 = wr0 + (size_t)(H1 >> 4) * 512;
     constexpr int KB = 8;
@@ -221,23 +275,18 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, q1[i], acc1, 0, 0, 0);
       }
     }
-    const int n0 = t0 * 32 + r, n1 = n0 + 32;
-    const float bias0 = a.b2[trunk][n0], bias1 = a.b2[trunk][n1];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       float v[4], w[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        v[i] = wide_tanh(acc0[4 * q + i] + bias0); w[i] = wide_tanh(acc1[4 * q + i] + bias1);
-        *reinterpret_cast<unsigned short *>(H2s + (8 * q + 4 * h + i) * S2 + 2 * n0) = wide_f2bf(v[i]);
-        *reinterpret_cast<unsigned short *>(H2s + (8 * q + 4 * h + i) * S2 + 2 * n1) = wide_f2bf(w[i]);
-      }
-      wide_store_t4(a.h2T[trunk], B, n0, b0 + 8 * q + 4 * h, v[0], v[1], v[2], v[3]);
-      wide_store_t4(a.h2T[trunk], B, n1, b0 + 8 * q + 4 * h, w[0], w[1], w[2], w[3]);
+      for (int i = 0; i < 4; i++) { v[i] = wide_tanh(acc0[4 * q + i] + bias0); w[i] = wide_tanh(acc1[4 * q + i] + bias1); }
+      wide_put4(H2s, S2, 8 * q + 4 * h, n0, a.h2T[trunk], B, b0 + 8 * q + 4 * h, v[0], v[1], v[2], v[3]);
+      wide_put4(H2s, S2, 8 * q + 4 * h, n1, a.h2T[trunk], B, b0 + 8 * q + 4 * h, w[0], w[1], w[2], w[3]);
     }
   }
   __syncthreads();
 
+  WPROF(3);
   // ---- head: out = H2 W3^T (32 columns, padded): K split over the eight waves, partial tiles summed through LDS
   {
     wide_f16 acc;
@@ -263,6 +312,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
   }
   __syncthreads();
 
+  WPROF(4);
   // ---- loss (arithmetic of ppo_loss_kernel): a half-wave per row, lane = action index; d out -> dZ3s (bf16) and, transposed, HBM
   {
     const int j = tid & 31, hw = tid >> 5;                    // 16 half-waves, two rows each
@@ -325,6 +375,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
     atomicAdd(&a.gb3[trunk][tid], s);
   }
 
+  WPROF(5);
   // ---- d layer 2: dZ2 = (dZ3 W3) x (1 - H2^2).  A = dZ3 rows (K = 32: two k-steps), B[k = a][col = n] = W3T row n
   for (int t0 = 2 * wave; t0 < (H2 >> 5); t0 += 2 * WIDE_NW) {
     wide_f16 acc0, acc1;
@@ -349,17 +400,16 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
         const float x1 = wide_bf2f(*reinterpret_cast<const unsigned short *>(H2s + m * S2 + 2 * n1));
         v[i] = acc0[4 * q + i] * (1.f - x0 * x0); w[i] = acc1[4 * q + i] * (1.f - x1 * x1);
         s0 += v[i]; s1 += w[i];
-        *reinterpret_cast<unsigned short *>(dZ2s + m * S2 + 2 * n0) = wide_f2bf(v[i]);
-        *reinterpret_cast<unsigned short *>(dZ2s + m * S2 + 2 * n1) = wide_f2bf(w[i]);
       }
-      wide_store_t4(a.dz2T[trunk], B, n0, b0 + 8 * q + 4 * h, v[0], v[1], v[2], v[3]);
-      wide_store_t4(a.dz2T[trunk], B, n1, b0 + 8 * q + 4 * h, w[0], w[1], w[2], w[3]);
+      wide_put4(dZ2s, S2, 8 * q + 4 * h, n0, a.dz2T[trunk], B, b0 + 8 * q + 4 * h, v[0], v[1], v[2], v[3]);
+      wide_put4(dZ2s, S2, 8 * q + 4 * h, n1, a.dz2T[trunk], B, b0 + 8 * q + 4 * h, w[0], w[1], w[2], w[3]);
     }
     s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32);
     if (h == 0) { atomicAdd(&a.gb2[trunk][n0], s0); atomicAdd(&a.gb2[trunk][n1], s1); }
   }
   __syncthreads();
 
+  WPROF(6);
   // ---- d layer 1: dZ1 = (dZ2 W2) x (1 - H1^2).  A = dZ2 rows (K = H2), B[k = n][col = k1] = W2T row k1; four 32-column tiles per
   // wave share every A fragment; weight rows through a two-deep ring of four-k-step register blocks
   for (int t0 = 4 * wave; t0 < (H1 >> 5); t0 += 4 * WIDE_NW) {
@@ -421,6 +471,13 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
       if (h == 0) atomicAdd(&a.gb1[trunk][n], s);
     }
   }
+#ifdef WIDE_PROFILE
+  __syncthreads();
+  WPROF(7);
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    printf("wide_fwdbwd wg0 ticks: obs %llu layer1 %llu layer2 %llu head %llu loss %llu dlayer2 %llu dlayer1 %llu\n", wprof[1] - wprof[0], wprof[2] - wprof[1],
+           wprof[3] - wprof[2], wprof[4] - wprof[3], wprof[5] - wprof[4], wprof[6] - wprof[5], wprof[7] - wprof[6]);
+#endif
 }
 
 // dW = dZ^T X for the six layers.  Operands are the TRANSPOSED arrays the chain wrote, in fragment order: AT = dZ^T (O x B),
