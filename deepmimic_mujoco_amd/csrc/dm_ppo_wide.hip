@@ -64,6 +64,7 @@ __device__ __forceinline__ wide_b8 wide_ldfrag(const unsigned short *M, int t, i
 #else
 #define WPROF(k) do {} while (0)
 #endif
+constexpr int WIDE_BIAS_WGRAD_H1 = 512; // from this first-layer width up the bias gradients come from the weight-gradient launch
 constexpr int WIDE_WG_WAVES = 4;        // waves of a weight-gradient workgroup: each takes a quarter of the workgroup's batch slice
 constexpr int WIDE_MAX_SPLITK = 8;      // more slices than this and the fp32 atomics into one tile queue up (sk = 64 on a [256,128] net: 46 us)
 constexpr int WIDE_R = 32, WIDE_NW = 8, WIDE_THREADS = 64 * WIDE_NW, WIDE_PART = 40;
@@ -134,6 +135,7 @@ struct WideArgs {
   unsigned short *xbT, *h1T[2], *dz1T[2], *h2T[2], *dz2T[2], *dz3T[2];   // [features][B] bf16
   float *part;
   float clip, vf_coef;
+  int bias_in_chain;               // 1: the chain adds its 32-row column sums of dZ to the bias gradients (small nets); 0: the weight-gradient launch forms them
 };
 
 // four consecutive batch rows row0 .. row0 + 3 (row0 % 4 == 0) of one feature column — accumulator registers 4 q .. 4 q + 3 of a
@@ -368,8 +370,11 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
     for (int i = 0; i < 16; i++) t += accs[i * 36 + tid];
     a.part[((size_t)trunk * nt + tile) * WIDE_PART + tid] = t;
   }
-  // bias gradient of the head: column sums of dZ3 over the workgroup's rows
-  if (tid < At) {
+  // bias gradients = column sums of dZ.  Wide nets: the weight-gradient launch forms them with one more MFMA per k-step against a
+  // fragment of ones (128 workgroups adding 32-row partial sums to the same 1 024 addresses from here cost d layer 1 ~15 % of its
+  // time: 117.5 -> 112.4 us per optimizer step); narrow nets keep the sums here (their few weight-gradient tiles would carry the
+  // extra MFMAs on the critical path: [256,128] 59.6 -> 65.2 us)
+  if (a.bias_in_chain && tid < At) {
     float s = 0.f;
     for (int m = 0; m < WIDE_R; m++) s += wide_bf2f(*reinterpret_cast<const unsigned short *>(dZ3s + m * S3 + 2 * tid));
     atomicAdd(&a.gb3[trunk][tid], s);
@@ -399,13 +404,15 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
         const float x0 = wide_bf2f(*reinterpret_cast<const unsigned short *>(H2s + m * S2 + 2 * n0));
         const float x1 = wide_bf2f(*reinterpret_cast<const unsigned short *>(H2s + m * S2 + 2 * n1));
         v[i] = acc0[4 * q + i] * (1.f - x0 * x0); w[i] = acc1[4 * q + i] * (1.f - x1 * x1);
-        s0 += v[i]; s1 += w[i];
       }
       wide_put4(dZ2s, S2, 8 * q + 4 * h, n0, a.dz2T[trunk], B, b0 + 8 * q + 4 * h, v[0], v[1], v[2], v[3]);
       wide_put4(dZ2s, S2, 8 * q + 4 * h, n1, a.dz2T[trunk], B, b0 + 8 * q + 4 * h, w[0], w[1], w[2], w[3]);
+      s0 += (v[0] + v[1]) + (v[2] + v[3]); s1 += (w[0] + w[1]) + (w[2] + w[3]);
     }
-    s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32);
-    if (h == 0) { atomicAdd(&a.gb2[trunk][n0], s0); atomicAdd(&a.gb2[trunk][n1], s1); }
+    if (a.bias_in_chain) {
+      s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32);
+      if (h == 0) { atomicAdd(&a.gb2[trunk][n0], s0); atomicAdd(&a.gb2[trunk][n1], s1); }
+    }
   }
   __syncthreads();
 
@@ -454,8 +461,8 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      float s = 0.f;
       const int n = (t0 + q) * 32 + r;
+      float s = 0.f;
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         float v[4];
@@ -463,12 +470,14 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
         for (int i = 0; i < 4; i++) {
           const float x = wide_bf2f(*reinterpret_cast<const unsigned short *>(H1s + (8 * g + 4 * h + i) * S1 + 2 * n));
           v[i] = acc[q][4 * g + i] * (1.f - x * x);
-          s += v[i];
         }
         wide_store_t4(a.dz1T[trunk], B, n, b0 + 8 * g + 4 * h, v[0], v[1], v[2], v[3]);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
       }
-      s += __shfl_xor(s, 32);
-      if (h == 0) atomicAdd(&a.gb1[trunk][n], s);
+      if (a.bias_in_chain) {
+        s += __shfl_xor(s, 32);
+        if (h == 0) atomicAdd(&a.gb1[trunk][n], s);
+      }
     }
   }
 #ifdef WIDE_PROFILE
@@ -493,7 +502,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) wide_fwdbwd_kernel(WideArgs a) {
 //   ... with global split-K 2 on top (292 workgroups, atomics back)                                        136.2
 //   four waves per 64 x 64, 64 KB LDS, two workgroups per CU (328 workgroups), two-k-step ring             122.7  <- this
 // Block 0 sums the loss partials (fixed order).
-struct WideWgradJob { const unsigned short *AT, *XT; float *dW; int O, I, ldw, ro, otiles, itiles, splitk, first, per; };
+struct WideWgradJob { const unsigned short *AT, *XT; float *dW, *db; int O, I, ldw, ro, otiles, itiles, splitk, first, per; };
 struct WideWgradArgs {
   WideWgradJob j[6];
   int njobs, nblocks, B;
@@ -525,6 +534,15 @@ __device__ __forceinline__ void wide_wgrad_tile(const WideWgradJob &J, const int
     for (int q = 0; q < CI; q++)
 #pragma unroll
       for (int j = 0; j < 16; j++) acc[p][q][j] = 0.f;
+  // bias gradient db = dZ^T 1: the workgroups of the first input tile multiply their dZ^T fragments by a fragment of ones as well
+  // (every column of that 32 x 32 product is the row sum; bf16 1.0 = 0x3F80)
+  const bool bias = J.db != nullptr && it == 0;
+  const wide_b8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  wide_f16 accb[RO];
+#pragma unroll
+  for (int p = 0; p < RO; p++)
+#pragma unroll
+    for (int j = 0; j < 16; j++) accb[p][j] = 0.f;
   const wide_b8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
   // two-deep ring of register blocks of two k-steps: the loads of the next block are in flight under the 16 MFMAs of this one
   constexpr int KB = 2;       // (a four-k-step ring: 126.0 against 122.7 us per optimizer step)
@@ -545,6 +563,12 @@ __device__ __forceinline__ void wide_wgrad_tile(const WideWgradJob &J, const int
       for (int p = 0; p < RO; p++)
 #pragma unroll
         for (int q = 0; q < CI; q++) acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[p][i], X_[q][i], acc[p][q], 0, 0, 0);
+    if (bias) {
+#pragma unroll
+      for (int i = 0; i < KB; i++)
+#pragma unroll
+        for (int p = 0; p < RO; p++) accb[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[p][i], ones, accb[p], 0, 0, 0);
+    }
   };
   const int nks = (u1 - u0) * 4;                     // k-steps of 16 rows: a multiple of 4 (of KB), possibly 0
   if (nks > 0) load_blk(av, xv, 0);
@@ -553,6 +577,15 @@ __device__ __forceinline__ void wide_wgrad_tile(const WideWgradJob &J, const int
     mma_blk(av, xv);
     if (kk + 2 * KB < nks) load_blk(av, xv, kk + 2 * KB);
     if (kk + KB < nks) mma_blk(aw, xw);
+  }
+  if (bias && r == 0) {
+#pragma unroll
+    for (int p = 0; p < RO; p++)
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const int row = o0 + 32 * p + wide_row(j, h);
+        if (row < J.O) atomicAdd(&J.db[row], accb[p][j]);      // 4 waves x splitk adds per address
+      }
   }
   // the four partial blocks meet in LDS, four tiles at a time ([wave][tile][register][lane]: lane-contiguous, conflict-free); wave w
   // then owns tile 4 ph + w: fixed summation order, and with splitk == 1 a plain store (no atomics, bit-reproducible gradients)
@@ -698,14 +731,16 @@ extern "C" int dm_ppo_wide_grad(const DmPpoWideStep *s, void *stream) {
     a.dz2T[t] = (unsigned short *)s->dz2T[t]; a.dz3T[t] = (unsigned short *)s->dz3T[t];
   }
   a.xbT = (unsigned short *)s->xbT; a.part = s->part; a.clip = s->clip_range; a.vf_coef = s->vf_coef;
+  const bool bias_wgrad = s->H1 >= WIDE_BIAS_WGRAD_H1;
+  a.bias_in_chain = bias_wgrad ? 0 : 1;
   hipLaunchKernelGGL(wide_fwdbwd_kernel, dim3(2 * (s->B / WIDE_R)), dim3(WIDE_THREADS), lds, st, a);
   // weight gradients: per trunk dW2 (the big one), dW1, dW3; split-K chosen so that every job brings ~64-128 workgroups
   WideWgradArgs g;
   memset(&g, 0, sizeof g);
   int first = 0, nj = 0;
-  auto add = [&](const void *AT, const void *XT, float *dW, int O, int I, int ldw, int ro, int want) {
+  auto add = [&](const void *AT, const void *XT, float *dW, float *db, int O, int I, int ldw, int ro, int want) {
     WideWgradJob &J = g.j[nj++];
-    J.AT = (const unsigned short *)AT; J.XT = (const unsigned short *)XT; J.dW = dW; J.O = O; J.I = I; J.ldw = ldw; J.ro = ro;
+    J.AT = (const unsigned short *)AT; J.XT = (const unsigned short *)XT; J.dW = dW; J.db = db; J.O = O; J.I = I; J.ldw = ldw; J.ro = ro;
     J.otiles = (O + 32 * ro - 1) / (32 * ro);
     J.itiles = (I + 32 * (4 / ro) - 1) / (32 * (4 / ro));
     int sk = 1;
@@ -715,9 +750,9 @@ extern "C" int dm_ppo_wide_grad(const DmPpoWideStep *s, void *stream) {
     first += 8 * J.per;
   };
   for (int t = 0; t < 2; t++) {
-    add(s->dz2T[t], s->h1T[t], s->gW[t][1], s->H2, s->H1, s->H1, 2, 128);
-    add(s->dz1T[t], s->xbT, s->gW[t][0], s->H1, s->D, s->D, 2, 32);
-    add(s->dz3T[t], s->h2T[t], s->gW[t][2], t ? 1 : s->A, s->H2, s->H2, 1, 4);
+    add(s->dz2T[t], s->h1T[t], s->gW[t][1], bias_wgrad ? s->gb[t][1] : nullptr, s->H2, s->H1, s->H1, 2, 128);
+    add(s->dz1T[t], s->xbT, s->gW[t][0], bias_wgrad ? s->gb[t][0] : nullptr, s->H1, s->D, s->D, 2, 32);
+    add(s->dz3T[t], s->h2T[t], s->gW[t][2], bias_wgrad ? s->gb[t][2] : nullptr, t ? 1 : s->A, s->H2, s->H2, 1, 4);
   }
   g.njobs = nj; g.nblocks = first; g.B = s->B;
   g.part = s->part; g.nblk = s->B / WIDE_R; g.A = s->A; g.log_std = s->log_std; g.vf_coef = s->vf_coef; g.ent_coef = s->ent_coef; g.stats = s->stats8;
