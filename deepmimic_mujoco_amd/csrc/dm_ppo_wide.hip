@@ -82,7 +82,8 @@ struct WidePackArgs {
 __global__ void __launch_bounds__(256) wide_pack_kernel(WidePackArgs a) {
   const int blk = blockIdx.x;
   if (blk == 2 * a.pack_blocks) {
-    ppo_prepare_body(a.adv, a.B, a.normalize, a.stats, a.out8, nullptr, 0);
+    if (a.B <= 8192) mlp_adv_stats(a.adv, a.B, a.normalize, a.stats, a.out8);     // every load in flight at once (dm_ppo_mlp.hip)
+    else ppo_prepare_body(a.adv, a.B, a.normalize, a.stats, a.out8, nullptr, 0);
     if (a.adam_state2 && threadIdx.x == 0) { a.adam_state2[0] = 0.f; a.adam_state2[1] += 1.f; }     // Adam's begin
     return;
   }
@@ -714,7 +715,7 @@ extern "C" int dm_ppo_wide_grad(const DmPpoWideStep *s, void *stream) {
   for (int t = 0; t < 2; t++) { for (int l = 0; l < 3; l++) p.W[t][l] = s->W[t][l]; p.pk[t] = (unsigned short *)s->wpk[t]; }
   p.D = s->D; p.Dp = Dp; p.H1 = s->H1; p.H2 = s->H2; p.A[0] = s->A; p.A[1] = 1;
   p.total = wide_packed_elems(s->D, s->H1, s->H2);
-  p.pack_blocks = 256;
+  p.pack_blocks = 1152;      // ~one 16-byte fragment per thread for the [1024,512] net (256 blocks: 11.4 us, the loop serialised four strided reads per thread)
   p.adv = s->adv; p.B = s->B; p.normalize = s->normalize_advantage; p.stats = s->stats8; p.out8 = s->out8;
   p.zero_ptr = s->zero_ptr; p.zero_floats = s->zero_ptr ? s->zero_floats : 0; p.adam_state2 = s->adam_state2;
   const int zero_blocks = (int)((p.zero_floats + 1023) / 1024);
