@@ -66,5 +66,14 @@ for i in range(140):
         est2 = w_before + (w_before.mean() * extra / t[~done].mean()) * prev_done
         print("   reset evaluation ~%.0f ticks; done among the 100 heaviest: %d; deferred-reset what-if: estimate order %.0f perfect %.0f max %.0f"
               % (extra, int(done[top].sum()), makespan(np.argsort(-est2, kind="stable"), t2), makespan(np.argsort(-t2), t2), t2.max()))
+    if i >= 100 and i % 8 == 0 and prev_done is not None and prev_t is not None:
+        # measured ticks of the previous step as the key, with the envs that were reset in it (their ticks include the evaluation
+        # at the reset state and belong to an episode that is over) keyed by the batch median instead
+        key = prev_t.copy()
+        key[prev_done] = np.median(prev_t[~prev_done])
+        print("   previous ticks with reset envs at the median: corr %.2f makespan %.0f" % (np.corrcoef(key, t)[0, 1], makespan(np.argsort(-key, kind="stable"), t)))
+        # mixture: average of the ranks under the two predictors
+        ra, rb = np.argsort(np.argsort(-key)), np.argsort(np.argsort(-w_before))
+        print("   rank average of that key and the kernel's estimate: makespan %.0f" % makespan(np.argsort(ra + rb, kind="stable"), t))
     prev_t = t
     prev_done = done
