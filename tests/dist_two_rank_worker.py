@@ -16,6 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
     ap.add_argument("--arch", default="256,128", help="hidden sizes: 256,128 (dm_ppo_mlp_grad) or 1024,512 (library-GEMM learner, BASELINE cfg3-5)")
+    ap.add_argument("--bf16", action="store_true", help="PPO(mlp_dtype=torch.bfloat16): the dm_ppo_wide_grad learner")
     args = ap.parse_args()
     arch = tuple(int(x) for x in args.arch.split(","))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -27,7 +28,9 @@ def main():
     res = {}
     for tag, dg in (("graph", True), ("eager", False)):
         env = HipDeepMimicVecEnv(64, motion="spinkick", device=0, seed=1234 + 7919 * rank)
-        ppo = PPO(env, net_arch=arch, n_steps=6, batch_size=128, n_epochs=1, seed=3, dist_graph=dg)
+        ppo = PPO(env, net_arch=arch, n_steps=6, batch_size=128, n_epochs=1, seed=3, dist_graph=dg,
+                  mlp_dtype=torch.bfloat16 if args.bf16 else torch.float32)
+        assert not args.bf16 or ppo._wide_ok
         buf = ppo.collect_rollouts()
         with torch.no_grad():
             mean = ppo.policy.action_net(ppo.policy.pi(buf["obs"].reshape(-1, 67)))

@@ -13,15 +13,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("arch", ["256,128", "1024,512"])
+@pytest.mark.parametrize("arch", ["256,128", "1024,512", "1024,512,bf16"])
 def test_two_ranks_one_gpu_flat_adam_allreduce(tmp_path, arch):
     """arch 256,128: graph A = gather + dm_ppo_mlp_grad; 1024,512 (the net BASELINE configs 3-5 name): graph A = gather + the
-    library-GEMM forward / dm_ppo_loss / backward (dm_linear_tanh, dm_tanh_linear_wgrad, ...) — VERDICT r2 item 3."""
+    library-GEMM forward / dm_ppo_loss / backward (dm_linear_tanh, dm_tanh_linear_wgrad, ...) — VERDICT r2 item 3; "1024,512,bf16":
+    graph A = gather + dm_ppo_wide_grad (PPO(mlp_dtype=torch.bfloat16), r3)."""
     import torch
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533" if arch == "256,128" else "29534", os.path.join(ROOT, "tests", "dist_two_rank_worker.py"),
-           "--out", str(tmp_path), "--arch", arch]
+           "--master-port", {"256,128": "29533", "1024,512": "29534"}.get(arch, "29535"), os.path.join(ROOT, "tests", "dist_two_rank_worker.py"),
+           "--out", str(tmp_path), "--arch", arch.replace(",bf16", "")] + (["--bf16"] if arch.endswith("bf16") else [])
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     a, b = (torch.load(os.path.join(tmp_path, "rank%d.pt" % k)) for k in (0, 1))
@@ -36,5 +37,7 @@ def test_two_ranks_one_gpu_flat_adam_allreduce(tmp_path, arch):
         assert torch.isfinite(a[tag]["params"]).all()
     assert a["graph"]["used_dist_graph"] and not a["eager"]["used_dist_graph"]
     # the captured two-graph step computes what the eager step computes
-    assert torch.allclose(a["graph"]["params"], a["eager"]["params"], rtol=1e-5, atol=1e-6)
-    assert abs(a["graph"]["loss"] - a["eager"]["loss"]) < 1e-4 * max(1.0, abs(a["eager"]["loss"]))
+    # (bf16 wide learner at this small minibatch: split-K with fp32 atomics, summation order differs from launch to launch)
+    tol = dict(rtol=1e-3, atol=1e-5) if arch.endswith("bf16") else dict(rtol=1e-5, atol=1e-6)
+    assert torch.allclose(a["graph"]["params"], a["eager"]["params"], **tol)
+    assert abs(a["graph"]["loss"] - a["eager"]["loss"]) < (1e-3 if arch.endswith("bf16") else 1e-4) * max(1.0, abs(a["eager"]["loss"]))
