@@ -11,17 +11,18 @@
 //                          activations live in LDS as bf16 (64 + 32 + 32 KB), every product is v_mfma_f32_32x32x16_bf16 with fp32
 //                          accumulation, weights stream from L2 in FRAGMENT order (below): one operand load of a wave is 1 KB of
 //                          consecutive bytes; outputs: the bf16 activations / pre-activation gradients the weight gradients need,
-//                          the bias gradients (column sums, fp32 atomics) and per-workgroup loss partials                     (1 launch)
+//                          per-workgroup loss partials, and on narrow nets the bias gradients (column sums, fp32 atomics)     (1 launch)
 //   3. wide_wgrad_kernel   dW = dZ^T X of all six layers: the chain leaves its activations and pre-activation gradients TRANSPOSED
 //                          (features x batch) in the same fragment order, written straight from the accumulator registers (four
-//                          consecutive batch rows of a column are 8 bytes of a fragment); a wave owns eight 32 x 32 tiles of dW,
-//                          split-K over workgroups, fp32 atomics into the gradient arena; its last block also sums the loss
-//                          partials                                                                                           (1 launch)
+//                          consecutive batch rows of a column are 8 bytes of a fragment); a workgroup of four waves owns four
+//                          32 x 32 tiles of dW, the waves split the batch and meet in LDS (plain stores on wide nets, split-K
+//                          with fp32 atomics only on narrow ones); the bias gradients of wide nets come from one more MFMA per
+//                          k-step against a fragment of ones; block 0 sums the loss partials                                 (1 launch)
 // Fragment order of a matrix M[N][K] (N % 32 == 0, K % 16 == 0) that feeds v_mfma_f32_32x32x16_bf16 as the operand with row / column
 // index n and reduction index k: element (n, k) lives at ((((n >> 5) * (K >> 4) + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)) * 8
 // + (k & 7)) — tile of 32 rows, k-step of 16, then the 64 lanes' 16-byte fragments in lane order.  A wave's load of one fragment is
 // base + lane * 16 bytes: eight full 128-byte lines.  (Row-major operands made every load touch 32 lines for 32 bytes each and lean
-// on the 32 KB vector L1 to hold 512 half-used lines across k-steps: 92 us for the chain, 58 us for the weight gradients.)
+// on the 32 KB vector L1 to hold 512 half-used lines across k-steps: 92 us for the chain, 58 us for the weight gradients; now 43 + 38.)
 // fp32 master weights, fp32 loss arithmetic, fp32 gradients and Adam; bf16 operands of the products only (north_star: "MFMA used
 // only for the policy-MLP GEMMs").  Included by dm_abi.hip after dm_ppo_mlp.hip.
 #include <hip/hip_runtime.h>
