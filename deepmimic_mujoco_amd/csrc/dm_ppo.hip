@@ -627,8 +627,16 @@ extern "C" int dm_ppo_gather(const long long *idx, int B, const float *obs, int 
 namespace {
 __global__ void adam_sumsq_kernel(const float *g, int n, float *state, int bump_step) {
   if (bump_step && blockIdx.x == 0 && threadIdx.x == 0) state[1] += 1.f;    // Adam's step count (read by the update launch)
-  float s = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s += g[i] * g[i];
+  // four independent chains (the loads of a thread in flight together; fixed order: a function of n and the grid only)
+  float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  const int stride = gridDim.x * blockDim.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const float a = g[i], b = g[i + stride], c = g[i + 2 * stride], d = g[i + 3 * stride];
+    s0 += a * a; s1 += b * b; s2 += c * c; s3 += d * d;
+  }
+  for (; i < n; i += stride) s0 += g[i] * g[i];
+  float s = (s0 + s1) + (s2 + s3);
   s = ppo_wave_sum(s);
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -637,8 +645,13 @@ __global__ void adam_sumsq_kernel(const float *g, int n, float *state, int bump_
 }
 __global__ void adam_update_kernel(float *p, const float *g, float *m, float *v, int n, float lr, float b1, float b2, float eps,
                                    float max_norm, float grad_scale, const float *state) {
-  float part = 0;
-  for (int i = threadIdx.x & 63; i < (int)gridDim.x; i += 64) part += state[2 + i];   // same partials, same order in every block
+  // the per-block partials of the norm, same order in every block (and on every rank); four independent chains so that the loads
+  // of a lane are in flight together — every block starts with this, and a serial loop put ~4 L2 round trips in front of the update
+  float p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+  int ip = threadIdx.x & 63;
+  for (; ip + 192 < (int)gridDim.x; ip += 256) { p0 += state[2 + ip]; p1 += state[2 + ip + 64]; p2 += state[2 + ip + 128]; p3 += state[2 + ip + 192]; }
+  for (; ip < (int)gridDim.x; ip += 64) p0 += state[2 + ip];
+  const float part = (p0 + p1) + (p2 + p3);
   // grad_scale: the gradient buffer holds grad_scale^-1 x the gradient (the SUM over ranks of an all-reduce: 1 / world); the
   // norm and every element are scaled here instead of by an extra elementwise launch after the collective
   const float total = grad_scale * sqrtf(ppo_wave_sum(part));
