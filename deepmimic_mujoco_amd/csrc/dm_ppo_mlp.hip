@@ -374,8 +374,11 @@ __global__ void __launch_bounds__(256, 2) mlp_wgrad_kernel(MlpWgradArgs a) {
       float t = 0.f;
       if (q < 252) {
         const float *p = a.part + (size_t)(col == 1 ? a.nwg : 0) * 36 + col;
-        for (int w = grp; w < a.nwg; w += 7) t += p[(size_t)w * 36];
-        tot[64 + q] = t;
+        float t1 = 0.f, t2 = 0.f, t3 = 0.f;             // four chains: the thread's loads are in flight together (fixed order)
+        int w = grp;
+        for (; w + 21 < a.nwg; w += 28) { t += p[(size_t)w * 36]; t1 += p[(size_t)(w + 7) * 36]; t2 += p[(size_t)(w + 14) * 36]; t3 += p[(size_t)(w + 21) * 36]; }
+        for (; w < a.nwg; w += 7) t += p[(size_t)w * 36];
+        tot[64 + q] = (t + t1) + (t2 + t3);
       }
       __syncthreads();
       if (q < 36) {

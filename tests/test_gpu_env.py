@@ -884,3 +884,19 @@ def test_wide_fused_learner_gradient_matches_fp32_autograd(arch, D, A, B):
     for _ in range(4):
         l1 = float(ppo._minibatch_step(obs, act, adv, ret, old_logp))
     assert l1 < l0
+
+
+def test_concurrent_streams_are_probed_and_shared():
+    """streams.concurrent_streams: k streams that the probe itself finds pairwise concurrent (two torch streams out of the pool share
+    a hardware queue about one time in six, and sub-batch pipelines on such a pair run slower than one batch), found once per
+    process and device: every caller gets the same set."""
+    import torch
+    from deepmimic_mujoco_amd import streams
+    dev = torch.device("cuda", 0)
+    a = streams.concurrent_streams(dev, 2)
+    assert len(a) == 2 and a[0].cuda_stream != a[1].cuda_stream
+    assert not streams._serialized(torch, dev, a[0], a[1])
+    b = streams.concurrent_streams(dev, 2)
+    assert [s.cuda_stream for s in a] == [s.cuda_stream for s in b]
+    c = streams.concurrent_streams(dev, 3)
+    assert [s.cuda_stream for s in c[:2]] == [s.cuda_stream for s in a] and len({s.cuda_stream for s in c}) == 3
