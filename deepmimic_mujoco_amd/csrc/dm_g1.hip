@@ -2589,6 +2589,7 @@ __device__ __forceinline__ void emit_pairs(const Dev &T, const Launch &P, const 
   int overflow = 0;
   const int nsurv = broadphase(T, PAIRCAP, overflow, lane);
   SYNC();
+  PROF(3);
   const size_t base = (size_t)env * PAIRCAP;
   int32_t *ctr = P.qctr + 4 * P.round, *tickA = P.tick, *tickB = P.tick + (size_t)P.N * PAIRCAP;
   int n_an = 0, n_pm = 0, n_mpr = 0;
@@ -2668,6 +2669,12 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_env_kernel(Launch P) {
   char *ws = P.ws + (size_t)env * WS_BYTES;
   int *wctx = reinterpret_cast<int *>(ws + WS_CTX_OFF);
   StepCtx X;
+#ifdef G1_PROFILE   // per-phase stamps of the split pipeline: accumulated over the rounds in the working set, written out by the last one
+#define G1_PROF_OUT() do { SYNC(); if (P.debug && lane < 16) P.debug[(size_t)env * DMG1_DEBUG_STRIDE + 900 + lane] = (float)S.prof[lane]; } while (0)
+  if (P.round == 0) { if (lane == 0) for (int i = 0; i < 18; i++) S.prof[i] = 0; S.prof_t = clock64(); }
+#else
+#define G1_PROF_OUT() do {} while (0)
+#endif
   if (P.round == 0) {
     if (!step_enter(P, T, env, lane, X)) { if (lane == 0) wctx[WC_FINISHED] = 1; return; }
     if (X.sim_err) {   // mj_checkPos / mj_checkVel failed: no evaluation, the task layer reports the error (and may reset the env)
@@ -2676,17 +2683,23 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_env_kernel(Launch P) {
   } else {
     if (wctx[WC_FINISHED]) return;
     ws_load(P, ws, X, lane);
+#ifdef G1_PROFILE
+    S.prof_t = clock64();      // (the time between the launches is not this env's)
+#endif
     const int ncon = gather_contacts(T, P, env, lane);            // second half of the evaluation in flight
+    PROF(13);                  // split pipeline: working-set reload is before the stamp; 13 = gather
     forward_post<true>(P, T, env, lane, ncon);
     // cost of this env in g1_env_kernel (the sort key of the next step's longest-first order): its pairs run in the other kernel, so
     // only the per-evaluation fixed part and rows x sweeps count — a row step costs about twice as much beyond 128 rows (A from L2)
     X.work += 16000 + S.info[1] * (24 + (S.info[1] > 128 ? 14 : 6) * S.info[3]);
     bool again = false;
     if (!X.after_reset) again = rk_advance(P, T, env, lane, X);
-    if (!again && !task_and_finish(P, T, env, lane, X)) { step_write_back(P, env, lane, X); if (lane == 0) wctx[WC_FINISHED] = 1; return; }
+    if (!again && !task_and_finish(P, T, env, lane, X)) { PROF(14); G1_PROF_OUT(); step_write_back(P, env, lane, X); if (lane == 0) wctx[WC_FINISHED] = 1; return; }
+    PROF(14);
   }
   forward_pre(T, lane, !X.after_reset && X.stage > 0);              // first half of the next evaluation
   emit_pairs(T, P, env, lane);
+  PROF(4);                     // split pipeline: 3 = broadphase (inside), 4 = tickets + staged geoms
   ws_save(ws, X, lane);
 }
 
@@ -2701,6 +2714,9 @@ struct NpLds { double geo[2][18]; int32_t geoi[2][6]; double rc[8][7]; double po
 
 // Narrowphase of the split pipeline: persistent one-wave workgroups pull tickets (support-query pairs first: they cost ~10 x an
 // analytic pair) until the queue is empty; one ticket = one (env, pair): its staged geoms in, its contacts out.
+// (Pulling the NEXT ticket while this one's narrowphase runs — queue head and ticket word prefetched — was 11 % SLOWER, 486 against
+// 436 us per launch: a wave inside a long MPR ticket then sits on a reserved ticket that an idle wave could have taken.  Filing the
+// geoms' integer records with the pair to save the table look-ups gained nothing either: those tables are L1 / scalar-cache hits.)
 #ifndef G1_PAIR_WAVES
 #define G1_PAIR_WAVES 2   // waves per SIMD of the pair kernel (VGPR budget 256: no spills; 168 at 3 spilled 34 and measured 2 % slower)
 #endif
