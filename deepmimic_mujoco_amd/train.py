@@ -31,10 +31,13 @@ def main(argv=None):
     ap.add_argument("--total", type=int, default=1_000_000)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--bf16-buffer", action="store_true", help="store rollout obs/actions in bf16 (config 5)")
+    ap.add_argument("--bf16-learner", action="store_true",
+                    help="PPO(mlp_dtype=bfloat16): bf16 matrix-pipe products in the learner (dm_ppo_wide_grad for [256,128] .. [1024,512]-class "
+                         "nets; fp32 master weights, loss, gradients and Adam) — 106 us instead of 378 us per optimizer step on MLP(1024,512)")
     ap.add_argument("--save", default="")
     ap.add_argument("--sub-batches", type=int, default=1,
-                    help="> 1: env sub-batches stepped as parallel chains of one captured rollout graph (measured slower "
-                         "than the plain loop on ROCm 7.2: ~5 us per graph node x 2 200 nodes)")
+                    help="> 1: the env batch as that many engines, each on its own probed concurrent HIP stream (double-buffered rollout: "
+                         "one sub-batch simulates while the policy runs on another; Unitree G1: 2 is ~10 %% faster than 1)")
     ap.add_argument("--rollout-graph", action="store_true", help="with --sub-batches > 1: capture the rollout as one hipGraph")
     ap.add_argument("--json", action="store_true", help="print a JSON throughput summary on rank 0")
     ap.add_argument("--eval-every", type=int, default=0, help="eval dashboard every N global steps (src/sb3_ppo.py:313 EVAL_N); 0 = off")
@@ -60,17 +63,20 @@ def main(argv=None):
     from .ppo import PPO
 
     motions = args.motion.split(",")
+    sb = args.sub_batches if args.envs % args.sub_batches == 0 else 1
     if args.env == "dp_combined_env":                                   # src/sb3_ppo.py:276-278
         from .combined_env import HipCombinedVecEnv
-        env = HipCombinedVecEnv(args.envs, robot=args.robot, device=local_rank, seed=1234 + 7919 * rank)
+        env = HipCombinedVecEnv(args.envs, robot=args.robot, device=local_rank, seed=1234 + 7919 * rank,
+                                **({"sub_batches": sb} if args.robot == "unitree_g1" else {}))      # (the humanoid3d variant has one engine)
     elif args.robot == "unitree_g1":                                    # src/sb3_ppo.py:274-275 with robot = "unitree_g1"
-        env = HipDeepMimicVecEnv(args.envs, motion=motions[0], robot="unitree_g1", device=local_rank, seed=1234 + 7919 * rank)
+        env = HipDeepMimicVecEnv(args.envs, motion=motions[0], robot="unitree_g1", device=local_rank, seed=1234 + 7919 * rank, sub_batches=sb)
     else:
         env = HipDeepMimicVecEnv(args.envs, motion=motions if len(motions) > 1 else motions[0], device=local_rank,
-                                 seed=1234 + 7919 * rank, sub_batches=args.sub_batches if args.envs % args.sub_batches == 0 else 1)
+                                 seed=1234 + 7919 * rank, sub_batches=sb)
     ppo = PPO(env, net_arch=tuple(int(x) for x in args.arch.split(",")), n_steps=args.horizon,
               batch_size=args.minibatch, n_epochs=args.epochs, learning_rate=args.lr, seed=args.seed,
-              buffer_dtype=torch.bfloat16 if args.bf16_buffer else torch.float32, rollout_graph=args.rollout_graph)
+              buffer_dtype=torch.bfloat16 if args.bf16_buffer else torch.float32, rollout_graph=args.rollout_graph,
+              mlp_dtype=torch.bfloat16 if args.bf16_learner else torch.float32)
     hist = []
     dash = None
     if args.eval_every > 0 and rank == 0:                               # src/sb3_ppo.py:273-313: one eval env next to the batch
