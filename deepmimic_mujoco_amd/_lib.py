@@ -26,7 +26,7 @@ EXPORTS = ["dm_default_config", "dm_create", "dm_destroy", "dm_last_error", "dm_
            "dm_set_state", "dm_get_state", "dm_get_counters", "dm_set_counters", "dm_set_debug",
            "dm_fill_random_actions", "dm_last_step_ms", "dm_enable_timing", "dm_get_work",
            "dm_set_clip_flags", "dm_obs_dim", "dm_terms_dim", "dm_get_env_clips", "dm_mean_step_ms", "dm_ppo_loss", "dm_forward", "dm_linear_wgrad", "dm_ppo_gather", "dm_flat_adam_step", "dm_policy_sample",
-           "dm_rollout_store", "dm_policy_pack", "dm_policy_forward", "dm_policy_packed_floats", "dm_ppo_mlp_grad", "dm_ppo_mlp_workspace_floats", "dm_flat_adam_update", "dm_colsum", "dm_set_seed",
+           "dm_rollout_store", "dm_policy_pack", "dm_policy_forward", "dm_policy_packed_floats", "dm_ppo_mlp_grad", "dm_ppo_mlp_workspace_floats", "dm_flat_adam_update", "dm_flat_adam_step_gather", "dm_colsum", "dm_set_seed",
            "dm_linear_tanh", "dm_tanh_linear_wgrad", "dm_tanh_bwd_colsum",
            "dm_ppo_wide_grad", "dm_ppo_wide_packed_elems", "dm_ppo_wide_dp", "dm_ppo_wide_supported"]
 
@@ -55,6 +55,13 @@ class DmPpoMlpStep(C.Structure):
                 ("W", (C.c_void_p * 3) * 2), ("b", (C.c_void_p * 3) * 2), ("gW", (C.c_void_p * 3) * 2), ("gb", (C.c_void_p * 3) * 2),
                 ("g_log_std", C.c_void_p), ("out8", C.c_void_p), ("workspace", C.c_void_p), ("workspace_floats", C.c_longlong),
                 ("zero_ptr", C.c_void_p), ("zero_floats", C.c_longlong), ("adam_state2", C.c_void_p), ("loss_acc", C.c_void_p)]
+
+
+class DmGatherSpec(C.Structure):
+    """include/deepmimic_hip.h: DmGatherSpec"""
+    _fields_ = [("idx", C.c_void_p), ("B", C.c_int32), ("D", C.c_int32), ("A", C.c_int32), ("reserved", C.c_int32),
+                ("obs", C.c_void_p), ("act", C.c_void_p), ("adv", C.c_void_p), ("ret", C.c_void_p), ("logp", C.c_void_p),
+                ("o_obs", C.c_void_p), ("o_act", C.c_void_p), ("o_adv", C.c_void_p), ("o_ret", C.c_void_p), ("o_logp", C.c_void_p)]
 
 
 class DmPpoWideStep(C.Structure):
@@ -125,6 +132,8 @@ def load_library():
     L.dm_tanh_linear_wgrad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
     L.dm_tanh_bwd_colsum.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.dm_flat_adam_update.argtypes = [vp, vp, vp, vp, i32] + [C.c_float] * 6 + [vp, i32, vp]
+    L.dm_flat_adam_step_gather.argtypes = [vp, vp, vp, vp, i32] + [C.c_float] * 6 + [vp, i32, i32, vp, vp]
+    L.dm_flat_adam_step_gather.restype = i32
     L.dm_ppo_gather.argtypes = [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.dm_get_counters.argtypes = [vp, vp, vp, vp, vp]
     L.dm_set_counters.argtypes = [vp, vp, vp, vp]

@@ -625,11 +625,28 @@ extern "C" int dm_ppo_gather(const long long *idx, int B, const float *obs, int 
 // in a FIXED order (per-block partials, then one tree every block repeats): data-parallel replicas that hold the same
 // all-reduced gradient then compute bit-identical updates (a float-atomic sum would let them drift apart by ulps).
 namespace {
-__global__ void adam_sumsq_kernel(const float *g, int n, float *state, int bump_step) {
+// Blocks [0, nsum): the partial sums of squares.  Blocks behind them (optional): the gather of the NEXT minibatch — it depends on
+// nothing this optimizer step computes, and as blocks of this launch it costs no launch of its own (a trivial launch is ~4.7 us
+// inside a graph; three other ways of hiding it lost: DESIGN 6).  Two rows per block, 128 threads each.
+struct AdamGather {
+  const long long *idx; int B, D, A;
+  const float *obs, *act, *adv, *ret, *logp;
+  float *o_obs, *o_act, *o_adv, *o_ret, *o_logp;
+};
+__global__ void adam_sumsq_kernel(const float *g, int n, float *state, int bump_step, int nsum, AdamGather G) {
+  if ((int)blockIdx.x >= nsum) {
+    const int r = 2 * ((int)blockIdx.x - nsum) + (threadIdx.x >> 7), t = threadIdx.x & 127;
+    if (r >= G.B) return;
+    const long long sr = G.idx[r];
+    for (int c = t; c < G.D; c += 128) G.o_obs[(size_t)r * G.D + c] = G.obs[(size_t)sr * G.D + c];
+    for (int c = t; c < G.A; c += 128) G.o_act[(size_t)r * G.A + c] = G.act[(size_t)sr * G.A + c];
+    if (t == 0) { G.o_adv[r] = G.adv[sr]; G.o_ret[r] = G.ret[sr]; G.o_logp[r] = G.logp[sr]; }
+    return;
+  }
   if (bump_step && blockIdx.x == 0 && threadIdx.x == 0) state[1] += 1.f;    // Adam's step count (read by the update launch)
   // four independent chains (the loads of a thread in flight together; fixed order: a function of n and the grid only)
   float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  const int stride = gridDim.x * blockDim.x;
+  const int stride = nsum * blockDim.x;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   for (; i + 3 * stride < n; i += 4 * stride) {
     const float a = g[i], b = g[i + stride], c = g[i + 2 * stride], d = g[i + 3 * stride];
@@ -683,13 +700,25 @@ __global__ void adam_update_kernel(float *p, const float *g, float *m, float *v,
 }  // namespace
 
 static int flat_adam_launch(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
-                            float max_norm, float grad_scale, float *state2, int state2_floats, void *stream, int begin) {
+                            float max_norm, float grad_scale, float *state2, int state2_floats, void *stream, int begin,
+                            const DmGatherSpec *next = nullptr) {
   if (!p || !g || !m || !v || !state2 || n < 1 || !(grad_scale > 0.f)) return -22;
   if (state2_floats < 2 + DM_ADAM_PARTIALS) return -22;   // the partial sums live behind the two scalars: a shorter buffer would be overrun
+  AdamGather G;
+  memset(&G, 0, sizeof G);
+  int gather_blocks = 0;
+  if (next) {
+    if (!next->idx || next->B < 1 || next->D < 1 || next->A < 1 || !next->obs || !next->act || !next->adv || !next->ret || !next->logp ||
+        !next->o_obs || !next->o_act || !next->o_adv || !next->o_ret || !next->o_logp) return -22;
+    G.idx = next->idx; G.B = next->B; G.D = next->D; G.A = next->A;
+    G.obs = next->obs; G.act = next->act; G.adv = next->adv; G.ret = next->ret; G.logp = next->logp;
+    G.o_obs = next->o_obs; G.o_act = next->o_act; G.o_adv = next->o_adv; G.o_ret = next->o_ret; G.o_logp = next->o_logp;
+    gather_blocks = (next->B + 1) / 2;
+  }
   hipStream_t s = (hipStream_t)stream;
   int blocks = (n + 256 * 8 - 1) / (256 * 8);
   if (blocks > DM_ADAM_PARTIALS) blocks = DM_ADAM_PARTIALS;
-  hipLaunchKernelGGL(adam_sumsq_kernel, dim3(blocks), dim3(256), 0, s, g, n, state2, begin);      // step count folded in: two launches
+  hipLaunchKernelGGL(adam_sumsq_kernel, dim3(blocks + gather_blocks), dim3(256), 0, s, g, n, state2, begin, blocks, G);   // step count folded in: two launches
   hipLaunchKernelGGL(adam_update_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, max_norm, grad_scale, state2);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
@@ -700,6 +729,11 @@ extern "C" int dm_flat_adam_step(float *p, const float *g, float *m, float *v, i
 extern "C" int dm_flat_adam_update(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
                                    float max_norm, float grad_scale, float *state2, int state2_floats, void *stream) {
   return flat_adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, max_norm, grad_scale, state2, state2_floats, stream, 0);
+}
+extern "C" int dm_flat_adam_step_gather(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
+                                        float max_norm, float grad_scale, float *state2, int state2_floats, int begin,
+                                        const DmGatherSpec *next, void *stream) {
+  return flat_adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, max_norm, grad_scale, state2, state2_floats, stream, begin ? 1 : 0, next);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -604,16 +604,29 @@ class FlatAdam:
     def grad_scale(self):
         return 1.0 / dist.get_world_size() if (dist.is_initialized() and dist.get_world_size() > 1) else 1.0
 
-    def step(self, begin=True):
-        """begin=False: state2 was prepared by dm_ppo_mlp_grad (adam_state2 fold) — two launches instead of three."""
+    def step(self, begin=True, gather_next=None):
+        """begin=False: state2 was prepared by dm_ppo_mlp_grad (adam_state2 fold) — two launches instead of three.
+        gather_next = (flat, idx, out): the gather of the NEXT minibatch (rows idx of flat["obs" | "act" | "adv" | "ret" | "logp"] ->
+        out[...]) rides on the norm launch (dm_flat_adam_step_gather): one launch less per optimizer step."""
         import ctypes as C
         from . import _lib
         p = lambda t: C.c_void_p(t.data_ptr())
         L = _lib.load_library()
-        rc = (L.dm_flat_adam_step if begin else L.dm_flat_adam_update)(p(self.flat_p), p(self.flat_g), p(self.m), p(self.v), self.n, self.lr,
-                                                   self.betas[0], self.betas[1], self.eps, self.max_grad_norm, self.grad_scale,
-                                                   p(self.state2), int(self.state2.numel()),
-                                                   C.c_void_p(torch.cuda.current_stream(self.flat_p.device).cuda_stream))
+        common = (p(self.flat_p), p(self.flat_g), p(self.m), p(self.v), self.n, self.lr, self.betas[0], self.betas[1], self.eps,
+                  self.max_grad_norm, self.grad_scale, p(self.state2), int(self.state2.numel()))
+        stream = C.c_void_p(torch.cuda.current_stream(self.flat_p.device).cuda_stream)
+        if gather_next is None:
+            rc = (L.dm_flat_adam_step if begin else L.dm_flat_adam_update)(*common, stream)
+        else:
+            flat, idx, out = gather_next
+            assert idx.dtype == torch.int64 and idx.is_contiguous()
+            for k in ("obs", "act", "adv", "ret", "logp"):
+                assert flat[k].dtype == torch.float32 and flat[k].is_contiguous() and out[k].dtype == torch.float32 and out[k].is_contiguous()
+            gs = _lib.DmGatherSpec()
+            gs.idx, gs.B, gs.D, gs.A = idx.data_ptr(), int(idx.numel()), int(flat["obs"].shape[1]), int(flat["act"].shape[1])
+            gs.obs, gs.act, gs.adv, gs.ret, gs.logp = (flat[k].data_ptr() for k in ("obs", "act", "adv", "ret", "logp"))
+            gs.o_obs, gs.o_act, gs.o_adv, gs.o_ret, gs.o_logp = (out[k].data_ptr() for k in ("obs", "act", "adv", "ret", "logp"))
+            rc = L.dm_flat_adam_step_gather(*common, int(bool(begin)), C.byref(gs), stream)
         if rc != 0:
             raise RuntimeError("dm_flat_adam_step failed (%d)" % rc)
         if self.flat_pb is not None:
@@ -1109,13 +1122,14 @@ class PPO:
         self.optimizer.gather_grads()
         return loss.detach(), True
 
-    def _minibatch_step(self, obs, act, adv, ret, old_logp):
+    def _minibatch_step(self, obs, act, adv, ret, old_logp, gather_next=None):
         if self.flat_adam:
             # clipping + Adam are one fused update on the flat buffer; with several ranks that buffer is all-reduced in between
             loss, begin = self._minibatch_grad(obs, act, adv, ret, old_logp)
             self.optimizer.all_reduce()
-            self.optimizer.step(begin=begin)
+            self.optimizer.step(begin=begin, gather_next=gather_next)
             return loss
+        assert gather_next is None
         loss = (self._loss_fused if (self.fused_loss and obs.is_cuda) else self._loss_torch)(obs, act, adv, ret, old_logp)
         # grads are re-created by backward (no zero-fill, no accumulate-add per parameter); inside a captured
         # hipGraph they live in the graph's private pool, so their addresses are the same at every replay
@@ -1235,9 +1249,15 @@ class PPO:
             self._minibatch_step(**kw)
 
         def body():
+            # one gather launch for the first minibatch; every later one rides on the previous optimizer step's norm launch (it
+            # depends on nothing that step computes, and the static minibatch was last read by that step's gradient launches)
+            ride = self.flat_adam
+            self._gather_minibatch(eg["flat"], eg["perm"][:B], gin)
             for s in range(0, n, B):
-                self._gather_minibatch(eg["flat"], eg["perm"][s:s + B], gin)
-                loss = self._minibatch_step(**kw)
+                nxt = (eg["flat"], eg["perm"][s + B:s + 2 * B], gin) if (ride and s + B < n) else None
+                loss = self._minibatch_step(gather_next=nxt, **kw)
+                if not ride and s + B < n:
+                    self._gather_minibatch(eg["flat"], eg["perm"][s + B:s + 2 * B], gin)
                 if not self._on_dev:
                     eg["loss"].add_(loss)
 

@@ -222,6 +222,18 @@ int dm_flat_adam_step(float *p, const float *g, float *m, float *v, int n, float
 int dm_flat_adam_update(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
                         float max_norm, float grad_scale, float *state2, int state2_floats, void *stream);
 
+/* the same (begin != 0: dm_flat_adam_step, else dm_flat_adam_update) with the gather of the NEXT minibatch riding on the first
+ * launch: dm_ppo_gather(next) as extra blocks of the norm launch — SB3's RolloutBuffer.get indexing [EXT] for minibatch j + 1
+ * beside clip_grad_norm_ of minibatch j, one launch less per optimizer step.  next == NULL: no gather. */
+typedef struct DmGatherSpec {
+  const long long *idx; int B, D, A, reserved;
+  const float *obs, *act, *adv, *ret, *logp;
+  float *o_obs, *o_act, *o_adv, *o_ret, *o_logp;
+} DmGatherSpec;
+int dm_flat_adam_step_gather(float *p, const float *g, float *m, float *v, int n, float lr, float beta1, float beta2, float eps,
+                             float max_norm, float grad_scale, float *state2, int state2_floats, int begin, const DmGatherSpec *next,
+                             void *stream);
+
 /* out[o] += sum_b Y[b][o] for a row-major [B x O] matrix (out zeroed by the caller, stream-ordered): the bias gradient of the
  * nn.Linear layers of PPO.train [EXT] whose weight gradient stays on the library GEMM (layers beyond 256 units). */
 int dm_colsum(const float *Y, int B, int O, float *out, void *stream);

@@ -900,3 +900,38 @@ def test_concurrent_streams_are_probed_and_shared():
     assert [s.cuda_stream for s in a] == [s.cuda_stream for s in b]
     c = streams.concurrent_streams(dev, 3)
     assert [s.cuda_stream for s in c[:2]] == [s.cuda_stream for s in a] and len({s.cuda_stream for s in c}) == 3
+
+
+def test_flat_adam_step_with_the_next_gather_riding_on_it():
+    """dm_flat_adam_step_gather: the gather of the next minibatch as extra blocks of Adam's norm launch — parameters, moments and
+    step count bit-identical to dm_flat_adam_step, gathered rows bit-identical to dm_ppo_gather."""
+    import torch
+    from deepmimic_mujoco_amd.ppo import PPO, MlpPolicy
+    dev = torch.device("cuda", 0)
+    n, B, D, A = 8192, 1024, 67, 28
+    g = torch.Generator(device=dev); g.manual_seed(23)
+    flat = dict(obs=torch.randn(n, D, device=dev, generator=g), act=torch.randn(n, A, device=dev, generator=g),
+                adv=torch.randn(n, device=dev, generator=g), ret=torch.randn(n, device=dev, generator=g), logp=torch.randn(n, device=dev, generator=g))
+    idx = torch.randperm(n, device=dev, generator=g)[:B].contiguous()
+    res = []
+    for ride in (False, True):
+        torch.manual_seed(5)
+        pol = MlpPolicy(obs_dim=D, act_dim=A, net_arch=(256, 128)).to(dev)
+        ppo = PPO(None, policy=pol, device=dev, batch_size=B, use_hip_graph=False)
+        opt = ppo.optimizer
+        gg = torch.Generator(device=dev); gg.manual_seed(99)
+        out = ppo._static_minibatch()
+        for _ in range(3):
+            opt.flat_g.copy_(torch.randn(opt.n, device=dev, generator=gg) * 0.05)
+            if ride:
+                opt.step(begin=True, gather_next=(flat, idx, out))
+            else:
+                opt.step(begin=True)
+                ppo._gather_minibatch(flat, idx, out)
+        torch.cuda.synchronize()
+        res.append((opt.flat_p.clone(), opt.m.clone(), opt.v.clone(), opt.state2[:2].clone(), {k: v.clone() for k, v in out.items()}))
+    a, b = res
+    for x, y in zip(a[:4], b[:4]):
+        assert torch.equal(x, y)
+    for k in a[4]:
+        assert torch.equal(a[4][k], b[4][k]) and torch.equal(a[4][k], flat[k][idx]), k
