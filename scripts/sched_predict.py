@@ -31,7 +31,7 @@ def makespan(order, t):
     return end
 
 
-prev_work = prev_t = prev_done = None
+prev_work = prev_t = prev_done = w_prev2 = None
 for i in range(140):
     eng.fill_random_actions(act, i)
     torch.cuda.synchronize()
@@ -75,5 +75,9 @@ for i in range(140):
         # mixture: average of the ranks under the two predictors
         ra, rb = np.argsort(np.argsort(-key)), np.argsort(np.argsort(-w_before))
         print("   rank average of that key and the kernel's estimate: makespan %.0f" % makespan(np.argsort(ra + rb, kind="stable"), t))
+    if i >= 100 and i % 8 == 0 and w_prev2 is not None:
+        # the order computed one step earlier (from the estimate of step t - 2): the schedule kernel could then run beside step t - 1
+        print("   estimate of two steps ago: corr %.2f makespan %.0f" % (np.corrcoef(w_prev2, t)[0, 1], makespan(np.argsort(-w_prev2, kind="stable"), t)))
     prev_t = t
     prev_done = done
+    w_prev2 = w_before
