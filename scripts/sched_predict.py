@@ -31,7 +31,7 @@ def makespan(order, t):
     return end
 
 
-prev_work = prev_t = prev_done = w_prev2 = None
+prev_work = prev_t = prev_done = w_prev2 = prev_last = None
 for i in range(140):
     eng.fill_random_actions(act, i)
     torch.cuda.synchronize()
@@ -78,6 +78,11 @@ for i in range(140):
     if i >= 100 and i % 8 == 0 and w_prev2 is not None:
         # the order computed one step earlier (from the estimate of step t - 2): the schedule kernel could then run beside step t - 1
         print("   estimate of two steps ago: corr %.2f makespan %.0f" % (np.corrcoef(w_prev2, t)[0, 1], makespan(np.argsort(-w_prev2, kind="stable"), t)))
+    st_all = dbg[:, 368:372].cpu().numpy()
+    if i >= 100 and i % 8 == 0 and prev_last is not None:
+        # fresher keys: the LAST RK stage of the previous step alone (ticks), and its mix with the kernel's estimate
+        print("   previous step's last-stage ticks: corr %.2f makespan %.0f" % (np.corrcoef(prev_last, t)[0, 1], makespan(np.argsort(-prev_last, kind="stable"), t)))
+    prev_last = st_all[:, 3] - st_all[:, 2]
     prev_t = t
     prev_done = done
     w_prev2 = w_before
