@@ -2691,7 +2691,7 @@ extern "C" __global__ void __launch_bounds__(64, 2) g1_env_kernel(Launch P) {
     forward_post<true>(P, T, env, lane, ncon);
     // cost of this env in g1_env_kernel (the sort key of the next step's longest-first order): its pairs run in the other kernel, so
     // only the per-evaluation fixed part and rows x sweeps count — a row step costs about twice as much beyond 128 rows (A from L2)
-    X.work += 16000 + S.info[1] * (24 + (S.info[1] > 128 ? 14 : 6) * S.info[3]);
+    X.work = (X.work >> 1) + 16000 + S.info[1] * (24 + (S.info[1] > 128 ? 14 : 6) * S.info[3]);   // (later evaluations weigh more: as dm_kernels.hip)
     bool again = false;
     if (!X.after_reset) again = rk_advance(P, T, env, lane, X);
     if (!again && !task_and_finish(P, T, env, lane, X)) { PROF(14); G1_PROF_OUT(); step_write_back(P, env, lane, X); if (lane == 0) wctx[WC_FINISHED] = 1; return; }
