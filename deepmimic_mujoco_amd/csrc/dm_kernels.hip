@@ -1756,7 +1756,8 @@ __device__ __forceinline__ void step_body(const DmLaunch &P) {
       if (it < 4) { stage_ncon |= (unsigned)(ncon & 0xFF) << (8 * it); stage_nefc |= (unsigned)(nefc & 0xFF) << (8 * it); }
       // the sort key of the next step's longest-first order: the later evaluations of the step weigh more (1/8, 1/4, 1/2, 1, and the
       // evaluation at the reset state last of all) — the key goes stale within a step (the plain sum: 13.56 M, this: 13.73 M; last only: 13.65 M)
-      work = (work >> 1) + 64 + (nefc > 0 ? 48 + 4 * nefc : 0) + nefc * solver_iter;
+      // (rows weigh 16: measured, building the rows costs twice the sweeps on average; 4 .. 32 and a wide-path surcharge: +-0.3 %)
+      work = (work >> 1) + 64 + (nefc > 0 ? 48 + 16 * nefc : 0) + nefc * solver_iter;
       if (P.f8) {   // every evaluation rewrites slots [0, ncon) of the contact array and leaves the rest
         bool rfs = false, lfs = false;
         if (lane < ncon) {
